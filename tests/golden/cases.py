@@ -1,0 +1,93 @@
+"""Case tables + seeded input builders shared by make_golden.py (reference side,
+build container) and the parity tests (oracle side and HIP side).  Data only."""
+import numpy as np
+import torch
+
+from ttdg_mgm_amd import synth
+
+AFF_CASES = ((5, 9), (9, 5), (22, 22), (40, 33))
+AFF_PARAM_SEED = 11
+MHA_CASES = (5, 22, 40)
+MHA_PARAM_SEED = 12
+HUNG_CASES = ((5, 32), (32, 32), (40, 32), (22, 35), (35, 22), (1, 7))
+PSTRIDE = 97
+
+
+def aff_inputs(ci):
+    n1, n2 = AFF_CASES[ci]
+    g = synth.gen(100 + ci)
+    X = synth.normal(g, (n1, 256), 0.5)
+    Y = synth.normal(g, (n2, 256), 0.5)
+    R = synth.normal(g, (n1, n2), 1.0)
+    return X, Y, R
+
+
+def mha_input(ci):
+    return synth.normal(synth.gen(200 + ci), (MHA_CASES[ci], 256), 1.0)
+
+
+def hung_input(ci):
+    r, c = HUNG_CASES[ci]
+    return synth.normal(synth.gen(300 + ci), (r, c), 1.0)
+
+
+GAGM_CASES = (  # name, sizes, seed
+    ("eq22", (22, 22, 22, 22), 500),
+    ("eq40", (40, 40, 40), 501),
+    ("uneq", (22, 35, 28, 40), 502),
+    ("uneq_small", (12, 30, 7), 503),
+    ("g2", (20, 26), 504),
+    ("eq32", (32, 32, 32), 505),
+)
+
+
+def gagm_inputs(sizes, seed):
+    """A: block-diagonal row-stochastic, zero diagonal; W: symmetric in [0,1]; U0: x U^T."""
+    g = synth.gen(seed)
+    Mtot = sum(sizes)
+    A = torch.zeros(Mtot, Mtot)
+    off = 0
+    for n in sizes:
+        A[off:off + n, off:off + n] = torch.softmax(synth.normal(g, (n, n), 1.0), dim=1)
+        off += n
+    A.fill_diagonal_(0)
+    Wh = torch.from_numpy(g.uniform(0, 1, size=(Mtot, Mtot)).astype(np.float32)) ** 4
+    W = (Wh + Wh.t()) * 0.5
+    U0 = synth.normal(g, (Mtot, 256), 0.1) @ synth.universe(seed + 1).t()
+    return A, W, U0
+
+
+MGM_CASES = (  # name, sizes, seed
+    ("g2", (18, 25), 600),
+    ("g3", (22, 22, 22), 601),
+    ("g4", (22, 35, 28, 40), 602),
+    ("g4eq40", (40, 40, 40, 40), 603),
+)
+
+
+
+def mgm_inputs(name):
+    for n, sizes, seed in MGM_CASES:
+        if n == name:
+            nodes, labels = synth.node_sets(seed, sizes, scale=0.5)
+            return synth.mgm3_params(seed + 50), nodes, labels, synth.universe(seed + 70), sizes
+    raise KeyError(name)
+
+
+PROTO_CASES = (  # name, image size, per-image box lists (xyxy, class) ; [] = no detections
+    ("two_obj", 384, [[(100.3, 90.2, 250.7, 260.1, 0), (140.0, 130.5, 210.2, 215.9, 1)],
+                      [(60.0, 70.0, 300.0, 310.0, 0), (120.0, 140.0, 220.0, 230.0, 1), (10.5, 12.5, 40.0, 38.0, 1)]]),
+    ("empty_mid", 384, [[(100.3, 90.2, 250.7, 260.1, 0)], [], [(50.0, 60.0, 330.0, 350.0, 1), (150.0, 150.0, 200.0, 210.0, 0)]]),
+    ("step_edge", 512, [[(200.0, 200.0, 285.0, 230.0, 0)], [(200.0, 200.0, 289.0, 230.0, 1)], [(200.0, 200.0, 293.0, 230.0, 0)],
+                        [(3.0, 3.0, 509.0, 509.0, 1)]]),
+    ("all_empty", 384, [[], []]),
+)
+
+
+
+def proto_inputs(ci):
+    name, size, per_img = PROTO_CASES[ci]
+    feats = synth.fpn_pyramid(700 + ci, len(per_img), size)
+    boxes = [torch.tensor([b[:4] for b in bx], dtype=torch.float32).reshape(-1, 4) for bx in per_img]
+    classes = [torch.tensor([b[4] for b in bx], dtype=torch.int64) for bx in per_img]
+    return name, feats, boxes, classes

@@ -1,0 +1,184 @@
+"""Generate golden vectors by running the REFERENCE's own modules (build container only).
+
+    python tests/golden/make_golden.py
+
+Imports /root/reference read-only through oracle/ref_import.py (namespace
+stubs + our Sinkhorn spec standing in for the absent pygmtools), feeds it the
+repo-owned PCG64 inputs of ttdg_mgm_amd.synth, and writes inputs-by-seed +
+reference outputs to tests/golden/*.npz.  Only data is written: no reference
+source text in any encoding.  MHA is put in .eval() (dropout off) so the
+reference is repeatable (SURVEY.md §7 'Dropout in train mode').
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_import  # noqa: E402
+from ttdg_mgm_amd import synth  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from cases import *  # noqa: E402,F401,F403
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(1)  # fixed reduction order for the goldens
+
+
+def ref_mgm3(mgm, seed):
+    m = mgm.MGM3_unsup(2, 32)
+    m.load_state_dict(synth.mgm3_params(seed), strict=True)
+    m.eval()
+    return m
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+# parameter gradients are stored as a strided sample (cases.PSTRIDE) + L2 norm: keeps fixtures small
+
+
+def pgrad(out, key, g):
+    flat = g.detach().reshape(-1)
+    out[key + "__sample"] = npy(flat[::PSTRIDE])
+    out[key + "__norm"] = npy(flat.double().norm())
+
+
+def gold_affinity(mgm):
+    out = {}
+    m = ref_mgm3(mgm, AFF_PARAM_SEED)
+    for ci, (n1, n2) in enumerate(AFF_CASES):
+        X, Y, R = aff_inputs(ci)
+        X.requires_grad_(), Y.requires_grad_()
+        m.zero_grad()
+        M = m.node_affinity(X, Y)
+        (M * R).sum().backward()
+        out[f"c{ci}_M"] = npy(M)
+        out[f"c{ci}_dX"] = npy(X.grad)
+        out[f"c{ci}_dY"] = npy(Y.grad)
+        for k, p in m.node_affinity.named_parameters():
+            pgrad(out, f"c{ci}_d_{k}", p.grad)
+    np.savez_compressed(os.path.join(OUT, "affinity.npz"), **out)
+
+
+def gold_mha(mgm):
+    out = {}
+    m = ref_mgm3(mgm, MHA_PARAM_SEED)
+    for ci, n in enumerate(MHA_CASES):
+        x = mha_input(ci)
+        _, adj = m.intra_domain_graph([x, x, x])
+        out[f"c{ci}_adj"] = npy(adj)
+    np.savez_compressed(os.path.join(OUT, "mha.npz"), **out)
+
+
+def gold_hungarian(mgm):
+    out = {}
+    for ci, (r, c) in enumerate(HUNG_CASES):
+        s = hung_input(ci)
+        out[f"c{ci}_x"] = npy(mgm.hungarian(s))
+    # structured ties: empty universe columns give exact-zero columns in V
+    g = synth.gen(320)
+    s = synth.normal(g, (12, 32), 1.0).abs()
+    s[:, [3, 7, 8, 20, 21, 22, 30]] = 0.0
+    s[4:9, :] = 0.0
+    out["ties_s"] = npy(s)
+    out["ties_x"] = npy(mgm.hungarian(s))
+    np.savez_compressed(os.path.join(OUT, "hungarian.npz"), **out)
+
+
+def gold_loss(mgm):
+    out = {}
+    crit = mgm.PermutationLoss()
+    for ci, (r, c) in enumerate(((5, 9), (22, 22), (40, 33))):
+        g = synth.gen(400 + ci)
+        s = torch.from_numpy(g.uniform(0, 1, size=(r, c)).astype(np.float32))
+        s[0, 0], s[-1, -1] = 0.0, 1.0  # exercise the clamp
+        s.requires_grad_()
+        t = torch.from_numpy((g.uniform(0, 1, size=(r, c)) < 0.1).astype(np.float32))
+        l = crit(s.unsqueeze(0), t.unsqueeze(0), torch.tensor(r), torch.tensor(c))
+        l.backward()
+        out[f"c{ci}_s"], out[f"c{ci}_t"] = npy(s), npy(t)
+        out[f"c{ci}_loss"], out[f"c{ci}_ds"] = npy(l), npy(s.grad)
+    np.savez_compressed(os.path.join(OUT, "loss.npz"), **out)
+
+
+def gold_gagm(mgm):
+    out = {}
+    solver = mgm.GA_GM(mgm_iter=[200], cluster_iter=10, sk_iter=20, sk_tau0=[0.1], sk_gamma=0.5,
+                       cluster_beta=[1.0, 0.0], converge_tol=1.0e-3, min_tau=[1.0e-2],
+                       projector0=["sinkhorn", "sinkhorn"])
+    for name, sizes, seed in GAGM_CASES:
+        A, W, U0 = gagm_inputs(sizes, seed)
+        ms = torch.tensor(sizes, dtype=torch.int)
+        Ub, cluster = solver(A, W, U0.clone(), ms, 32, 0.5, 1)
+        out[f"{name}_U"] = npy(Ub)
+        # first-iteration V exactly as multi_graph_matching.py:317-321 computes it
+        UUt = U0 @ U0.t()
+        V = torch.chain_matmul(A, UUt, A, U0) * 0.5 * 2 + W @ U0
+        out[f"{name}_V0"] = npy(V / len(sizes))
+    np.savez_compressed(os.path.join(OUT, "gagm.npz"), **out)
+
+
+def gold_mgm3(mgm):
+    out = {}
+    for name, sizes, seed in MGM_CASES:
+        params, nodes, labels, U, _ = mgm_inputs(name)
+        m = mgm.MGM3_unsup(2, 32)
+        m.load_state_dict(params, strict=True)
+        m.eval()
+        nodes = [x.requires_grad_() for x in nodes]
+        m.zero_grad()
+        loss = m(nodes, labels, U)
+        loss.backward()
+        out[f"{name}_loss"] = npy(loss)
+        for gi, x in enumerate(nodes):
+            out[f"{name}_dnode{gi}"] = npy(x.grad)
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                pgrad(out, f"{name}_d_{k}", p.grad)
+            else:
+                out[f"{name}_nograd_{k}"] = np.zeros(0, np.float32)
+    # single graph -> None (multi_graph_matching.py:489-490)
+    m = ref_mgm3(mgm, 1)
+    nodes, labels = synth.node_sets(1, (9,))
+    assert m(nodes, labels, synth.universe(2)) is None
+    assert m(None, None, synth.universe(2)) is None
+    np.savez_compressed(os.path.join(OUT, "mgm3.npz"), **out)
+
+
+def gold_proto(bg):
+    out = {}
+    pc = bg.PrototypeComputation(2, 10)
+    for ci, (name, size, per_img) in enumerate(PROTO_CASES):
+        _, feats, boxes, classes = proto_inputs(ci)
+        insts = [ref_import.FakeInstances(b, c) for b, c in zip(boxes, classes)]
+        nodes, labels = pc(feats, insts)
+        if nodes is None:
+            out[f"{name}_none"] = np.ones(1, np.int64)
+            continue
+        out[f"{name}_count"] = np.array([len(n) for n in nodes], np.int64)
+        for gi, (n, l) in enumerate(zip(nodes, labels)):
+            out[f"{name}_nodes{gi}"] = npy(n)
+            out[f"{name}_labels{gi}"] = npy(l)
+    np.savez_compressed(os.path.join(OUT, "proto.npz"), **out)
+
+
+def main():
+    mgm, bg = ref_import.load()
+    gold_affinity(mgm)
+    gold_mha(mgm)
+    gold_hungarian(mgm)
+    gold_loss(mgm)
+    gold_gagm(mgm)
+    gold_mgm3(mgm)
+    gold_proto(bg)
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

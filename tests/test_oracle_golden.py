@@ -1,0 +1,128 @@
+"""Pin the CPU oracle (oracle/gmodule.py) against golden vectors produced by the
+reference's own modules (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import gmodule as og
+from ttdg_mgm_amd import synth
+
+torch.set_num_threads(1)
+TOL = 1e-6  # restatement verified <=1e-6 against the imported reference
+
+
+def close(a, b, tol=TOL):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    assert a.shape == tuple(b.shape), (a.shape, b.shape)
+    err = float(np.max(np.abs(a - b))) if a.size else 0.0
+    assert err <= tol, err
+
+
+def check_pgrad(gold, key, g, tol=TOL):
+    flat = g.detach().reshape(-1)
+    close(flat[::cases.PSTRIDE], gold[key + "__sample"], tol)
+    assert abs(float(flat.double().norm()) - float(gold[key + "__norm"])) <= tol * max(1.0, float(gold[key + "__norm"])) * 10
+
+
+@pytest.mark.parametrize("ci", range(len(cases.AFF_CASES)))
+def test_affinity(golden, ci):
+    gold = golden("affinity")
+    p = {k: v.clone().requires_grad_() for k, v in synth.mgm3_params(cases.AFF_PARAM_SEED).items()}
+    X, Y, R = cases.aff_inputs(ci)
+    X.requires_grad_(), Y.requires_grad_()
+    M = og.affinity(p, X, Y)
+    (M * R).sum().backward()
+    close(M, gold[f"c{ci}_M"])
+    close(X.grad, gold[f"c{ci}_dX"], 1e-5)
+    close(Y.grad, gold[f"c{ci}_dY"], 1e-5)
+    for k in ("fc_M.0.weight", "fc_M.0.bias", "fc_M.2.weight", "fc_M.2.bias", "project_sr.weight", "project_tg.weight"):
+        check_pgrad(gold, f"c{ci}_d_{k}", p["node_affinity." + k].grad, 1e-4)
+
+
+@pytest.mark.parametrize("ci", range(len(cases.MHA_CASES)))
+def test_mha_adjacency(golden, ci):
+    gold = golden("mha")
+    p = synth.mgm3_params(cases.MHA_PARAM_SEED)
+    close(og.mha_adjacency(p, cases.mha_input(ci)), gold[f"c{ci}_adj"])
+
+
+@pytest.mark.parametrize("ci", range(len(cases.HUNG_CASES)))
+def test_hungarian(golden, ci):
+    gold = golden("hungarian")
+    close(og.hungarian(cases.hung_input(ci)), gold[f"c{ci}_x"], 0)
+
+
+def test_hungarian_ties(golden):
+    gold = golden("hungarian")
+    close(og.hungarian(torch.from_numpy(gold["ties_s"])), gold["ties_x"], 0)
+
+
+def test_hungarian_bad_rank():
+    with pytest.raises(ValueError):
+        og.hungarian(torch.zeros(3))
+
+
+@pytest.mark.parametrize("ci", range(3))
+def test_permutation_loss(golden, ci):
+    gold = golden("loss")
+    s = torch.from_numpy(gold[f"c{ci}_s"]).requires_grad_()
+    t = torch.from_numpy(gold[f"c{ci}_t"])
+    l = og.permutation_loss(s.unsqueeze(0), t.unsqueeze(0))
+    l.backward()
+    close(l, gold[f"c{ci}_loss"])
+    close(s.grad, gold[f"c{ci}_ds"])
+
+
+def test_permutation_loss_range_assert():
+    with pytest.raises(AssertionError):
+        og.permutation_loss(torch.full((1, 2, 2), 1.5), torch.zeros(1, 2, 2))
+
+
+@pytest.mark.parametrize("name,sizes,seed", cases.GAGM_CASES)
+def test_gagm(golden, name, sizes, seed):
+    gold = golden("gagm")
+    A, W, U0 = cases.gagm_inputs(sizes, seed)
+    tr = {}
+    U = og.gagm(A, W, U0.clone(), sizes, trace=tr)
+    close(tr["V0"], gold[f"{name}_V0"], 1e-5)
+    close(U, gold[f"{name}_U"], 0)       # identical permutations
+    assert tr["stages"][-1][0] == "hungarian" and len(tr["stages"]) == 6
+
+
+@pytest.mark.parametrize("name", [c[0] for c in cases.MGM_CASES])
+def test_mgm3_forward_backward(golden, name):
+    gold = golden("mgm3")
+    params, nodes, labels, U, sizes = cases.mgm_inputs(name)
+    p = {k: v.clone().requires_grad_() for k, v in params.items()}
+    nodes = [x.requires_grad_() for x in nodes]
+    loss = og.mgm3_unsup_forward(p, nodes, labels, U)
+    loss.backward()
+    close(loss, gold[f"{name}_loss"])
+    for gi, x in enumerate(nodes):
+        close(x.grad, gold[f"{name}_dnode{gi}"])
+    for k, v in p.items():
+        if f"{name}_nograd_{k}" in gold:
+            assert v.grad is None, k
+        else:
+            check_pgrad(gold, f"{name}_d_{k}", v.grad, 1e-5)
+
+
+def test_mgm3_none_cases():
+    nodes, labels = synth.node_sets(1, (9,))
+    assert og.mgm3_unsup_forward(synth.mgm3_params(1), nodes, labels, synth.universe(2)) is None
+    assert og.mgm3_unsup_forward(synth.mgm3_params(1), None, None, synth.universe(2)) is None
+
+
+@pytest.mark.parametrize("ci", range(len(cases.PROTO_CASES)))
+def test_prototype_computation(golden, ci):
+    gold = golden("proto")
+    name, feats, boxes, classes = cases.proto_inputs(ci)
+    nodes, labels = og.prototype_computation(feats, boxes, classes)
+    if f"{name}_none" in gold:
+        assert nodes is None and labels is None
+        return
+    assert [len(n) for n in nodes] == gold[f"{name}_count"].tolist()
+    for gi, (n, l) in enumerate(zip(nodes, labels)):
+        close(n, gold[f"{name}_nodes{gi}"], 0)
+        close(l, gold[f"{name}_labels{gi}"], 0)
