@@ -1,0 +1,183 @@
+/* ttdg_mgm.h — C ABI of libttdg_mgm.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the multi-graph-matching test-time-adaptation hot path
+ * of Yore0/TTDG-MGM.  The reference has no FFI of its own: the
+ * path is a sequence of PyTorch ops inside adapteacher/modeling/GModule/.  Each
+ * entry point below replaces one reference operator; the citation names the
+ * reference lines whose arithmetic it implements (paths relative to
+ * /root/reference/adapteacher/modeling/GModule/).  INTEGRATION.md shows the
+ * ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 / int32 unless stated; row-major;
+ *  - the caller (PyTorch caching allocator) owns every buffer incl. workspaces,
+ *    the library allocates nothing and keeps no state but a thread-local
+ *    error string;
+ *  - all work is enqueued on `stream` (a hipStream_t); no implicit device sync;
+ *  - return value 0 = ok, otherwise a negative TTDG_E* code or a positive
+ *    hipError_t; ttdg_last_error() describes the last failure on this thread.
+ */
+#ifndef TTDG_MGM_H
+#define TTDG_MGM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TTDG_VERSION 100 /* 0.1.0 */
+#define TTDG_MAX_GRAPHS 64
+#define TTDG_UNIV 32            /* universe size (rcnn.py:116) */
+#define TTDG_EINVAL (-1)
+#define TTDG_ELIMIT (-2)        /* shape outside what the kernels support */
+
+typedef void* ttdg_stream_t;
+
+int ttdg_version(void);
+const char* ttdg_last_error(void);
+
+/* Graph partition of the M = sum(n_g) stacked nodes: off[0]=0 .. off[G]=M.
+ * Passed by value (kernel argument), never dereferenced on the host side of a stream. */
+typedef struct {
+  int32_t G;
+  int32_t off[TTDG_MAX_GRAPHS + 1];
+} ttdg_graphs_t;
+
+/* ---- dense fp32 GEMM on MFMA (v_mfma_f32_32x32x2_f32, exact fp32) ----------------
+ * C[m,n] = alpha * sum_k A(m,k) * B(n,k) + bias[n] + beta * C[m,n]
+ * A(m,k) = A[m*sam + k*sak], B(n,k) = B[n*sbn + k*sbk], C[m*scm + n*scn]; bias may be NULL.
+ * Covers nn.Linear forward (utils/affinity.py:46-47,55; utils/attentions.py:72-74),
+ * its two backward products and x @ U^T (multi_graph_matching.py:531). */
+int ttdg_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbn, int64_t sbk,
+                  float* C, int64_t scm, int64_t scn, const float* bias, int M, int N, int K,
+                  float alpha, float beta, ttdg_stream_t stream);
+
+/* column sums: out[n] = sum_m X[m*ld + n]  (bias gradients) */
+int ttdg_colsum_f32(const float* X, int64_t ld, float* out, int M, int N, ttdg_stream_t stream);
+
+/* ---- A4 affinity, decomposed form (utils/affinity.py:44-57) ----------------------
+ * P = (X Psr^T) W1[:, :d]^T, Q = (X Ptg^T) W1[:, d:]^T + b1 are produced with ttdg_gemm_f32.
+ * fwd: part[s][i][j] = sum_{k in slice s} w2[k] * relu(P[i,k] + Q[j,k]) for every (i,j) whose
+ *      graphs satisfy g(i) >= g(j) (the reference's src_idx >= tgt_idx pairs,
+ *      multi_graph_matching.py:507-513); M_ij = sum_s part[s][i][j] + b2 is folded into the
+ *      Sinkhorn load.  part is (ksplit, M, M); entries with g(i) < g(j) are unspecified. */
+int ttdg_affinity_pairwise_fwd(const float* P, const float* Q, const float* w2, int H, ttdg_graphs_t gr,
+                               int ksplit, float* part, ttdg_stream_t stream);
+/* bwd: given dM (M x M, read only where g(i) > g(j)):
+ *      dP[i,k] = w2[k] * sum_j dM[i,j] [P[i,k]+Q[j,k] > 0],  dQ[j,k] likewise over i,
+ *      dw2[k]  = sum_i P[i,k] S[i,k] + sum_j Q[j,k] R[j,k]  (S,R = the unscaled sums), db2 = sum dM. */
+int ttdg_affinity_pairwise_bwd(const float* P, const float* Q, const float* w2, const float* dM, int H,
+                               ttdg_graphs_t gr, float* dP, float* dQ, float* dw2, float* db2,
+                               ttdg_stream_t stream);
+
+/* ---- A5 log-space Sinkhorn, pair stage (utils/sinkhorn.py:85-87 -> pygmtools [3P];
+ *      call sites multi_graph_matching.py:518-525) --------------------------------
+ * For every ordered pair a >= b: block = (sum_s part[s] + b2)[a-rows, b-cols], oriented rows<=cols,
+ * dummy rows (-100), `iters` alternating row/col normalisations at temperature tau, exp; the
+ * result is written to Wds[a,b] and (a != b) transposed to Wds[b,a]  (Wds is M x M, fully written).
+ * pot receives the per-sweep potentials needed by the backward ((npairs, iters, cmax+1) floats,
+ * cmax = max n_g); pass NULL when no backward will follow. */
+int ttdg_sinkhorn_pairs_fwd(const float* part, int ksplit, const float* b2, ttdg_graphs_t gr, float tau, int iters,
+                            float* Wds, float* pot, ttdg_stream_t stream);
+/* bwd: dWds (M x M; only blocks a<b are read, as the loss only touches those,
+ * multi_graph_matching.py:615-631) -> dM (M x M, written for g(i) > g(j)). */
+int ttdg_sinkhorn_pairs_bwd(const float* part, int ksplit, const float* b2, const float* pot, const float* dWds,
+                            ttdg_graphs_t gr, float tau, int iters, float* dM, ttdg_stream_t stream);
+
+/* stand-alone batched Sinkhorn (the operator behind GModule.utils.sinkhorn.Sinkhorn.forward):
+ * s is (b, r, c) with strides (sb, sr, sc); n1/n2 optional per-matrix valid sizes (device int32);
+ * out is (b, r, c) contiguous.  Orientation, dummy rows and padding as SURVEY.md Appendix B. */
+int ttdg_sinkhorn_batched_fwd(const float* s, int64_t sb, int64_t sr, int64_t sc, int b, int r, int c,
+                              const int32_t* n1, const int32_t* n2, int dummy_row, float tau, int iters,
+                              float* out, ttdg_stream_t stream);
+
+/* ---- A3 intra-graph attention adjacency (utils/attentions.py:60-86, v2, 1 head) --
+ * q, k: (M, d) projections (ttdg_gemm_f32).  Apack receives, per graph, softmax(q k^T * scale)
+ * with the diagonal zeroed (multi_graph_matching.py:496-502), packed block after block
+ * (block g at offset sum_{h<g} n_h^2).  drop_p > 0 applies train-mode dropout on the attention
+ * (attentions.py:40) from a Philox stream keyed by (seed, graph, row, col). */
+int ttdg_mha_adjacency(const float* q, const float* k, int d, ttdg_graphs_t gr, float scale, float drop_p,
+                       uint64_t seed, float* Apack, ttdg_stream_t stream);
+
+/* ---- A6+A7 graduated-assignment multi-graph matching, whole solve on device ------
+ * (multi_graph_matching.py:223-244, 300-389 with num_clusters == 1; utils/hungarian.py:8-66 ->
+ * scipy.optimize.linear_sum_assignment [3P] re-implemented on device, one wavefront per LAP.)
+ * Apack as above, W = Wds (M x M), U0 (M x 32).  U (M x 32) receives the 0/1 matching.
+ * info (int32[16], device): [0..5] iterations per stage, [6] total, [7] stages run, [8] status.
+ * ws: workspace of ttdg_gagm_workspace_bytes(M) bytes (also receives the first-iteration V at
+ * its start, M*32 floats, for parity tests). */
+typedef struct {
+  float tau0, gamma, min_tau, tol, quad_weight;
+  int32_t max_iter, sk_iter;
+} ttdg_gagm_cfg_t;
+size_t ttdg_gagm_workspace_bytes(int M);
+int ttdg_gagm_solve(const float* Apack, const float* W, const float* U0, ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg,
+                    float* U, int32_t* info, void* ws, ttdg_stream_t stream);
+
+/* batched LAP (maximise), the operator behind GModule.utils.hungarian.hungarian:
+ * s (b, r, c) contiguous -> x (b, r, c) 0/1.  One wavefront per matrix, fp64 duals,
+ * tie-breaking identical to scipy's rectangular LSAP. min(r,c) <= 64, max(r,c) <= 256. */
+int ttdg_lap_batched(const float* s, int b, int r, int c, float* x, ttdg_stream_t stream);
+
+/* ---- A8+A9 pseudo-label permutation loss (multi_graph_matching.py:535-564,
+ *      utils/losses.py:83-103,419-455) ---------------------------------------------
+ * loss = mean over pairs a<b of mean over elements of focal-BCE(clamp(Wds[a,b]), U_a U_b^T).
+ * dWds (M x M) is fully written (zero outside the a<b blocks) with d loss / d Wds.
+ * flag[0] is set to 1 if any Wds entry of an a<b block is outside [0,1] (losses.py:437-439).
+ * pair_ws: G(G-1)/2 floats of scratch (per-pair means, summed in fixed order). */
+int ttdg_perm_loss_fwd_bwd(const float* Wds, const float* U, ttdg_graphs_t gr, float alpha, float eps,
+                           float* loss, float* dWds, int32_t* flag, float* pair_ws, ttdg_stream_t stream);
+
+/* ---- A2 node sampler (build_graph.py:27-115,133-250) -----------------------------
+ * Step 1: per image, per FPN location: label of the minimum-area box that contains the point and
+ * cares about the level (0 = none).  boxes (B, kmax, 4) xyxy, classes (B, kmax) int32, nbox (B).
+ * Level l has h[l] x w[l] points at stride[l]; labels is (B, npts_total) int32.  B here counts the
+ * images that HAVE boxes: the reference skips box-less images when it builds labels but indexes
+ * features by list position (build_graph.py:79 vs :173-181); the host wrapper reproduces that pairing.
+ * Step 2: per (image, level): positives in raster order, step = cnt // sample_dist, keep [::step]
+ * when step > 1; sel_idx (B, cap) receives level-local point ids tagged with the level
+ * (id | level << 28), sel_lab the labels, count[B] the node counts (cap >= 5 * (2*sample_dist - 1)).
+ * Step 3/4: gather / scatter-add of the selected 256-d feature columns from/to NCHW maps. */
+#define TTDG_MAX_LEVELS 8
+typedef struct {
+  int32_t n;                       /* number of FPN levels (5: p2..p6) */
+  int32_t h[TTDG_MAX_LEVELS], w[TTDG_MAX_LEVELS], stride[TTDG_MAX_LEVELS];
+  float lo[TTDG_MAX_LEVELS], hi[TTDG_MAX_LEVELS];   /* object_sizes_of_interest (build_graph.py:28-33) */
+} ttdg_levels_t;
+typedef struct {
+  int32_t n, C;
+  int32_t h[TTDG_MAX_LEVELS], w[TTDG_MAX_LEVELS];
+  float* feat[TTDG_MAX_LEVELS];    /* NCHW maps (B, C, h, w), one per level */
+} ttdg_fpn_t;
+int ttdg_node_labels(const float* boxes, const int32_t* classes, const int32_t* nbox, int B, int kmax,
+                     ttdg_levels_t lv, int32_t* labels, ttdg_stream_t stream);
+int ttdg_node_select(const int32_t* labels, int B, ttdg_levels_t lv, int sample_dist, int cap,
+                     int32_t* sel_idx, int32_t* sel_lab, int32_t* count, ttdg_stream_t stream);
+/* img[i], pid[i] (= point | level << 28) name node i; out/dout are (n, C) row-major.
+ * The backward ADDS into the (caller-zeroed) gradient maps. */
+int ttdg_node_gather_fwd(ttdg_fpn_t fp, const int32_t* img, const int32_t* pid, int n, float* out,
+                         ttdg_stream_t stream);
+int ttdg_node_gather_bwd(ttdg_fpn_t dfp, const int32_t* img, const int32_t* pid, int n, const float* dout,
+                         ttdg_stream_t stream);
+
+/* ---- A11 fused multi-tensor SGD (torch.optim.SGD as built by detectron2 [3P];
+ *      engine/trainer.py:480-482) ---------------------------------------------------
+ * For every tensor t: d = g + wd[t]*p; buf = first[t] ? d : momentum*buf + d; p -= lr*buf.
+ * table: device array of ntensors descriptors; chunk tables map thread blocks to tensors. */
+typedef struct {
+  float* p;
+  const float* g;
+  float* buf;
+  int64_t n;
+  float wd;
+  int32_t first;
+} ttdg_sgd_tensor_t;
+int ttdg_sgd_multi_tensor(const ttdg_sgd_tensor_t* table, const int32_t* chunk_tensor, const int64_t* chunk_off,
+                          int nchunks, int chunk, float lr, float momentum, ttdg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TTDG_MGM_H */

@@ -1,0 +1,277 @@
+// A4 — learned pairwise affinity, decomposed form (reference utils/affinity.py:44-57).
+//
+// The reference materialises cat([X'_i ; Y'_j]) as an (n1, n2, 512) tensor and pushes it through
+// Linear(512,512)+ReLU+Linear(512,1).  Splitting the first Linear by input half gives the exact identity
+//     M_ij = sum_k w2[k] * relu(P[i,k] + Q[j,k]) + b2,   P = X' W1[:, :256]^T,  Q = Y' W1[:, 256:]^T + b1
+// (SURVEY.md §8a A4).  P and Q are two small GEMMs (gemm.hip, MFMA); what remains is this pairwise
+// reduction: 3 VALU lane-ops (add, max, fma) per (i, j, k), arithmetic intensity ~100 FLOP/B -> fp32
+// VALU bound, not HBM and not MFMA (relu sits between the two contractions).
+//
+// Forward:  workgroup = 64(i) x 64(j) outputs x one K slice, 256 threads, 4x4 register tile per thread
+//           (rows ty+16a, cols tx+16b so that the LDS row stride of 36 words is conflict-free for
+//           ds_read_b128), P/Q slabs staged row-major [row][k] in LDS.  K may be split over blockIdx.z
+//           into `ksplit` partial planes that the Sinkhorn load sums (deterministic, no atomics) so that
+//           a batch of four ~30-node graphs still fills the chip.
+// Backward: S[i,k] = sum_j dM[i,j] [P[i,k] + Q[j,k] > 0] and its mirror R[j,k]; same tiling with the
+//           roles (row, reduced index) swapped by a template flag; 3 lane-ops per (i,j,k) per pass.
+#include "common.h"
+
+#define TILE 64
+#define BK 32
+#define LDK (BK + 4)  // 36-word row stride: 16 rows x 4 words hit 64 distinct banks
+
+__device__ __forceinline__ bool tile_needed(const ttdg_graphs_t& gr, int i0, int j0, int M) {
+  // the tile holds a wanted pair iff graph(last row) >= graph(first col)
+  const int il = min(i0 + TILE, M) - 1;
+  return graph_of(gr, il) >= graph_of(gr, j0);
+}
+
+__global__ __launch_bounds__(256) void affinity_fwd_kernel(const float* __restrict__ P, const float* __restrict__ Q,
+                                                           const float* __restrict__ w2, int H, ttdg_graphs_t gr,
+                                                           int kslice, float* __restrict__ part) {
+  const int M = gr.off[gr.G];
+  const int i0 = blockIdx.y * TILE, j0 = blockIdx.x * TILE;
+  if (!tile_needed(gr, i0, j0, M)) return;
+  __shared__ __attribute__((aligned(16))) float Ps[TILE][LDK];
+  __shared__ __attribute__((aligned(16))) float Qs[TILE][LDK];
+  __shared__ __attribute__((aligned(16))) float Ws[BK];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int kbeg = blockIdx.z * kslice;
+
+  float acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+
+  const int lrow = tid >> 3, lk = (tid & 7) * 4;  // staging map: 8 lanes x float4 cover one 32-wide row
+  for (int k0 = kbeg; k0 < kbeg + kslice; k0 += BK) {
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int row = lrow + 32 * r;
+      float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), qv = pv;
+      if (i0 + row < M) pv = *reinterpret_cast<const float4*>(P + (size_t)(i0 + row) * H + k0 + lk);
+      if (j0 + row < M) qv = *reinterpret_cast<const float4*>(Q + (size_t)(j0 + row) * H + k0 + lk);
+      *reinterpret_cast<float4*>(&Ps[row][lk]) = pv;
+      *reinterpret_cast<float4*>(&Qs[row][lk]) = qv;
+    }
+    if (tid < BK) Ws[tid] = w2[k0 + tid];
+    __syncthreads();
+#pragma unroll 2
+    for (int kk = 0; kk < BK; kk += 4) {
+      float4 p[4], q[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) p[a] = *reinterpret_cast<const float4*>(&Ps[ty + 16 * a][kk]);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) q[b] = *reinterpret_cast<const float4*>(&Qs[tx + 16 * b][kk]);
+      const float4 w = *reinterpret_cast<const float4*>(&Ws[kk]);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          acc[a][b] = fmaf(w.x, fmaxf(p[a].x + q[b].x, 0.f), acc[a][b]);
+          acc[a][b] = fmaf(w.y, fmaxf(p[a].y + q[b].y, 0.f), acc[a][b]);
+          acc[a][b] = fmaf(w.z, fmaxf(p[a].z + q[b].z, 0.f), acc[a][b]);
+          acc[a][b] = fmaf(w.w, fmaxf(p[a].w + q[b].w, 0.f), acc[a][b]);
+        }
+    }
+    __syncthreads();
+  }
+  float* out = part + (size_t)blockIdx.z * M * M;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int i = i0 + ty + 16 * a;
+    if (i >= M) continue;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int j = j0 + tx + 16 * b;
+      if (j < M) out[(size_t)i * M + j] = acc[a][b];
+    }
+  }
+}
+
+extern "C" int ttdg_affinity_pairwise_fwd(const float* P, const float* Q, const float* w2, int H, ttdg_graphs_t gr,
+                                          int ksplit, float* part, ttdg_stream_t stream) {
+  TTDG_REQUIRE(P && Q && w2 && part, "affinity_fwd: null pointer");
+  if (int e = ttdg_validate_graphs(gr)) return e;
+  TTDG_REQUIRE(ksplit >= 1 && H % (ksplit * BK) == 0, "affinity_fwd: H must be a multiple of ksplit*32");
+  const int M = gr.off[gr.G];
+  const int nt = (M + TILE - 1) / TILE;
+  hipLaunchKernelGGL(affinity_fwd_kernel, dim3(nt, nt, ksplit), dim3(256), 0, (hipStream_t)stream, P, Q, w2, H, gr,
+                     H / ksplit, part);
+  return ttdg_launch_status("affinity_fwd");
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Backward accumulate:  O[r,k] = sum_c D(r,c) * [X[r,k] + Y[c,k] > 0]
+//   kRowsAreSrc = true  (dP pass): r = i (src node), c = j over graphs strictly before graph(i);  D = dM[r][c]
+//   kRowsAreSrc = false (dQ pass): r = j (tgt node), c = i over graphs strictly after graph(j);   D = dM[c][r]
+// Workgroup = 64 rows x 64 k, thread tile 4 rows (ty*4+a) x 4 k (tx*4+b); the reduced index c is streamed in
+// slabs of 32 through LDS: Dt[c][r] (row index contiguous -> one ds_read_b128 per c) and Ys[c][k] = -Y.
+#define BC 32
+#define LDR (TILE + 4)
+
+template <bool kRowsAreSrc>
+__global__ __launch_bounds__(256) void affinity_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Y,
+                                                           const float* __restrict__ dM, int H, ttdg_graphs_t gr,
+                                                           float* __restrict__ O) {
+  const int M = gr.off[gr.G];
+  const int r0 = blockIdx.y * TILE, k0 = blockIdx.x * TILE;
+  __shared__ __attribute__((aligned(16))) float Dt[BC][LDR];
+  __shared__ __attribute__((aligned(16))) float Ys[BC][LDR];
+  __shared__ int rlim[TILE];  // per row: first (dP) / one-past-last excluded (dQ) reduced index
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+
+  if (tid < TILE) {
+    const int r = r0 + tid;
+    int lim = kRowsAreSrc ? 0 : M;
+    if (r < M) {
+      const int g = graph_of(gr, r);
+      lim = kRowsAreSrc ? gr.off[g] : gr.off[g + 1];
+    }
+    rlim[tid] = lim;
+  }
+  __syncthreads();
+  // reduced range for the whole tile
+  int cbeg, cend;
+  {
+    const int rl = min(r0 + TILE, M) - 1;
+    if (kRowsAreSrc) { cbeg = 0; cend = gr.off[graph_of(gr, rl)]; }
+    else { cbeg = gr.off[graph_of(gr, r0) + 1]; cend = M; }
+  }
+
+  float x[4][4], acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int r = r0 + ty * 4 + a;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < M) v = *reinterpret_cast<const float4*>(X + (size_t)r * H + k0 + tx * 4);
+    x[a][0] = v.x; x[a][1] = v.y; x[a][2] = v.z; x[a][3] = v.w;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+  }
+
+  for (int c0 = cbeg; c0 < cend; c0 += BC) {
+    // stage Y slab: 32 c x 64 k
+    {
+      const int c = tid >> 4, kq = (tid & 15) * 4;
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int cc = c + 16 * rr;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c0 + cc < M) v = *reinterpret_cast<const float4*>(Y + (size_t)(c0 + cc) * H + k0 + kq);
+        // store -Y: relu'(x + y) = [x > -y] exactly (fp32 sums of finite values never round to 0 unless 0)
+        *reinterpret_cast<float4*>(&Ys[cc][kq]) = make_float4(-v.x, -v.y, -v.z, -v.w);
+      }
+    }
+    // stage D slab as Dt[c][r], masked to the wanted blocks (everything else contributes 0)
+    if (kRowsAreSrc) {
+      // D(r,c) = dM[r][c]: global rows are r, contiguous along c -> transposing store
+      const int r = tid >> 3, cq = (tid & 7) * 4;
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int rl = r + 32 * rr, rg = r0 + rl;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (rg < M) {
+          const int lim = rlim[rl];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int c = c0 + cq + e;
+            if (c < lim) v[e] = dM[(size_t)rg * M + c];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Dt[cq + e][rl] = v[e];
+      }
+    } else {
+      // D(r,c) = dM[c][r]: global rows are c, contiguous along r -> direct, coalesced
+      const int rl = tid & 63, cb = tid >> 6;
+      const int rg = r0 + rl, lim = rlim[rl];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = cb + 4 * e, cg = c0 + c;
+        float v = 0.f;
+        if (rg < M && cg < M && cg >= lim) v = dM[(size_t)cg * M + rg];
+        Dt[c][rl] = v;
+      }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int cc = 0; cc < BC; ++cc) {
+      const float4 d = *reinterpret_cast<const float4*>(&Dt[cc][ty * 4]);
+      const float4 y = *reinterpret_cast<const float4*>(&Ys[cc][tx * 4]);
+      const float dv[4] = {d.x, d.y, d.z, d.w};
+      const float yv[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] += (x[a][b] > yv[b]) ? dv[a] : 0.f;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int r = r0 + ty * 4 + a;
+    if (r < M)
+      *reinterpret_cast<float4*>(O + (size_t)r * H + k0 + tx * 4) = make_float4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
+  }
+}
+
+// finish: dw2[k] = sum_i P S + sum_j Q R (unscaled sums), then scale S,R by w2 in place -> dP,dQ.
+// One wavefront per 64 k-columns slice x 4 row groups; deterministic tree over rows.
+__global__ __launch_bounds__(256) void affinity_bwd_finish_kernel(const float* __restrict__ P, const float* __restrict__ Q,
+                                                                  const float* __restrict__ w2, int H, int M,
+                                                                  float* __restrict__ S, float* __restrict__ R,
+                                                                  float* __restrict__ dw2) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  const float w = w2[k];
+  float s = 0.f;
+  for (int m = wave; m < M; m += 4) {
+    const size_t o = (size_t)m * H + k;
+    const float sv = S[o], rv = R[o];
+    s += P[o] * sv + Q[o] * rv;
+    S[o] = sv * w;
+    R[o] = rv * w;
+  }
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0) dw2[k] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// db2 = sum of dM over the blocks with graph(i) > graph(j); one workgroup, fixed summation order.
+__global__ __launch_bounds__(1024) void affinity_db2_kernel(const float* __restrict__ dM, ttdg_graphs_t gr,
+                                                            float* __restrict__ db2) {
+  const int M = gr.off[gr.G];
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int i = gr.off[1] + (threadIdx.x >> 6); i < M; i += 16) {
+    const int lim = gr.off[graph_of(gr, i)];
+    for (int j = threadIdx.x & 63; j < lim; j += 64) s += dM[(size_t)i * M + j];
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    *db2 = t;
+  }
+}
+
+extern "C" int ttdg_affinity_pairwise_bwd(const float* P, const float* Q, const float* w2, const float* dM, int H,
+                                          ttdg_graphs_t gr, float* dP, float* dQ, float* dw2, float* db2,
+                                          ttdg_stream_t stream) {
+  TTDG_REQUIRE(P && Q && w2 && dM && dP && dQ && dw2 && db2, "affinity_bwd: null pointer");
+  if (int e = ttdg_validate_graphs(gr)) return e;
+  TTDG_REQUIRE(H % TILE == 0, "affinity_bwd: H must be a multiple of 64");
+  const int M = gr.off[gr.G];
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(H / TILE, (M + TILE - 1) / TILE);
+  hipLaunchKernelGGL((affinity_bwd_kernel<true>), grid, dim3(256), 0, st, P, Q, dM, H, gr, dP);
+  hipLaunchKernelGGL((affinity_bwd_kernel<false>), grid, dim3(256), 0, st, Q, P, dM, H, gr, dQ);
+  hipLaunchKernelGGL(affinity_bwd_finish_kernel, dim3(H / 64), dim3(256), 0, st, P, Q, w2, H, M, dP, dQ, dw2);
+  hipLaunchKernelGGL(affinity_db2_kernel, dim3(1), dim3(1024), 0, st, dM, gr, db2);
+  return ttdg_launch_status("affinity_bwd");
+}

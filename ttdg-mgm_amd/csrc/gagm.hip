@@ -1,0 +1,321 @@
+// A6 + A7 — graduated-assignment multi-graph matching, the whole solve in ONE persistent workgroup.
+// Reference: GA_GM.forward / gagm, multi_graph_matching.py:223-244, 300-389 (num_clusters == 1, so
+// cluster_M == 1 and hung_iter is True), projector Sinkhorn (utils/sinkhorn.py -> pygmtools [3P]) then
+// Hungarian (utils/hungarian.py -> scipy [3P]).
+//
+// What the reference does per iteration: UU^T (M x M), chain_matmul(A, UU^T, A, U), W U, then a 20-sweep
+// Sinkhorn (20+ kernel launches) or G host round-trips to scipy, then two norm() host syncs; up to
+// 5 x 200 Sinkhorn-stage + 200 Hungarian-stage iterations (data dependent).  Here nothing leaves the
+// GPU and nothing is launched inside the loop:
+//   B = A U (block diagonal)      S = U^T B (32x32)      V = (2q B S + W U) / G      [A (UU^T) A U == B S]
+//   projection: one wavefront per graph, either a register-resident log-Sinkhorn (the n x 32 block is
+//   held twice, column-wise and row-wise, so both sweeps are lane-local; dual potentials are exchanged
+//   through wavefront-private LDS) or the on-device LAP of lap_device.h;
+//   convergence: ||U - lastU|| < tol or U == lastU2 (exact 2-cycle), reduced in LDS.
+// State (U, lastU, lastU2/B, V) lives in LDS when 4*M*32 floats fit, else in the L2-resident workspace.
+#include "lap_device.h"
+
+#define NU TTDG_UNIV
+#define NEG_BIG (-INFINITY)
+
+
+// ---- register-resident Sinkhorn projection of one graph block, one wavefront --------------------------
+// V block: Vb[node*32 + univ], n nodes.  Oriented problem: r = min(n,32) rows, c = max(n,32) columns,
+// (c - r) dummy rows.  CW = ceil(c / 64) columns per lane.
+template <int CW>
+__device__ __forceinline__ void sk_wave_project(const float* Vb, int n, float scale, int iters, float* Ub, float* fbuf, float* gbuf) {
+  const int lane = threadIdx.x & 63;
+  const bool tr = n > NU;            // rows = universe, cols = nodes
+  const int r = tr ? NU : n, c = tr ? n : NU, mult = c - r;
+  const float D = -100.0f * TTDG_LOG2E;
+  // column layout: lane owns columns q = lane + 64*w; Lc[w][p]
+  float Lc[CW][NU];
+#pragma unroll
+  for (int w = 0; w < CW; ++w) {
+    const int q = lane + 64 * w;
+#pragma unroll
+    for (int p = 0; p < NU; ++p) {
+      float v = NEG_BIG;
+      if (q < c && p < r) v = (tr ? Vb[q * NU + p] : Vb[p * NU + q]) * scale;
+      Lc[w][p] = v;
+    }
+  }
+  // row layout: lane (p = lane & 31, h = lane >> 5) owns row p, columns q in [h*32*CW, (h+1)*32*CW)
+  const int rp = lane & 31, rh = lane >> 5;
+  const int qbase = rh * 32 * CW;
+  float Lr[32 * CW];
+#pragma unroll
+  for (int k = 0; k < 32 * CW; ++k) {
+    const int q = qbase + k;
+    float v = NEG_BIG;
+    if (q < c && rp < r) v = (tr ? Vb[q * NU + rp] : Vb[rp * NU + q]) * scale;
+    Lr[k] = v;
+  }
+  // potentials: g lives in the column lanes (registers) and in gbuf; f in fbuf[0..31], dummy in fbuf[32]
+  float gq[CW];
+#pragma unroll
+  for (int w = 0; w < CW; ++w) { gq[w] = 0.f; if (lane + 64 * w < 64 * CW) gbuf[lane + 64 * w] = 0.f; }
+  if (lane < 33) fbuf[lane] = 0.f;
+  wave_sync();
+
+  for (int it = 0; it < iters; ++it) {
+    if ((it & 1) == 0) {
+      // rows: f_p = lse_q(L_pq - g_q), lane-local over the lane's half row, then combine the two halves
+      float m = NEG_BIG;
+#pragma unroll
+      for (int k = 0; k < 32 * CW; k += 4) {
+        const float4 g4 = *reinterpret_cast<const float4*>(gbuf + qbase + k);
+        m = fmaxf(m, fmaxf(fmaxf(Lr[k] - g4.x, Lr[k + 1] - g4.y), fmaxf(Lr[k + 2] - g4.z, Lr[k + 3] - g4.w)));
+      }
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      const float ms = (m == NEG_BIG) ? 0.f : m;   // rows >= r hold no finite entry
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32 * CW; k += 4) {
+        const float4 g4 = *reinterpret_cast<const float4*>(gbuf + qbase + k);
+        s += fast_exp2(Lr[k] - g4.x - ms) + fast_exp2(Lr[k + 1] - g4.y - ms) + fast_exp2(Lr[k + 2] - g4.z - ms) +
+             fast_exp2(Lr[k + 3] - g4.w - ms);
+      }
+      s += __shfl_xor(s, 32, 64);
+      if (lane < 32) fbuf[lane] = (lane < r) ? ms + fast_log2(s) : 0.f;
+      if (mult > 0) {
+        // dummy row: fd = D + lse_q(-g_q) over the c real columns
+        float dm = NEG_BIG;
+#pragma unroll
+        for (int w = 0; w < CW; ++w) if (lane + 64 * w < c) dm = fmaxf(dm, -gq[w]);
+        dm = wave_max(dm);
+        float ds = 0.f;
+#pragma unroll
+        for (int w = 0; w < CW; ++w) if (lane + 64 * w < c) ds += fast_exp2(-gq[w] - dm);
+        ds = wave_sum(ds);
+        if (lane == 0) fbuf[32] = D + dm + fast_log2(ds);
+      }
+    } else {
+      // cols: g_q = lse over real rows p < r and `mult` dummy rows, lane-local
+      const float td = (mult > 0) ? D - fbuf[32] : NEG_BIG;
+#pragma unroll
+      for (int w = 0; w < CW; ++w) {
+        float m = td;
+#pragma unroll
+        for (int p = 0; p < NU; p += 4) {
+          const float4 f4 = *reinterpret_cast<const float4*>(fbuf + p);
+          m = fmaxf(m, fmaxf(fmaxf(Lc[w][p] - f4.x, Lc[w][p + 1] - f4.y), fmaxf(Lc[w][p + 2] - f4.z, Lc[w][p + 3] - f4.w)));
+        }
+        const float ms = (m == NEG_BIG) ? 0.f : m;
+        float s = (mult > 0) ? (float)mult * fast_exp2(td - ms) : 0.f;
+#pragma unroll
+        for (int p = 0; p < NU; p += 4) {
+          const float4 f4 = *reinterpret_cast<const float4*>(fbuf + p);
+          s += fast_exp2(Lc[w][p] - f4.x - ms) + fast_exp2(Lc[w][p + 1] - f4.y - ms) + fast_exp2(Lc[w][p + 2] - f4.z - ms) +
+               fast_exp2(Lc[w][p + 3] - f4.w - ms);
+        }
+        const int q = lane + 64 * w;
+        gq[w] = (q < c) ? ms + fast_log2(s) : 0.f;
+        gbuf[q] = gq[w];
+      }
+    }
+    wave_sync();
+  }
+  // U = exp(L - f - g) in the row layout (contiguous stores when rows are nodes)
+  const float fp = fbuf[rp];
+#pragma unroll
+  for (int k = 0; k < 32 * CW; ++k) {
+    const int q = qbase + k;
+    if (q < c && rp < r) {
+      const float v = fast_exp2(Lr[k] - fp - gbuf[q]);
+      if (tr) Ub[q * NU + rp] = v; else Ub[rp * NU + q] = v;
+    }
+  }
+}
+
+template <int GA_WAVES>
+__device__ __forceinline__ float block_sum2(float a, float b, float* red, float& outb) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) { red[wave] = a; red[GA_WAVES + wave] = b; }
+  __syncthreads();
+  float sa = 0.f, sb = 0.f;
+#pragma unroll
+  for (int w = 0; w < GA_WAVES; ++w) { sa += red[w]; sb += red[GA_WAVES + w]; }
+  outb = sb;
+  return sa;
+}
+
+// 512 threads (8 wavefronts, 2 per SIMD): the register-resident Sinkhorn block needs the 256-VGPR budget.
+// CWMAX 1: graphs up to 64 nodes; CWMAX 2: up to 128 nodes.
+template <bool kLds, int GA_THREADS, int CWMAX>
+__global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restrict__ Apack, const float* __restrict__ W,
+                                                          const float* __restrict__ U0, ttdg_graphs_t gr,
+                                                          ttdg_gagm_cfg_t cfg, float* __restrict__ Uout,
+                                                          int32_t* __restrict__ info, float* __restrict__ ws, int cmaxp) {
+  extern __shared__ __attribute__((aligned(16))) float ga_smem[];
+  constexpr int GA_WAVES = GA_THREADS / 64;
+  const int M = gr.off[gr.G], G = gr.G;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int MU = M * NU;
+  // workspace (global): [V0 snapshot MU][state 4*MU when !kLds]
+  float* V0snap = ws;
+  float* base = kLds ? ga_smem : ws + MU;
+  float* Ucur = base;
+  float* Uprev = base + MU;
+  float* X = base + 2 * MU;
+  float* V = base + 3 * MU;
+  float* sm = kLds ? ga_smem + 4 * MU : ga_smem;   // always-LDS part
+  float* S = sm;                 // 1024
+  float* red = S + NU * NU;      // 64
+  float* wex = red + 64;         // GA_WAVES * (40 + cmaxp)
+  const int wex_stride = 40 + cmaxp;
+  unsigned char* lapb = (unsigned char*)(wex + GA_WAVES * wex_stride);
+  const size_t lap_stride = (lap_scratch_bytes(NU, cmaxp) + 15) & ~(size_t)15;
+
+  __shared__ int s_off[TTDG_MAX_GRAPHS + 4];     // sized so the static LDS total stays a multiple of 16 B (dynamic base alignment)
+  __shared__ int s_aoff[TTDG_MAX_GRAPHS + 4];   // start of graph g's block in Apack
+  __shared__ short s_gid[4096];                 // node -> graph (M <= 4096 on this solver)
+  if (tid <= G) s_off[tid] = gr.off[tid];
+  if (tid == 0) {
+    int a = 0;
+    for (int g = 0; g < G; ++g) { s_aoff[g] = a; const int n = gr.off[g + 1] - gr.off[g]; a += n * n; }
+  }
+  for (int r = tid; r < M; r += GA_THREADS) s_gid[r] = (short)graph_of(gr, r);
+  for (int e = tid; e < MU; e += GA_THREADS) { Ucur[e] = U0[e]; Uprev[e] = 0.f; }   // lastU = zeros (:305)
+  __syncthreads();
+
+  float tau = cfg.tau0;
+  bool hungarian = false;
+  int stage = 0, total = 0;
+  const float qw2 = cfg.quad_weight * 2.f, invG = 1.f / (float)G;
+  bool first = true;
+
+  for (;;) {   // stages (:311)
+    int i = 0;
+    for (; i < cfg.max_iter; ++i) {   // :312
+      // ---- B = A U, block diagonal (X <- B) ----
+      for (int e = tid; e < MU; e += GA_THREADS) {
+        const int row = e >> 5, u = e & 31;
+        const int g = s_gid[row];
+        const int o = s_off[g], n = s_off[g + 1] - o;
+        const float* arow = Apack + s_aoff[g] + (size_t)(row - o) * n;
+        float acc = 0.f;
+        for (int j = 0; j < n; ++j) acc = fmaf(arow[j], Ucur[(o + j) * NU + u], acc);
+        X[e] = acc;
+      }
+      __syncthreads();
+      // ---- S = U^T B ----
+      {
+        const int u = tid >> 5, v = tid & 31;
+        float acc = 0.f;
+        for (int r = 0; r < M; ++r) acc = fmaf(Ucur[r * NU + u], X[r * NU + v], acc);
+        S[tid] = acc;
+      }
+      __syncthreads();
+      // ---- V = (2q B S + W U) / G ----
+      for (int e = tid; e < MU; e += GA_THREADS) {
+        const int row = e >> 5, u = e & 31;
+        float q = 0.f;
+#pragma unroll 8
+        for (int v = 0; v < NU; ++v) q = fmaf(X[row * NU + v], S[v * NU + u], q);
+        const float* wrow = W + (size_t)row * M;
+        float lin = 0.f;
+        for (int j = 0; j < M; ++j) lin = fmaf(wrow[j], Ucur[j * NU + u], lin);
+        const float val = (q * qw2 + lin) * invG;
+        V[e] = val;
+        if (first) V0snap[e] = val;
+      }
+      first = false;
+      __syncthreads();
+      // ---- projection (X <- projected U), one wavefront per graph ----
+      for (int g = wave; g < G; g += GA_WAVES) {
+        const int o = s_off[g], n = s_off[g + 1] - o;
+        float* Ub = X + o * NU;
+        const float* Vb = V + o * NU;
+        if (!hungarian) {
+          float* fbuf = wex + wave * wex_stride;
+          float* gbuf = fbuf + 40;
+          const float scale = TTDG_LOG2E / tau;
+          if (CWMAX == 1 || n <= 64) sk_wave_project<1>(Vb, n, scale, cfg.sk_iter, Ub, fbuf, gbuf);
+          else sk_wave_project<CWMAX>(Vb, n, scale, cfg.sk_iter, Ub, fbuf, gbuf);
+        } else {
+          const bool tr = n > NU;
+          const int nr = tr ? NU : n, nc = tr ? n : NU;
+          LapScratch sc = lap_carve(lapb + wave * lap_stride, nr, nc);
+          for (int e = lane; e < n * NU; e += 64) Ub[e] = 0.f;
+          lap_wave_solve(nr, nc, Vb, tr ? 1 : NU, tr ? NU : 1, sc);
+          wave_sync();
+          for (int a = lane; a < nr; a += 64) {
+            const int b = sc.col4row[a];
+            if (tr) Ub[b * NU + a] = 1.f; else Ub[a * NU + b] = 1.f;
+          }
+        }
+      }
+      __syncthreads();
+      if (G == 2) {   // :358-359
+        const int n0 = s_off[1];
+        for (int e = tid; e < n0 * NU; e += GA_THREADS) X[e] = ((e >> 5) == (e & 31)) ? 1.f : 0.f;
+        __syncthreads();
+      }
+      // ---- convergence (:361) ----
+      float d1 = 0.f, d2 = 0.f;
+      for (int e = tid; e < MU; e += GA_THREADS) {
+        const float un = X[e];
+        const float a = un - Ucur[e], b = un - Uprev[e];
+        d1 = fmaf(a, a, d1);
+        d2 = fmaf(b, b, d2);
+      }
+      float s2;
+      const float s1 = block_sum2<GA_WAVES>(d1, d2, red, s2);
+      // rotate: lastU2 <- lastU, lastU <- U, U <- new  (buffers rotate; the old lastU2 becomes scratch X)
+      float* t = Uprev; Uprev = Ucur; Ucur = X; X = t;
+      ++total;
+      if (sqrtf(s1) < cfg.tol || s2 == 0.f) break;
+    }
+    const int its = (i < cfg.max_iter) ? i + 1 : cfg.max_iter;
+    if (tid == 0 && stage < 6) info[stage] = its;
+    ++stage;
+    if (hungarian) break;            // :374-376
+    if (tau > cfg.min_tau) tau *= cfg.gamma;   // :377-379
+    else hungarian = true;           // :382-383
+    __syncthreads();
+  }
+  __syncthreads();
+  for (int e = tid; e < MU; e += GA_THREADS) Uout[e] = Ucur[e];
+  if (tid == 0) { info[6] = total; info[7] = stage; info[8] = 0; }
+}
+
+static size_t ga_fixed_lds_bytes(int cmaxp, int GA_WAVES) {
+  // + static LDS: s_off, s_aoff (2 x 65 ints) and s_gid (4096 shorts) ~ 8.8 KB
+  return (size_t)9 * 1024 + (size_t)(NU * NU + 64 + GA_WAVES * (40 + cmaxp)) * sizeof(float) +
+         GA_WAVES * ((lap_scratch_bytes(NU, cmaxp) + 15) & ~(size_t)15);
+}
+
+extern "C" size_t ttdg_gagm_workspace_bytes(int M) { return (size_t)5 * M * NU * sizeof(float); }
+
+extern "C" int ttdg_gagm_solve(const float* Apack, const float* W, const float* U0, ttdg_graphs_t gr,
+                               ttdg_gagm_cfg_t cfg, float* U, int32_t* info, void* ws, ttdg_stream_t stream) {
+  TTDG_REQUIRE(Apack && W && U0 && U && info && ws, "gagm: null pointer");
+  if (int e = ttdg_validate_graphs(gr)) return e;
+  TTDG_REQUIRE(cfg.max_iter >= 1 && cfg.sk_iter >= 0 && cfg.tau0 > 0.f && cfg.gamma > 0.f && cfg.gamma < 1.f,
+               "gagm: bad configuration");
+  int cmax = NU;
+  for (int g = 0; g < gr.G; ++g) cmax = gr.off[g + 1] - gr.off[g] > cmax ? gr.off[g + 1] - gr.off[g] : cmax;
+  TTDG_LIMIT(cmax <= 128, "gagm: graphs with more than 128 nodes need the multi-workgroup solver (not built yet)");
+  TTDG_LIMIT(gr.off[gr.G] <= 4096, "gagm: more than 4096 nodes in total");
+  const int cmaxp = (cmax + 63) & ~63;
+  const int M = gr.off[gr.G];
+  const int waves = 8;
+  const size_t fixed = ga_fixed_lds_bytes(cmaxp, waves);
+  const size_t state = (size_t)4 * M * NU * sizeof(float);
+  const bool lds = fixed + state <= 158 * 1024;
+  const size_t bytes = lds ? fixed + state : fixed;
+  hipStream_t st = (hipStream_t)stream;
+#define GA_LAUNCH(L, T, C)                                                                                         \
+  do {                                                                                                             \
+    TTDG_ALLOW_LDS((gagm_kernel<L, T, C>), bytes);                                                                 \
+    hipLaunchKernelGGL((gagm_kernel<L, T, C>), dim3(1), dim3(T), bytes, st, Apack, W, U0, gr, cfg, U, info, (float*)ws, cmaxp); \
+  } while (0)
+  if (cmax <= 64) { if (lds) GA_LAUNCH(true, 512, 1); else GA_LAUNCH(false, 512, 1); }
+  else            { if (lds) GA_LAUNCH(true, 512, 2);  else GA_LAUNCH(false, 512, 2); }
+#undef GA_LAUNCH
+  return ttdg_launch_status("gagm");
+}
