@@ -95,11 +95,11 @@ int ttdg_sinkhorn_batched_fwd(const float* s, int64_t sb, int64_t sr, int64_t sc
 
 /* ---- A3 intra-graph attention adjacency (utils/attentions.py:60-86, v2, 1 head) --
  * q, k: (M, d) projections (ttdg_gemm_f32).  Apack receives, per graph, softmax(q k^T * scale)
- * with the diagonal zeroed (multi_graph_matching.py:496-502), packed block after block
+ * with the diagonal zeroed when zero_diag != 0 (multi_graph_matching.py:496-502), packed block after block
  * (block g at offset sum_{h<g} n_h^2).  drop_p > 0 applies train-mode dropout on the attention
  * (attentions.py:40) from a Philox stream keyed by (seed, graph, row, col). */
 int ttdg_mha_adjacency(const float* q, const float* k, int d, ttdg_graphs_t gr, float scale, float drop_p,
-                       uint64_t seed, float* Apack, ttdg_stream_t stream);
+                       uint64_t seed, int zero_diag, float* Apack, ttdg_stream_t stream);
 
 /* ---- A6+A7 graduated-assignment multi-graph matching, whole solve on device ------
  * (multi_graph_matching.py:223-244, 300-389 with num_clusters == 1; utils/hungarian.py:8-66 ->

@@ -1,0 +1,425 @@
+"""GPU parity tests (run on the MI355X box with `-m gpu`): every HIP operator, called through the C ABI,
+against the CPU oracle and the committed golden vectors on the same seeded inputs.
+
+Bars (BASELINE.json north_star / SURVEY.md §8d): <=1e-4 fp32 on Wds, V, loss and gradients; identical
+permutation matrices; bit-exact for integer/index work (sampler, LAP)."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from ttdg_mgm_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    from ttdg_mgm_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def maxerr(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))) if a.size else 0.0
+
+
+def check_pgrad(gold, key, g, tol):
+    flat = g.detach().reshape(-1).cpu()
+    assert maxerr(flat[::cases.PSTRIDE], gold[key + "__sample"]) <= tol, key
+    n0 = float(gold[key + "__norm"])
+    assert abs(float(flat.double().norm()) - n0) <= tol * max(1.0, n0) * 10, key
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (7, 5, 3), (64, 64, 16), (120, 512, 256), (131, 257, 70), (2048, 32, 256)])
+def test_gemm_all_layouts(dev, M, N, K):
+    from ttdg_mgm_amd import ops
+    g = synth.gen(M * 1000 + N * 10 + K)
+    A, B = synth.normal(g, (M, K)).to(dev), synth.normal(g, (N, K)).to(dev)
+    bias = synth.normal(g, (N,)).to(dev)
+    ref = A.double() @ B.double().t()
+    tol = 2e-6 * K ** 0.5 * 4 + 1e-6
+    C = torch.empty(M, N, device=dev)
+    ops.gemm(A, K, 1, B, K, 1, C, N, 1, M, N, K)                                       # NT
+    assert maxerr(C, ref.float()) <= tol * 4
+    At, Bt = A.t().contiguous(), B.t().contiguous()
+    C2 = torch.empty(M, N, device=dev)
+    ops.gemm(At, 1, M, Bt, 1, N, C2, N, 1, M, N, K, bias=bias)                         # TN with bias
+    assert maxerr(C2, (ref + bias.double()).float()) <= tol * 4
+    C3 = torch.full((N, M), 2.0, device=dev)
+    ops.gemm(A, K, 1, B, K, 1, C3, 1, M, M, N, K, alpha=0.5, beta=1.0)                 # transposed C, alpha/beta
+    assert maxerr(C3, (0.5 * ref.t() + 2.0).float()) <= tol * 4
+
+
+def test_linear_autograd(dev):
+    from ttdg_mgm_amd import ops
+    g = synth.gen(77)
+    x, W, b = (synth.normal(g, s).to(dev).requires_grad_() for s in ((45, 256), (512, 256), (512,)))
+    y = ops.LinearFn.apply(x, W, b)
+    y.square().sum().backward()
+    xr, Wr, br = (t.detach().clone().requires_grad_() for t in (x, W, b))
+    torch.nn.functional.linear(xr, Wr, br).square().sum().backward()
+    assert maxerr(x.grad, xr.grad) <= 5e-3 and maxerr(W.grad, Wr.grad) <= 5e-3 and maxerr(b.grad, br.grad) <= 5e-3
+
+
+# ------------------------------------------------------------------------------------------- A4
+@pytest.mark.parametrize("ci", range(len(cases.AFF_CASES)))
+def test_affinity_golden(dev, golden, ci):
+    from ttdg_mgm_amd.GModule.utils.affinity import Affinity
+    gold = golden("affinity")
+    m = Affinity(256).to(dev)
+    sd = {k[len("node_affinity."):]: v for k, v in synth.mgm3_params(cases.AFF_PARAM_SEED).items() if k.startswith("node_affinity.")}
+    m.load_state_dict(sd, strict=True)
+    X, Y, R = (t.to(dev) for t in cases.aff_inputs(ci))
+    X.requires_grad_(), Y.requires_grad_()
+    M = m(X, Y)
+    (M * R).sum().backward()
+    assert maxerr(M, gold[f"c{ci}_M"]) <= 1e-5
+    assert maxerr(X.grad, gold[f"c{ci}_dX"]) <= TOL and maxerr(Y.grad, gold[f"c{ci}_dY"]) <= TOL
+    for k, p in m.named_parameters():
+        check_pgrad(gold, f"c{ci}_d_{k}", p.grad, 5e-4)
+
+
+def test_affinity_large_matches_oracle(dev):
+    """cfg-3 node count per graph (256) with K split and tile edges; oracle = materialised-MLP formulation."""
+    from oracle import gmodule as og
+    from ttdg_mgm_amd.GModule.utils.affinity import Affinity
+    p = synth.mgm3_params(31)
+    g = synth.gen(32)
+    X, Y = synth.normal(g, (200, 256), 0.5), synth.normal(g, (131, 256), 0.5)
+    ref = og.affinity(p, X, Y)
+    m = Affinity(256).to(dev)
+    m.load_state_dict({k[len("node_affinity."):]: v for k, v in p.items() if k.startswith("node_affinity.")})
+    assert maxerr(m(X.to(dev), Y.to(dev)), ref) <= 2e-5
+
+
+# ------------------------------------------------------------------------------------------- A3
+@pytest.mark.parametrize("ci", range(len(cases.MHA_CASES)))
+def test_mha_adjacency_golden(dev, golden, ci):
+    from ttdg_mgm_amd.GModule.utils.attentions import MultiHeadAttention
+    gold = golden("mha")
+    m = MultiHeadAttention(256, 1, dropout=0.1, version='v2').to(dev).eval()
+    sd = {k[len("intra_domain_graph."):]: v for k, v in synth.mgm3_params(cases.MHA_PARAM_SEED).items() if k.startswith("intra_domain_graph.")}
+    m.load_state_dict(sd, strict=True)
+    x = cases.mha_input(ci).to(dev)
+    out, adj = m([x, x, x])
+    assert maxerr(adj, gold[f"c{ci}_adj"]) <= 1e-5
+    assert out.shape == x.shape
+
+
+def test_mha_dropout_statistics(dev):
+    from ttdg_mgm_amd import ops
+    n, d = 64, 256
+    g = synth.gen(5)
+    q, k = synth.normal(g, (n, d), 0.1).to(dev), synth.normal(g, (n, d), 0.1).to(dev)
+    a0 = ops.mha_adjacency(q, k, ops.graphs([n]), [n], d ** -0.5, 0.0, 1, zero_diag=False).view(n, n)
+    a1 = ops.mha_adjacency(q, k, ops.graphs([n]), [n], d ** -0.5, 0.1, 1, zero_diag=False).view(n, n)
+    a2 = ops.mha_adjacency(q, k, ops.graphs([n]), [n], d ** -0.5, 0.1, 2, zero_diag=False).view(n, n)
+    kept = a1 != 0
+    assert 0.85 < float(kept.float().mean()) < 0.95                      # keep probability 0.9
+    assert maxerr(a1[kept], (a0 / 0.9)[kept]) <= 1e-6                     # survivors are rescaled
+    assert not torch.equal(a1 != 0, a2 != 0)                              # seed changes the mask
+
+
+# ------------------------------------------------------------------------------------------- A5
+SK_CASES = [  # b, r, c, dummy, tau, iters, n1, n2
+    (1, 9, 14, True, 0.05, 20, None, None), (1, 14, 9, True, 0.05, 20, None, None), (3, 16, 16, False, 0.5, 21, None, None),
+    (4, 22, 32, True, 0.1, 20, None, None), (3, 32, 40, True, 0.00625, 20, None, None), (1, 1, 5, True, 0.1, 20, None, None),
+    (3, 30, 32, True, 0.1, 20, (12, 30, 7), None), (3, 40, 32, True, 0.1, 20, (22, 40, 35), None),
+    (2, 100, 130, True, 0.05, 20, None, None), (1, 256, 256, True, 0.05, 20, None, None),
+]
+
+
+@pytest.mark.parametrize("b,r,c,dummy,tau,iters,n1,n2", SK_CASES)
+def test_sinkhorn_batched_vs_oracle(dev, b, r, c, dummy, tau, iters, n1, n2):
+    from oracle.sinkhorn_spec import sinkhorn as osk
+    from ttdg_mgm_amd import ops
+    s = synth.normal(synth.gen(b * 7 + r * 3 + c), (b, r, c), 0.3)
+    if n1 is not None:   # zero padding beyond the valid rows, as pad_tensor produces
+        for i, n in enumerate(n1):
+            s[i, n:] = 0
+    t1 = None if n1 is None else torch.tensor(n1)
+    ref = osk(s, n1=t1, dummy_row=dummy, max_iter=iters, tau=tau, batched_operation=True)
+    got = ops.sinkhorn_batched(s.to(dev), t1, None, dummy, tau, iters)
+    assert maxerr(got, ref) <= TOL
+
+
+def test_sinkhorn_module_2d_and_transposed_view(dev):
+    from oracle.sinkhorn_spec import sinkhorn as osk
+    from ttdg_mgm_amd.GModule.utils.sinkhorn import Sinkhorn
+    s = synth.normal(synth.gen(91), (12, 5), 0.3)
+    sk = Sinkhorn(max_iter=20, tau=0.05, epsilon=1e-10, batched_operation=False)
+    assert maxerr(sk(s.to(dev), dummy_row=True), osk(s, dummy_row=True, max_iter=20, tau=0.05)) <= TOL
+    assert maxerr(sk(s.to(dev).t(), dummy_row=True), osk(s.t(), dummy_row=True, max_iter=20, tau=0.05)) <= TOL
+
+
+@pytest.mark.parametrize("sizes", [(9, 14), (22, 22, 22), (22, 35, 28, 40), (5, 3)])
+def test_pair_sinkhorn_forward_backward(dev, sizes):
+    """Pair stage (Wds) and its backward against autograd through the oracle's Sinkhorn."""
+    from oracle import gmodule as og
+    from ttdg_mgm_amd import ops
+    G, M = len(sizes), sum(sizes)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    g = synth.gen(sum(sizes) * 13)
+    Mraw = synth.normal(g, (M, M), 0.1)
+    Rw = synth.normal(g, (M, M), 1.0)
+    b2 = torch.tensor([0.03])
+    # oracle: same loop as multi_graph_matching.py:504-525 on the raw affinities
+    Mr = Mraw.clone().requires_grad_()
+    Wds = torch.zeros(M, M)
+    for a in range(G):
+        for b in range(G):
+            if a < b:
+                continue
+            blk = Mr[off[a]:off[a + 1], off[b]:off[b + 1]] + b2
+            ds = og.sinkhorn_pair(blk) if sizes[b] >= sizes[a] else og.sinkhorn_pair(blk.t()).t()
+            Wds[off[a]:off[a + 1], off[b]:off[b + 1]] += ds
+            if a != b:
+                Wds[off[b]:off[b + 1], off[a]:off[a + 1]] += ds.t()
+    # loss only touches the a<b blocks (rows of graph a, cols of graph b)
+    mask = torch.zeros(M, M)
+    for a in range(G):
+        for b in range(a + 1, G):
+            mask[off[a]:off[a + 1], off[b]:off[b + 1]] = 1
+    (Wds * Rw * mask).sum().backward()
+
+    gr = ops.graphs(sizes)
+    ks = 2
+    part = torch.stack([Mraw * 0.25, Mraw * 0.75]).to(dev).contiguous()   # two K-slices that sum to Mraw
+    Wd, pot = ops.sinkhorn_pairs_fwd(part, b2.to(dev), gr, list(sizes), 0.05, 20)
+    assert maxerr(Wd, Wds) <= TOL
+    dM = ops.sinkhorn_pairs_bwd(part, b2.to(dev), pot, (Rw * mask).to(dev), gr, 0.05, 20)
+    low = torch.zeros(M, M)
+    for a in range(G):
+        for b in range(a):
+            low[off[a]:off[a + 1], off[b]:off[b + 1]] = 1
+    assert maxerr(dM.cpu() * low, Mr.grad * low) <= 2e-3 * float(Mr.grad.abs().max()) + 1e-5
+
+
+# ------------------------------------------------------------------------------------------- A7
+@pytest.mark.parametrize("ci", range(len(cases.HUNG_CASES)))
+def test_hungarian_golden(dev, golden, ci):
+    from ttdg_mgm_amd.GModule.utils.hungarian import hungarian
+    gold = golden("hungarian")
+    assert maxerr(hungarian(cases.hung_input(ci).to(dev)), gold[f"c{ci}_x"]) == 0
+
+
+def test_hungarian_ties_and_errors(dev, golden):
+    from ttdg_mgm_amd.GModule.utils.hungarian import hungarian
+    gold = golden("hungarian")
+    assert maxerr(hungarian(torch.from_numpy(gold["ties_s"]).to(dev)), gold["ties_x"]) == 0
+    with pytest.raises(ValueError):
+        hungarian(torch.zeros(3, device=dev))
+
+
+@pytest.mark.parametrize("shape", [(6, 6), (12, 32), (40, 32), (32, 95), (64, 64), (256, 32), (20, 33)])
+def test_lap_batched_vs_scipy_incl_ties(dev, shape):
+    import scipy.optimize
+    from ttdg_mgm_amd import ops
+    mats = []
+    for seed in range(24):
+        g = synth.gen(9300 + seed)
+        if seed % 2:
+            m = g.integers(0, 3, size=shape).astype(np.float32)
+            if seed % 3 == 0:
+                m[:, g.integers(0, shape[1], size=max(1, shape[1] // 3))] = 0
+        else:
+            m = g.standard_normal(shape).astype(np.float32)
+        mats.append(m)
+    s = torch.from_numpy(np.stack(mats))
+    x = ops.lap_batched(s.to(dev)).cpu().numpy()
+    for i, m in enumerate(mats):
+        r, c = scipy.optimize.linear_sum_assignment(m.astype(np.float64) * -1)
+        ref = np.zeros(shape, np.float32)
+        ref[r, c] = 1
+        assert np.array_equal(x[i], ref), i
+
+
+# ------------------------------------------------------------------------------------------- A6
+@pytest.mark.parametrize("name,sizes,seed", cases.GAGM_CASES)
+def test_gagm_golden(dev, golden, name, sizes, seed):
+    from ttdg_mgm_amd.GModule.multi_graph_matching import GA_GM
+    gold = golden("gagm")
+    A, W, U0 = cases.gagm_inputs(sizes, seed)
+    solver = GA_GM(mgm_iter=[200], cluster_iter=10, sk_iter=20, sk_tau0=[0.1], sk_gamma=0.5, cluster_beta=[1.0, 0.0],
+                   converge_tol=1.0e-3, min_tau=[1.0e-2], projector0=['sinkhorn', 'sinkhorn'])
+    U, cluster = solver(A.to(dev), W.to(dev), U0.to(dev), torch.tensor(sizes, dtype=torch.int), 32, 0.5, 1)
+    info = solver.last_info.cpu().tolist()
+    print(name, "iterations per stage", info[:6], "total", info[6])
+    assert info[7] == 6 and tuple(cluster.tolist()) == (0,) * len(sizes)
+    Ug = gold[f"{name}_U"]
+    Uc = U.cpu().numpy()
+    assert set(np.unique(Uc)).issubset({0.0, 1.0})
+    assert np.array_equal(Uc, Ug), "permutations differ from the reference on %d of %d rows" % (
+        int((Uc != Ug).any(1).sum()), Uc.shape[0])
+
+
+@pytest.mark.parametrize("name,sizes,seed", cases.GAGM_CASES)
+def test_gagm_first_iteration_V(dev, golden, name, sizes, seed):
+    from ttdg_mgm_amd import ops
+    gold = golden("gagm")
+    A, W, U0 = cases.gagm_inputs(sizes, seed)
+    off, blocks = 0, []
+    for n in sizes:
+        blocks.append(A[off:off + n, off:off + n].reshape(-1))
+        off += n
+    U, info, V0 = ops.gagm_solve(torch.cat(blocks).to(dev), W.to(dev), U0.to(dev), ops.graphs(sizes), list(sizes),
+                                 ops.gagm_cfg(max_iter=1))
+    ref = gold[f"{name}_V0"]
+    assert maxerr(V0, ref) <= TOL * max(1.0, float(np.abs(ref).max()))
+
+
+def test_gagm_rejects_unknown_modes(dev):
+    from ttdg_mgm_amd.GModule.multi_graph_matching import GA_GM
+    with pytest.raises(NameError):
+        GA_GM(projector0=('nope',))._cfg(1.0)
+    with pytest.raises(NotImplementedError):
+        GA_GM()(torch.zeros(2, 2), torch.zeros(2, 2), torch.zeros(2, 32), torch.tensor([1, 1]), 32, num_clusters=2)
+
+
+# ------------------------------------------------------------------------------------------- A8/A9
+@pytest.mark.parametrize("ci", range(3))
+def test_perm_loss_kernel_vs_golden(dev, golden, ci):
+    """loss.hip on a 2-graph problem: the a<b block of Wds is the golden score matrix (clamp edges included),
+    the pseudo-label is U_a U_b^T for random one-hot assignments; checked against the oracle formula, which
+    tests/test_oracle_golden.py pins to the reference's PermutationLoss."""
+    from oracle import gmodule as og
+    from ttdg_mgm_amd import ops
+    gold = golden("loss")
+    s = gold[f"c{ci}_s"]
+    na, nb = s.shape
+    g = synth.gen(40 + ci)
+    Ua = torch.zeros(na, 32); Ub = torch.zeros(nb, 32)
+    Ua[torch.arange(na), torch.from_numpy(g.integers(0, 32, na))] = 1
+    Ub[torch.arange(nb), torch.from_numpy(g.integers(0, 32, nb))] = 1
+    M = na + nb
+    Wds = torch.zeros(M, M)
+    Wds[:na, na:] = torch.from_numpy(s)
+    sr = torch.from_numpy(s).clone().requires_grad_()
+    ref = og.permutation_loss(sr.unsqueeze(0), (Ua @ Ub.t()).unsqueeze(0))
+    ref.backward()
+    loss, dW, flag = ops.perm_loss_fwd_bwd(Wds.to(dev), torch.cat([Ua, Ub]).to(dev), ops.graphs([na, nb]), 2)
+    assert abs(float(loss) - float(ref)) <= 1e-6
+    assert maxerr(dW[:na, na:], sr.grad) <= 1e-6 and int(flag.item()) == 0
+    assert float(dW[na:, :].abs().max()) == 0 and float(dW[:na, :na].abs().max()) == 0
+    bad = Wds.clone(); bad[0, na] = 1.5
+    _, _, flag = ops.perm_loss_fwd_bwd(bad.to(dev), torch.cat([Ua, Ub]).to(dev), ops.graphs([na, nb]), 2)
+    assert int(flag.item()) == 1
+
+
+@pytest.mark.parametrize("name", [c[0] for c in cases.MGM_CASES])
+def test_mgm3_end_to_end_golden(dev, golden, name):
+    from ttdg_mgm_amd.GModule import MGM3_unsup
+    gold = golden("mgm3")
+    params, nodes, labels, U, sizes = cases.mgm_inputs(name)
+    m = MGM3_unsup(2, 32).to(dev).eval()
+    m.load_state_dict(params, strict=True)
+    dn = [x.to(dev).requires_grad_() for x in nodes]
+    tr = {}
+    loss = m(dn, [l.to(dev) for l in labels], U.to(dev), trace=tr)
+    loss.backward()
+    print(name, "gagm iterations", tr["info"].cpu().tolist()[:7])
+    assert abs(float(loss) - float(gold[f"{name}_loss"])) <= TOL
+    for gi, x in enumerate(dn):
+        assert maxerr(x.grad, gold[f"{name}_dnode{gi}"]) <= TOL, gi
+    for k, p in m.named_parameters():
+        if f"{name}_nograd_{k}" in gold:
+            assert p.grad is None, k
+        else:
+            check_pgrad(gold, f"{name}_d_{k}", p.grad, TOL)
+
+
+@pytest.mark.parametrize("name", [c[0] for c in cases.MGM_CASES])
+def test_mgm3_intermediates_vs_oracle(dev, name):
+    from oracle import gmodule as og
+    from ttdg_mgm_amd.GModule import MGM3_unsup
+    params, nodes, labels, U, sizes = cases.mgm_inputs(name)
+    otr = {}
+    og.mgm3_unsup_forward(params, nodes, labels, U, trace=otr)
+    m = MGM3_unsup(2, 32).to(dev).eval()
+    m.load_state_dict(params, strict=True)
+    tr = {}
+    with torch.no_grad():
+        m([x.to(dev) for x in nodes], [l.to(dev) for l in labels], U.to(dev), trace=tr)
+    assert maxerr(tr["Wds"], otr["Wds"]) <= TOL
+    assert maxerr(tr["U0"], otr["U0"]) <= TOL * max(1.0, float(otr["U0"].abs().max()))
+    assert maxerr(tr["V0"], otr["V0"]) <= TOL * max(1.0, float(otr["V0"].abs().max()))
+    off, blocks = 0, []
+    for n in sizes:
+        blocks.append(otr["A"][off:off + n, off:off + n].reshape(-1))
+        off += n
+    assert maxerr(tr["apack"], torch.cat(blocks)) <= 1e-5
+    assert torch.equal(tr["Ub"].cpu(), otr["Ub"])
+    assert tr["info"].cpu().tolist()[:6] == otr["iters"]
+
+
+def test_mgm3_none_and_train_mode(dev):
+    from ttdg_mgm_amd.GModule import MGM3_unsup
+    m = MGM3_unsup(2, 32).to(dev)
+    nodes, labels = synth.node_sets(1, (9,))
+    U = synth.universe(2).to(dev)
+    assert m([nodes[0].to(dev)], [labels[0].to(dev)], U) is None
+    assert m(None, None, U) is None
+    nodes, labels = synth.node_sets(3, (20, 24, 17), scale=0.5)
+    m.load_state_dict(synth.mgm3_params(9), strict=True)
+    m.train()                                     # dropout on the attention: stochastic but finite
+    l1 = m([x.to(dev) for x in nodes], [l.to(dev) for l in labels], U)
+    assert torch.isfinite(l1) and float(l1) > 0
+
+
+# ------------------------------------------------------------------------------------------- A2
+@pytest.mark.parametrize("ci", range(len(cases.PROTO_CASES)))
+def test_prototype_computation_golden(dev, golden, ci):
+    from oracle.ref_import import FakeInstances
+    from ttdg_mgm_amd.GModule import PrototypeComputation
+    gold = golden("proto")
+    name, feats, boxes, classes = cases.proto_inputs(ci)
+    pc = PrototypeComputation(2, 10)
+    fd = [f.to(dev).requires_grad_() for f in feats]
+    nodes, labels = pc(fd, [FakeInstances(b.to(dev), c.to(dev)) for b, c in zip(boxes, classes)])
+    if f"{name}_none" in gold:
+        assert nodes is None and labels is None
+        return
+    assert [len(n) for n in nodes] == gold[f"{name}_count"].tolist()
+    for gi, (n, l) in enumerate(zip(nodes, labels)):
+        assert maxerr(n, gold[f"{name}_nodes{gi}"]) == 0, gi
+        assert np.array_equal(l.cpu().numpy(), gold[f"{name}_labels{gi}"]) and l.dtype == torch.int64
+    # gather backward = scatter: gradient of sum(nodes * R) lands exactly on the selected points
+    tot = sum((n * (gi + 1)).sum() for gi, n in enumerate(nodes))
+    tot.backward()
+    nsel = sum(len(n) for n in nodes)
+    nz = sum(int((f.grad != 0).sum()) for f in fd)
+    assert nz == nsel * 256
+
+
+# ------------------------------------------------------------------------------------------- A11
+def test_fused_sgd_vs_oracle(dev):
+    from oracle import gmodule as og
+    from ttdg_mgm_amd.optim import FusedSGD
+    g = synth.gen(123)
+    shapes = [(512, 512), (512,), (1, 512), (1,), (256, 256), (3, 3, 64, 64), (7,), (1000003,)]
+    ps = [synth.normal(g, s) for s in shapes]
+    ref_p = [p.clone() for p in ps]
+    bufs = [None] * len(ps)
+    dp = [torch.nn.Parameter(p.clone().to(dev)) for p in ps]
+    opt = FusedSGD([{"params": [p], "weight_decay": (0.0 if i == 1 else 1e-4)} for i, p in enumerate(dp)], lr=0.005, momentum=0.9)
+    for step in range(3):
+        grads = [synth.normal(g, s) for s in shapes]
+        if step == 1:
+            grads[4] = None                     # tensors without a gradient are skipped
+        for p, gr in zip(dp, grads):
+            p.grad = None if gr is None else gr.to(dev)
+        opt.step()
+        # oracle step with per-tensor weight decay
+        for i, (p, gr) in enumerate(zip(ref_p, grads)):
+            b = [bufs[i]]
+            og.sgd_step([p], [gr], b, 0.005, 0.9, 0.0 if i == 1 else 1e-4)
+            bufs[i] = b[0]
+    for p, r in zip(dp, ref_p):
+        assert maxerr(p, r) <= 1e-6

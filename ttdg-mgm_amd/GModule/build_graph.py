@@ -1,0 +1,62 @@
+"""PrototypeComputation — mirror of reference build_graph.py:11-250 (graph-node sampler).
+
+Same constructor, same ``__call__(features, targets) -> (nodes, labels) | (None, None)``; targets are
+detectron2-style Instances (``len(t)``, ``t.pred_boxes.tensor`` / ``t.gt_boxes.tensor``,
+``t.pred_classes`` / ``t.gt_classes``).  Label assignment, ordered strided selection and the feature
+gather (+ its scatter backward) are HIP kernels (csrc/sampler.hip); one small D2H copy returns the node
+counts the host needs to shape the graphs."""
+import torch
+
+from .. import ops
+
+INF = 100000000
+
+
+class PrototypeComputation(object):
+    def __init__(self, num_cls, sample_dist):
+        self.num_class = num_cls
+        self.num_nodes_per_class = sample_dist
+        self.bg_ratio = 8
+        self.strides = [4, 8, 16, 32, 64]
+        self.object_sizes_of_interest = [[-1, 64], [64, 128], [128, 256], [256, 512], [512, INF]]
+
+    @staticmethod
+    def _boxes_classes(t):
+        fields = getattr(t, "_fields", {})
+        if 'gt_boxes' in fields:
+            return t.gt_boxes.tensor, t.gt_classes
+        return t.pred_boxes.tensor, t.pred_classes
+
+    def __call__(self, features, targets):
+        if not any(len(t) for t in targets):
+            return None, None
+        dev = features[0].device
+        nl = len(features)
+        shapes = [(int(f.shape[-2]), int(f.shape[-1])) for f in features]
+        lv = ops.levels_desc(shapes, self.strides[:nl], self.object_sizes_of_interest[:nl])
+        npts = sum(h * w for h, w in shapes)
+        # the reference skips box-less images when it builds labels (:79) but pairs label list entry k with
+        # feature image k (:173-181): reproduce that pairing
+        with_boxes = [t for t in targets if len(t)]
+        B = len(with_boxes)
+        kmax = max(len(t) for t in with_boxes)
+        boxes = torch.zeros(B, kmax, 4, device=dev, dtype=torch.float32)
+        classes = torch.zeros(B, kmax, device=dev, dtype=torch.int32)
+        for k, t in enumerate(with_boxes):
+            bx, cl = self._boxes_classes(t)
+            boxes[k, :len(t)] = bx.detach().to(dev, torch.float32)
+            classes[k, :len(t)] = cl.detach().to(dev, torch.int32)
+        nbox = torch.tensor([len(t) for t in with_boxes], dtype=torch.int32).to(dev, non_blocking=True)
+        labels = ops.node_labels(boxes, classes, nbox, lv, npts)
+        cap = nl * (2 * self.num_nodes_per_class - 1)
+        sel_idx, sel_lab, count = ops.node_select(labels, lv, self.num_nodes_per_class, cap)
+        counts = count.tolist()                                   # the one host sync of the sampler
+        img = torch.cat([torch.full((c,), k, dtype=torch.int32) for k, c in enumerate(counts)]).to(dev, non_blocking=True)
+        flat = torch.cat([torch.arange(c, dtype=torch.int64) + k * cap for k, c in enumerate(counts)]).to(dev, non_blocking=True)
+        pid = sel_idx.view(-1)[flat].contiguous()
+        lab = sel_lab.view(-1)[flat].to(torch.int64)
+        feats = [f if (f.dtype == torch.float32 and f.is_contiguous()) else f.float().contiguous() for f in features]
+        rows = ops.NodeGatherFn.apply(img, pid, *feats)
+        nodes = list(torch.split(rows, counts, dim=0))
+        labs = list(torch.split(lab, counts, dim=0))
+        return nodes, labs

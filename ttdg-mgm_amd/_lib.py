@@ -1,0 +1,130 @@
+"""ctypes binding of csrc/libttdg_mgm.so (the C ABI of include/ttdg_mgm.h).
+
+No torch types cross the boundary: tensors are passed as raw device pointers
+(``tensor.data_ptr()``) plus sizes, and every call is enqueued on torch's
+current HIP stream.  There is NO fallback: a missing library, a CPU tensor or
+a non-zero status raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libttdg_mgm.so")
+
+MAX_GRAPHS = 64
+MAX_LEVELS = 8
+UNIV = 32
+
+
+class Graphs(C.Structure):
+    _fields_ = [("G", C.c_int32), ("off", C.c_int32 * (MAX_GRAPHS + 1))]
+
+
+class GagmCfg(C.Structure):
+    _fields_ = [("tau0", C.c_float), ("gamma", C.c_float), ("min_tau", C.c_float), ("tol", C.c_float),
+                ("quad_weight", C.c_float), ("max_iter", C.c_int32), ("sk_iter", C.c_int32)]
+
+
+class Levels(C.Structure):
+    _fields_ = [("n", C.c_int32), ("h", C.c_int32 * MAX_LEVELS), ("w", C.c_int32 * MAX_LEVELS),
+                ("stride", C.c_int32 * MAX_LEVELS), ("lo", C.c_float * MAX_LEVELS), ("hi", C.c_float * MAX_LEVELS)]
+
+
+class Fpn(C.Structure):
+    _fields_ = [("n", C.c_int32), ("C", C.c_int32), ("h", C.c_int32 * MAX_LEVELS), ("w", C.c_int32 * MAX_LEVELS),
+                ("feat", C.c_void_p * MAX_LEVELS)]
+
+
+class SgdTensor(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("buf", C.c_void_p), ("n", C.c_int64), ("wd", C.c_float),
+                ("first", C.c_int32)]
+
+
+_P, _I, _L, _F, _S = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_void_p
+
+# name -> (restype, argtypes); one entry per symbol declared in include/ttdg_mgm.h
+SIGNATURES = {
+    "ttdg_version": (C.c_int, []),
+    "ttdg_last_error": (C.c_char_p, []),
+    "ttdg_gemm_f32": (C.c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _F, _F, _S]),
+    "ttdg_colsum_f32": (C.c_int, [_P, _L, _P, _I, _I, _S]),
+    "ttdg_affinity_pairwise_fwd": (C.c_int, [_P, _P, _P, _I, Graphs, _I, _P, _S]),
+    "ttdg_affinity_pairwise_bwd": (C.c_int, [_P, _P, _P, _P, _I, Graphs, _P, _P, _P, _P, _S]),
+    "ttdg_sinkhorn_pairs_fwd": (C.c_int, [_P, _I, _P, Graphs, _F, _I, _P, _P, _S]),
+    "ttdg_sinkhorn_pairs_bwd": (C.c_int, [_P, _I, _P, _P, _P, Graphs, _F, _I, _P, _S]),
+    "ttdg_sinkhorn_batched_fwd": (C.c_int, [_P, _L, _L, _L, _I, _I, _I, _P, _P, _I, _F, _I, _P, _S]),
+    "ttdg_mha_adjacency": (C.c_int, [_P, _P, _I, Graphs, _F, _F, C.c_uint64, _I, _P, _S]),
+    "ttdg_gagm_workspace_bytes": (C.c_size_t, [_I]),
+    "ttdg_gagm_solve": (C.c_int, [_P, _P, _P, Graphs, GagmCfg, _P, _P, _P, _S]),
+    "ttdg_lap_batched": (C.c_int, [_P, _I, _I, _I, _P, _S]),
+    "ttdg_perm_loss_fwd_bwd": (C.c_int, [_P, _P, Graphs, _F, _F, _P, _P, _P, _P, _S]),
+    "ttdg_node_labels": (C.c_int, [_P, _P, _P, _I, _I, Levels, _P, _S]),
+    "ttdg_node_select": (C.c_int, [_P, _I, Levels, _I, _I, _P, _P, _P, _S]),
+    "ttdg_node_gather_fwd": (C.c_int, [Fpn, _P, _P, _I, _P, _S]),
+    "ttdg_node_gather_bwd": (C.c_int, [Fpn, _P, _P, _I, _P, _S]),
+    "ttdg_sgd_multi_tensor": (C.c_int, [_P, _P, _P, _I, _I, _F, _F, _S]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "ttdg_mgm_amd: %s is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError = ABI drift, fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def graphs(sizes):
+    sizes = [int(s) for s in sizes]
+    if not 1 <= len(sizes) <= MAX_GRAPHS:
+        raise ValueError("between 1 and %d graphs are supported, got %d" % (MAX_GRAPHS, len(sizes)))
+    g = Graphs()
+    g.G = len(sizes)
+    acc = 0
+    for i, s in enumerate(sizes):
+        if s <= 0:
+            raise ValueError("empty graph")
+        g.off[i] = acc
+        acc += s
+    g.off[len(sizes)] = acc
+    return g
+
+
+def ptr(t):
+    """Device pointer of a tensor the kernels may touch: fp32/int32/int64 on a HIP device, contiguous unless
+    the callee takes strides."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("ttdg_mgm_amd operators run on the GPU only (got a %s tensor); no CPU fallback" % t.device)
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (name, rc, lib.ttdg_last_error().decode()))
+
+
+def check_f32(*ts):
+    for t in ts:
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise TypeError("expected contiguous float32 tensors")

@@ -29,7 +29,7 @@ __device__ __forceinline__ uint32_t philox_uniform_bits(uint64_t seed, uint32_t 
 
 __global__ __launch_bounds__(256) void mha_adjacency_kernel(const float* __restrict__ q, const float* __restrict__ k, int d,
                                                             ttdg_graphs_t gr, float scale, float drop_p, uint64_t seed,
-                                                            float* __restrict__ Apack, int nmax) {
+                                                            int zero_diag, float* __restrict__ Apack, int nmax) {
   extern __shared__ __attribute__((aligned(16))) float mha_smem[];  // [MHA_ROWS][d] q rows + [MHA_ROWS][nmax] scores
   const int g = blockIdx.y;
   const int n = gr.off[g + 1] - gr.off[g];
@@ -77,12 +77,12 @@ __global__ __launch_bounds__(256) void mha_adjacency_kernel(const float* __restr
       const float u = (float)(philox_uniform_bits(seed, (uint32_t)g, (uint32_t)i, (uint32_t)j) >> 8) * (1.f / 16777216.f);
       v = (u < drop_p) ? 0.f : v * keep_scale;
     }
-    arow[j] = (j == i) ? 0.f : v;
+    arow[j] = (zero_diag && j == i) ? 0.f : v;
   }
 }
 
 extern "C" int ttdg_mha_adjacency(const float* q, const float* k, int d, ttdg_graphs_t gr, float scale, float drop_p,
-                                  uint64_t seed, float* Apack, ttdg_stream_t stream) {
+                                  uint64_t seed, int zero_diag, float* Apack, ttdg_stream_t stream) {
   TTDG_REQUIRE(q && k && Apack && d > 0 && d % 4 == 0, "mha_adjacency: bad arguments");
   TTDG_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "mha_adjacency: dropout probability out of range");
   if (int e = ttdg_validate_graphs(gr)) return e;
@@ -92,6 +92,6 @@ extern "C" int ttdg_mha_adjacency(const float* q, const float* k, int d, ttdg_gr
   TTDG_LIMIT(bytes <= 150 * 1024, "mha_adjacency: graph too large");
   TTDG_ALLOW_LDS(mha_adjacency_kernel, bytes);
   hipLaunchKernelGGL(mha_adjacency_kernel, dim3((nmax + MHA_ROWS - 1) / MHA_ROWS, gr.G), dim3(256), bytes,
-                     (hipStream_t)stream, q, k, d, gr, scale, drop_p, seed, Apack, nmax);
+                     (hipStream_t)stream, q, k, d, gr, scale, drop_p, seed, zero_diag, Apack, nmax);
   return ttdg_launch_status("mha_adjacency");
 }

@@ -1,0 +1,291 @@
+"""Operators over the C ABI (include/ttdg_mgm.h) + their autograd wiring.
+
+Every function here launches hand-written HIP kernels through ``_lib.call``;
+PyTorch only provides device memory, the current stream and the autograd tape.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import call, check_f32, graphs, ptr, stream
+
+DIM, HID, UNIV = 256, 512, 32
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+def gemm(A, sam, sak, B, sbn, sbk, Cout, scm, scn, M, N, K, bias=None, alpha=1.0, beta=0.0,
+         a_off=0, b_off=0, c_off=0):
+    """C[m,n] = alpha * sum_k A(m,k) B(n,k) + bias[n] + beta*C[m,n] (element strides; offsets in elements)."""
+    call("ttdg_gemm_f32", ptr(A) + 4 * a_off, sam, sak, ptr(B) + 4 * b_off, sbn, sbk, ptr(Cout) + 4 * c_off, scm, scn,
+         ptr(bias), M, N, K, float(alpha), float(beta), stream())
+    return Cout
+
+
+def linear_raw(x, W, b=None, w_col_off=0, w_ld=None, out=None):
+    """y = x @ W[:, off:off+K]^T + b  (x: (M,K) contiguous, W row-major with leading dimension w_ld)."""
+    M, K = x.shape
+    N = W.shape[0]
+    ld = W.shape[1] if w_ld is None else w_ld
+    y = out if out is not None else torch.empty(M, N, device=x.device, dtype=torch.float32)
+    gemm(x, K, 1, W, ld, 1, y, N, 1, M, N, K, bias=b, b_off=w_col_off)
+    return y
+
+
+def colsum(X):
+    out = torch.empty(X.shape[1], device=X.device, dtype=torch.float32)
+    call("ttdg_colsum_f32", ptr(X), X.shape[1], ptr(out), X.shape[0], X.shape[1], stream())
+    return out
+
+
+class LinearFn(torch.autograd.Function):
+    """nn.Linear on the MFMA GEMM (forward + both backward products)."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        check_f32(x, W)
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = b is not None
+        return linear_raw(x, W, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, K = x.shape
+        N = W.shape[0]
+        dx = torch.empty_like(x)
+        gemm(dy, N, 1, W, 1, K, dx, K, 1, M, K, N)                 # dx = dy W
+        dW = torch.empty_like(W)
+        gemm(dy, 1, N, x, 1, K, dW, K, 1, N, K, M)                 # dW = dy^T x
+        db = colsum(dy) if ctx.has_bias else None
+        return dx, dW, db
+
+
+# ------------------------------------------------------------------------------------------- pieces
+def pick_ksplit(M, H=HID):
+    """Split K so that the pairwise kernel launches >= ~256 workgroups (one per CU) on small batches."""
+    nt = (M + 63) // 64
+    tiles = nt * (nt + 1) // 2
+    ks = 1
+    while ks < 16 and tiles * ks < 256 and H % (ks * 2 * 32) == 0:
+        ks *= 2
+    return ks
+
+
+def affinity_pairwise_fwd(P, Q, w2, gr, ksplit):
+    M = P.shape[0]
+    part = torch.empty(ksplit, M, M, device=P.device, dtype=torch.float32)
+    call("ttdg_affinity_pairwise_fwd", ptr(P), ptr(Q), ptr(w2), P.shape[1], gr, ksplit, ptr(part), stream())
+    return part
+
+
+def affinity_pairwise_bwd(P, Q, w2, dM, gr):
+    dP, dQ = torch.empty_like(P), torch.empty_like(Q)
+    dw2 = torch.empty(P.shape[1], device=P.device, dtype=torch.float32)
+    db2 = torch.empty(1, device=P.device, dtype=torch.float32)
+    call("ttdg_affinity_pairwise_bwd", ptr(P), ptr(Q), ptr(w2), ptr(dM), P.shape[1], gr, ptr(dP), ptr(dQ), ptr(dw2),
+         ptr(db2), stream())
+    return dP, dQ, dw2, db2
+
+
+def sinkhorn_pairs_fwd(part, b2, gr, sizes, tau, iters, want_pot=True):
+    ks, M, _ = part.shape
+    Wds = torch.empty(M, M, device=part.device, dtype=torch.float32)
+    G = len(sizes)
+    pot = None
+    if want_pot:
+        pot = torch.empty(G * (G + 1) // 2, iters, max(sizes) + 1, device=part.device, dtype=torch.float32)
+    call("ttdg_sinkhorn_pairs_fwd", ptr(part), ks, ptr(b2), gr, float(tau), int(iters), ptr(Wds), ptr(pot), stream())
+    return Wds, pot
+
+
+def sinkhorn_pairs_bwd(part, b2, pot, dWds, gr, tau, iters):
+    ks, M, _ = part.shape
+    dM = torch.empty(M, M, device=part.device, dtype=torch.float32)
+    call("ttdg_sinkhorn_pairs_bwd", ptr(part), ks, ptr(b2), ptr(pot), ptr(dWds), gr, float(tau), int(iters), ptr(dM), stream())
+    return dM
+
+
+def sinkhorn_batched(s, n1=None, n2=None, dummy_row=False, tau=1.0, iters=10):
+    """(b, r, c) -> (b, r, c); any strides on the input."""
+    assert s.dim() == 3 and s.dtype == torch.float32
+    b, r, c = s.shape
+    out = torch.empty(b, r, c, device=s.device, dtype=torch.float32)
+    n1 = None if n1 is None else n1.to(device=s.device, dtype=torch.int32).contiguous()
+    n2 = None if n2 is None else n2.to(device=s.device, dtype=torch.int32).contiguous()
+    call("ttdg_sinkhorn_batched_fwd", ptr(s), s.stride(0), s.stride(1), s.stride(2), b, r, c, ptr(n1), ptr(n2),
+         int(bool(dummy_row)), float(tau), int(iters), ptr(out), stream())
+    return out
+
+
+def mha_adjacency(q, k, gr, sizes, scale, drop_p=0.0, seed=0, zero_diag=True):
+    apack = torch.empty(sum(n * n for n in sizes), device=q.device, dtype=torch.float32)
+    call("ttdg_mha_adjacency", ptr(q), ptr(k), q.shape[1], gr, float(scale), float(drop_p), C.c_uint64(int(seed)),
+         int(bool(zero_diag)), ptr(apack), stream())
+    return apack
+
+
+def gagm_cfg(tau0=0.1, gamma=0.5, min_tau=1e-2, tol=1e-3, quad_weight=0.5, max_iter=200, sk_iter=20):
+    c = _lib.GagmCfg()
+    c.tau0, c.gamma, c.min_tau, c.tol, c.quad_weight = tau0, gamma, min_tau, tol, quad_weight
+    c.max_iter, c.sk_iter = int(max_iter), int(sk_iter)
+    return c
+
+
+def gagm_solve(apack, W, U0, gr, sizes, cfg=None):
+    """Returns (U (M,32) 0/1, info int32[16] on device, V0 (M,32) first-iteration V)."""
+    M = sum(sizes)
+    cfg = cfg or gagm_cfg()
+    nbytes = _lib.load().ttdg_gagm_workspace_bytes(M)
+    ws = torch.empty(nbytes // 4, device=W.device, dtype=torch.float32)
+    U = torch.empty(M, UNIV, device=W.device, dtype=torch.float32)
+    info = torch.zeros(16, device=W.device, dtype=torch.int32)
+    call("ttdg_gagm_solve", ptr(apack), ptr(W), ptr(U0), gr, cfg, ptr(U), ptr(info), ptr(ws), stream())
+    return U, info, ws[:M * UNIV].view(M, UNIV)
+
+
+def lap_batched(s):
+    assert s.dim() == 3
+    s = s.contiguous().float()
+    x = torch.empty_like(s)
+    call("ttdg_lap_batched", ptr(s), s.shape[0], s.shape[1], s.shape[2], ptr(x), stream())
+    return x
+
+
+def perm_loss_fwd_bwd(Wds, U, gr, G, alpha=0.25, eps=1e-6):
+    M = Wds.shape[0]
+    loss = torch.empty((), device=Wds.device, dtype=torch.float32)
+    dWds = torch.empty(M, M, device=Wds.device, dtype=torch.float32)
+    flag = torch.empty(1, device=Wds.device, dtype=torch.int32)
+    pws = torch.empty(G * (G - 1) // 2, device=Wds.device, dtype=torch.float32)
+    call("ttdg_perm_loss_fwd_bwd", ptr(Wds), ptr(U), gr, float(alpha), float(eps), ptr(loss), ptr(dWds), ptr(flag),
+         ptr(pws), stream())
+    return loss, dWds, flag
+
+
+# ------------------------------------------------------------------------------------------- fused matching loss
+class MatchingLossFn(torch.autograd.Function):
+    """MGM3_unsup.forward (reference multi_graph_matching.py:487-569) as one tape node.
+
+    forward : P/Q projections (MFMA GEMM) -> pairwise affinity -> pair Sinkhorn (Wds) ;
+              q/k projections -> attention adjacency (A) ; U0 = X U^T ; GA-MGM solve (no grad) ;
+              focal permutation loss, whose kernel also emits d loss / d Wds.
+    backward: Sinkhorn bwd -> affinity bwd -> GEMM bwd, into the stacked node features and the six
+              node_affinity tensors.  intra_domain_graph.* and U receive no gradient, as in the
+              reference (A and U0 only feed the gradient-free solver).
+    """
+
+    @staticmethod
+    def forward(ctx, X, W1, b1, w2, b2, Psr, Ptg, Wq, bq, Wk, bk, U, sizes, opts):
+        check_f32(X, W1, b1, w2, b2, Psr, Ptg, Wq, bq, Wk, bk, U)
+        sizes = [int(s) for s in sizes]
+        gr = graphs(sizes)
+        G, M = len(sizes), sum(sizes)
+        Xs = linear_raw(X, Psr)
+        Xt = linear_raw(X, Ptg)
+        P = linear_raw(Xs, W1, None, 0, HID)
+        Q = linear_raw(Xt, W1, b1, DIM, HID)
+        w2f = w2.reshape(-1)
+        ks = opts.get("ksplit") or pick_ksplit(M)
+        part = affinity_pairwise_fwd(P, Q, w2f, gr, ks)
+        tau, iters = opts.get("pair_tau", 0.05), opts.get("pair_iters", 20)
+        Wds, pot = sinkhorn_pairs_fwd(part, b2, gr, sizes, tau, iters)
+        q = linear_raw(X, Wq, bq)
+        k = linear_raw(X, Wk, bk)
+        apack = mha_adjacency(q, k, gr, sizes, DIM ** -0.5, opts.get("drop_p", 0.0), opts.get("seed", 0))
+        U0 = linear_raw(X, U)
+        Ub, info, V0 = gagm_solve(apack, Wds, U0, gr, sizes, opts.get("gagm_cfg"))
+        loss, dWds, flag = perm_loss_fwd_bwd(Wds, Ub, gr, G)
+        ctx.save_for_backward(X, Xs, Xt, P, Q, W1, w2f, b2, Psr, Ptg, part, pot, dWds)
+        ctx.meta = (sizes, tau, iters)
+        trace = opts.get("trace")
+        if trace is not None:
+            trace.update(Wds=Wds, apack=apack, U0=U0, Ub=Ub, info=info, V0=V0, P=P, Q=Q, part=part)
+        ctx.mark_non_differentiable(flag)
+        return loss, flag
+
+    @staticmethod
+    def backward(ctx, gloss, _gflag):
+        X, Xs, Xt, P, Q, W1, w2f, b2, Psr, Ptg, part, pot, dWds = ctx.saved_tensors
+        sizes, tau, iters = ctx.meta
+        gr = graphs(sizes)
+        M = X.shape[0]
+        # everything downstream is linear in dWds: apply the incoming loss scale (normally 1.0) once, here
+        dM = sinkhorn_pairs_bwd(part, b2, pot, dWds * gloss, gr, tau, iters)
+        dP, dQ, dw2, db2 = affinity_pairwise_bwd(P, Q, w2f, dM, gr)
+        dW1 = torch.empty_like(W1)
+        gemm(dP, 1, HID, Xs, 1, DIM, dW1, HID, 1, HID, DIM, M)                    # dW1[:, :256] = dP^T Xs
+        gemm(dQ, 1, HID, Xt, 1, DIM, dW1, HID, 1, HID, DIM, M, c_off=DIM)         # dW1[:, 256:] = dQ^T Xt
+        db1 = colsum(dQ)
+        dXs = torch.empty_like(Xs)
+        dXt = torch.empty_like(Xt)
+        gemm(dP, HID, 1, W1, 1, HID, dXs, DIM, 1, M, DIM, HID)                    # dXs = dP W1[:, :256]
+        gemm(dQ, HID, 1, W1, 1, HID, dXt, DIM, 1, M, DIM, HID, b_off=DIM)         # dXt = dQ W1[:, 256:]
+        dPsr = torch.empty_like(Psr)
+        dPtg = torch.empty_like(Ptg)
+        gemm(dXs, 1, DIM, X, 1, DIM, dPsr, DIM, 1, DIM, DIM, M)                   # dPsr = dXs^T X
+        gemm(dXt, 1, DIM, X, 1, DIM, dPtg, DIM, 1, DIM, DIM, M)
+        dX = torch.empty_like(X)
+        gemm(dXs, DIM, 1, Psr, 1, DIM, dX, DIM, 1, M, DIM, DIM)                   # dX = dXs Psr + dXt Ptg
+        gemm(dXt, DIM, 1, Ptg, 1, DIM, dX, DIM, 1, M, DIM, DIM, beta=1.0)
+        return (dX, dW1, db1, dw2.view(1, HID), db2, dPsr, dPtg, None, None, None, None, None, None, None)
+
+
+# ------------------------------------------------------------------------------------------- node gather
+class NodeGatherFn(torch.autograd.Function):
+    """Gather selected FPN points (build_graph.py:181-195): rows[i] = feat[level][img[i], :, point]."""
+
+    @staticmethod
+    def forward(ctx, img, pid, *feats):
+        n = img.numel()
+        Cc = feats[0].shape[1]
+        fp = _lib.Fpn()
+        fp.n, fp.C = len(feats), Cc
+        for l, f in enumerate(feats):
+            if f.dtype != torch.float32 or not f.is_contiguous():
+                raise TypeError("FPN maps must be contiguous float32 NCHW")
+            fp.h[l], fp.w[l], fp.feat[l] = f.shape[2], f.shape[3], ptr(f)
+        out = torch.empty(n, Cc, device=feats[0].device, dtype=torch.float32)
+        call("ttdg_node_gather_fwd", fp, ptr(img), ptr(pid), n, ptr(out), stream())
+        ctx.save_for_backward(img, pid)
+        ctx.shapes = [tuple(f.shape) for f in feats]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        img, pid = ctx.saved_tensors
+        dout = dout.contiguous()
+        grads = [torch.zeros(s, device=dout.device, dtype=torch.float32) for s in ctx.shapes]
+        fp = _lib.Fpn()
+        fp.n, fp.C = len(grads), ctx.shapes[0][1]
+        for l, g in enumerate(grads):
+            fp.h[l], fp.w[l], fp.feat[l] = g.shape[2], g.shape[3], ptr(g)
+        call("ttdg_node_gather_bwd", fp, ptr(img), ptr(pid), img.numel(), ptr(dout), stream())
+        return (None, None, *grads)
+
+
+def levels_desc(shapes, strides=(4, 8, 16, 32, 64),
+                ranges=((-1, 64), (64, 128), (128, 256), (256, 512), (512, 100000000))):
+    lv = _lib.Levels()
+    lv.n = len(shapes)
+    for l, (h, w) in enumerate(shapes):
+        lv.h[l], lv.w[l], lv.stride[l] = int(h), int(w), int(strides[l])
+        lv.lo[l], lv.hi[l] = float(ranges[l][0]), float(ranges[l][1])
+    return lv
+
+
+def node_labels(boxes, classes, nbox, lv, npts):
+    B, kmax = boxes.shape[0], boxes.shape[1]
+    labels = torch.empty(B, npts, device=boxes.device, dtype=torch.int32)
+    call("ttdg_node_labels", ptr(boxes), ptr(classes), ptr(nbox), B, kmax, lv, ptr(labels), stream())
+    return labels
+
+
+def node_select(labels, lv, sample_dist, cap):
+    B = labels.shape[0]
+    sel_idx = torch.empty(B, cap, device=labels.device, dtype=torch.int32)
+    sel_lab = torch.empty(B, cap, device=labels.device, dtype=torch.int32)
+    count = torch.empty(B, device=labels.device, dtype=torch.int32)
+    call("ttdg_node_select", ptr(labels), B, lv, int(sample_dist), int(cap), ptr(sel_idx), ptr(sel_lab), ptr(count), stream())
+    return sel_idx, sel_lab, count

@@ -1,0 +1,74 @@
+"""FusedSGD — the optimizer step of the TTA loop (reference engine/trainer.py:480-482) as ONE kernel launch.
+
+Semantics are torch.optim.SGD's as detectron2's build_optimizer configures it [3P] (momentum 0.9, per-group
+weight decay, no dampening / nesterov): parameters whose ``.grad`` is None are skipped, the momentum buffer is
+initialised with the first decayed gradient.  The per-step descriptor table (pointers change as autograd
+allocates fresh gradients) is staged in pinned host memory and copied asynchronously."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+CHUNK = 65536  # elements per workgroup
+
+
+class FusedSGD(torch.optim.Optimizer):
+    def __init__(self, params, lr, momentum=0.9, weight_decay=0.0):
+        if momentum <= 0:
+            raise ValueError("FusedSGD implements SGD with momentum (the TTA configuration)")
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        self._pinned = None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("closures are not used on the TTA path")
+        lr = mom = None
+        todo = []
+        for group in self.param_groups:
+            lr = group["lr"] if lr is None else lr
+            mom = group["momentum"] if mom is None else mom
+            if group["lr"] != lr or group["momentum"] != mom:
+                raise ValueError("FusedSGD needs one lr / momentum for all groups (true for the TTA optimizer)")
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise TypeError("FusedSGD handles contiguous float32 parameters")
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                st = self.state[p]
+                first = "momentum_buffer" not in st
+                if first:
+                    st["momentum_buffer"] = torch.empty_like(p)
+                todo.append((p, g, st["momentum_buffer"], group["weight_decay"], first))
+        if not todo:
+            return None
+        dev = todo[0][0].device
+        nt = len(todo)
+        chunks_t, chunks_o = [], []
+        for ti, (p, _, _, _, _) in enumerate(todo):
+            n = p.numel()
+            for off in range(0, n, CHUNK):
+                chunks_t.append(ti)
+                chunks_o.append(off)
+        nc = len(chunks_t)
+        tbytes = C.sizeof(_lib.SgdTensor) * nt
+        total = tbytes + 4 * nc + 8 * nc + 64
+        if self._pinned is None or self._pinned.numel() < total:
+            self._pinned = torch.empty(total * 2, dtype=torch.uint8).pin_memory()
+        host = self._pinned
+        table = (_lib.SgdTensor * nt).from_address(host.data_ptr())
+        for ti, (p, g, b, wd, first) in enumerate(todo):
+            table[ti].p, table[ti].g, table[ti].buf = ptr(p), ptr(g), ptr(b)
+            table[ti].n, table[ti].wd, table[ti].first = p.numel(), float(wd), int(first)
+        o_off = (tbytes + 7) // 8 * 8
+        t_off = o_off + 8 * nc
+        (C.c_int64 * nc).from_address(host.data_ptr() + o_off)[:] = chunks_o
+        (C.c_int32 * nc).from_address(host.data_ptr() + t_off)[:] = chunks_t
+        devbuf = host[:t_off + 4 * nc].to(dev, non_blocking=True)
+        base = devbuf.data_ptr()
+        call("ttdg_sgd_multi_tensor", base, base + t_off, base + o_off, nc, CHUNK, float(lr), float(mom), stream())
+        self._keepalive = (devbuf, [t[1] for t in todo])
+        return None
