@@ -106,11 +106,13 @@ int ttdg_mha_adjacency(const float* q, const float* k, int d, ttdg_graphs_t gr, 
  * scipy.optimize.linear_sum_assignment [3P] re-implemented on device, one wavefront per LAP.)
  * Apack as above, W = Wds (M x M), U0 (M x 32).  U (M x 32) receives the 0/1 matching.
  * info (int32[16], device): [0..5] iterations per stage, [6] total, [7] stages run, [8] status.
- * ws: workspace of ttdg_gagm_workspace_bytes(M) bytes (also receives the first-iteration V at
- * its start, M*32 floats, for parity tests). */
+ * ws: workspace of ttdg_gagm_workspace_bytes(M) bytes; its first 2*M*32 floats receive the
+ * first-iteration V and the first projected U (parity tests). */
 typedef struct {
   float tau0, gamma, min_tau, tol, quad_weight;
   int32_t max_iter, sk_iter;
+  int32_t max_stages;        /* 0 = run the full schedule; k > 0 stops after k stages (parity tests) */
+  int32_t start_hungarian;   /* non-zero: the first stage already uses the Hungarian projector (parity tests) */
 } ttdg_gagm_cfg_t;
 size_t ttdg_gagm_workspace_bytes(int M);
 int ttdg_gagm_solve(const float* Apack, const float* W, const float* U0, ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg,

@@ -66,11 +66,56 @@ MGM_CASES = (  # name, sizes, seed
 
 
 
+# "Planted" cases: a trained-like synthetic model.  Node features are noisy copies of universe rows
+# (x = 0.2 * U[id] + noise) and the affinity weights realise M_ij ~ c * ||x_i + x_j||_1 (+ small random jitter),
+# so that Wds is sharp and cycle-consistent and the graduated-assignment solver converges in every stage.
+# With random weights (MGM_CASES) the Sinkhorn stages collapse U to the uniform matrix and the Hungarian stage
+# is decided by fp32 rounding noise: the REFERENCE ITSELF returns different permutations with 1 vs 8 CPU threads
+# there (DESIGN.md "Solver parity"), so identical-permutation goldens are only meaningful on planted cases.
+PLANTED_CASES = (  # name, sizes, seed
+    ("p2", (18, 25), 900),
+    ("p3", (22, 22, 22), 900),
+    ("p3b", (22, 22, 22), 901),
+    ("p4", (22, 30, 28, 25), 900),
+    ("p4b", (22, 30, 28, 25), 901),
+    ("p4c", (22, 30, 28, 25), 902),
+)
+
+
+def planted_params(seed, c=0.02, jitter=0.002):
+    p = synth.mgm3_params(seed, std=jitter)
+    eye = torch.eye(256)
+    w1 = torch.zeros(512, 512)
+    w1[:256, :256], w1[:256, 256:], w1[256:, :256], w1[256:, 256:] = eye, eye, -eye, -eye
+    p["node_affinity.fc_M.0.weight"] = p["node_affinity.fc_M.0.weight"] + w1
+    p["node_affinity.fc_M.2.weight"] = p["node_affinity.fc_M.2.weight"] + c
+    p["node_affinity.project_sr.weight"] = p["node_affinity.project_sr.weight"] + eye
+    p["node_affinity.project_tg.weight"] = p["node_affinity.project_tg.weight"] + eye
+    return p
+
+
+def planted_nodes(seed, sizes, alpha=0.2, noise=0.02):
+    g = synth.gen(seed)
+    U = synth.universe(seed + 70)
+    nodes, labels = [], []
+    for n in sizes:
+        assert n <= 32
+        ids = torch.from_numpy(g.permutation(32)[:n])
+        nodes.append(alpha * U[ids] + synth.normal(g, (n, 256), noise))
+        labels.append(torch.from_numpy(g.integers(1, 3, size=n).astype(np.int64)))
+    return nodes, labels, U
+
+
 def mgm_inputs(name):
+    """-> (params, nodes, labels, U, sizes) for a random (MGM_CASES) or planted (PLANTED_CASES) case."""
     for n, sizes, seed in MGM_CASES:
         if n == name:
             nodes, labels = synth.node_sets(seed, sizes, scale=0.5)
             return synth.mgm3_params(seed + 50), nodes, labels, synth.universe(seed + 70), sizes
+    for n, sizes, seed in PLANTED_CASES:
+        if n == name:
+            nodes, labels, U = planted_nodes(seed, sizes)
+            return planted_params(seed + 50), nodes, labels, U, sizes
     raise KeyError(name)
 
 

@@ -141,6 +141,43 @@ def gold_mgm3(mgm):
                 pgrad(out, f"{name}_d_{k}", p.grad)
             else:
                 out[f"{name}_nograd_{k}"] = np.zeros(0, np.float32)
+    # planted (trained-like) cases: the solver converges, the reference is rounding-stable -> U is golden too
+    for name, sizes, seed in PLANTED_CASES:
+        params, nodes, labels, U, _ = mgm_inputs(name)
+        runs = []
+        for trial in range(4):          # 1 thread, 8 threads, and two 1e-7-relative input perturbations
+            torch.set_num_threads(8 if trial == 1 else 1)
+            m = mgm.MGM3_unsup(2, 32)
+            m.load_state_dict(params, strict=True)
+            m.eval()
+            xs = [x.clone() for x in nodes]
+            if trial >= 2:
+                g = synth.gen(77 + trial)
+                xs = [x * (1 + 1e-7 * synth.normal(g, tuple(x.shape))) for x in xs]
+            xs = [x.requires_grad_() for x in xs]
+            cap = {}
+            orig = m.ga_mgmc.forward
+
+            def spy(*a, _o=orig, _c=cap, **k):
+                out = _o(*a, **k)
+                _c["U"] = out[0].detach().clone()
+                return out
+            m.ga_mgmc.forward = spy
+            loss = m(xs, labels, U)
+            loss.backward()
+            runs.append((cap["U"], loss.detach(), m, xs))
+        torch.set_num_threads(1)
+        assert all(torch.equal(runs[0][0], r[0]) for r in runs[1:]), "reference not rounding-stable on " + name
+        Ub, loss, m, xs = runs[0]
+        out[f"{name}_loss"] = npy(loss)
+        out[f"{name}_U"] = npy(Ub)
+        for gi, x in enumerate(xs):
+            out[f"{name}_dnode{gi}"] = npy(x.grad)
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                pgrad(out, f"{name}_d_{k}", p.grad)
+            else:
+                out[f"{name}_nograd_{k}"] = np.zeros(0, np.float32)
     # single graph -> None (multi_graph_matching.py:489-490)
     m = ref_mgm3(mgm, 1)
     nodes, labels = synth.node_sets(1, (9,))

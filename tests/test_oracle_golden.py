@@ -126,3 +126,20 @@ def test_prototype_computation(golden, ci):
     for gi, (n, l) in enumerate(zip(nodes, labels)):
         close(n, gold[f"{name}_nodes{gi}"], 0)
         close(l, gold[f"{name}_labels{gi}"], 0)
+
+
+@pytest.mark.parametrize("name", [c[0] for c in cases.PLANTED_CASES])
+def test_mgm3_planted_cases(golden, name):
+    """Trained-like planted cases: the reference converges and is rounding-stable, so U itself is golden."""
+    gold = golden("mgm3")
+    params, nodes, labels, U, sizes = cases.mgm_inputs(name)
+    p = {k: v.clone().requires_grad_() for k, v in params.items()}
+    nodes = [x.requires_grad_() for x in nodes]
+    tr = {}
+    loss = og.mgm3_unsup_forward(p, nodes, labels, U, trace=tr)
+    loss.backward()
+    close(loss, gold[f"{name}_loss"])
+    close(tr["Ub"], gold[f"{name}_U"], 0)
+    assert max(tr["iters"]) < 200
+    for gi, x in enumerate(nodes):
+        close(x.grad, gold[f"{name}_dnode{gi}"], 1e-5)

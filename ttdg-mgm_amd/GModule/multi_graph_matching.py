@@ -115,9 +115,10 @@ class MGM3_unsup(nn.Module):
         self.check_range = False       # True: sync and raise like losses.py:437-442 when Wds leaves [0,1]
         self.last = None               # intermediates of the last forward (when trace is requested)
 
-    def forward(self, nodes, labels, U, trace=None):
+    def forward(self, nodes, labels, U, trace=None, forced_U=None):
         """nodes: list of (n_g, dim) tensors, labels: list of (n_g,) -> scalar loss, or None when there are
-        fewer than two graphs (reference :489-490)."""
+        fewer than two graphs (reference :489-490).  ``trace`` (dict) receives the intermediates;
+        ``forced_U`` replaces the solver's output (teacher-forced parity tests)."""
         if nodes is None or len(nodes) == 1:
             return None
         sizes = [len(l) for l in labels]
@@ -129,7 +130,7 @@ class MGM3_unsup(nn.Module):
         opts = {
             "pair_tau": self.sinkhorn.tau, "pair_iters": self.sinkhorn.max_iter,
             "drop_p": att.drop_p if self.training else 0.0, "seed": self.dropout_seed,
-            "gagm_cfg": self.ga_mgmc._cfg(self.quad_weight), "trace": trace,
+            "gagm_cfg": self.ga_mgmc._cfg(self.quad_weight), "trace": trace, "forced_U": forced_U,
         }
         loss, flag = ops.MatchingLossFn.apply(
             X, aff.fc_M[0].weight, aff.fc_M[0].bias, aff.fc_M[2].weight, aff.fc_M[2].bias,

@@ -155,9 +155,10 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
   const int M = gr.off[gr.G], G = gr.G;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int MU = M * NU;
-  // workspace (global): [V0 snapshot MU][state 4*MU when !kLds]
+  // workspace (global): [V0 snapshot MU][first projected U, MU][state 4*MU when !kLds]
   float* V0snap = ws;
-  float* base = kLds ? ga_smem : ws + MU;
+  float* U1snap = ws + MU;
+  float* base = kLds ? ga_smem : ws + 2 * MU;
   float* Ucur = base;
   float* Uprev = base + MU;
   float* X = base + 2 * MU;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
   __syncthreads();
 
   float tau = cfg.tau0;
-  bool hungarian = false;
+  bool hungarian = cfg.start_hungarian != 0;
   int stage = 0, total = 0;
   const float qw2 = cfg.quad_weight * 2.f, invG = 1.f / (float)G;
   bool first = true;
@@ -203,11 +204,11 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
       }
       __syncthreads();
       // ---- S = U^T B ----
-      {
-        const int u = tid >> 5, v = tid & 31;
+      for (int e = tid; e < NU * NU; e += GA_THREADS) {
+        const int u = e >> 5, v = e & 31;
         float acc = 0.f;
         for (int r = 0; r < M; ++r) acc = fmaf(Ucur[r * NU + u], X[r * NU + v], acc);
-        S[tid] = acc;
+        S[e] = acc;
       }
       __syncthreads();
       // ---- V = (2q B S + W U) / G ----
@@ -223,7 +224,6 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
         V[e] = val;
         if (first) V0snap[e] = val;
       }
-      first = false;
       __syncthreads();
       // ---- projection (X <- projected U), one wavefront per graph ----
       for (int g = wave; g < G; g += GA_WAVES) {
@@ -259,6 +259,7 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
       float d1 = 0.f, d2 = 0.f;
       for (int e = tid; e < MU; e += GA_THREADS) {
         const float un = X[e];
+        if (first) U1snap[e] = un;
         const float a = un - Ucur[e], b = un - Uprev[e];
         d1 = fmaf(a, a, d1);
         d2 = fmaf(b, b, d2);
@@ -267,6 +268,7 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
       const float s1 = block_sum2<GA_WAVES>(d1, d2, red, s2);
       // rotate: lastU2 <- lastU, lastU <- U, U <- new  (buffers rotate; the old lastU2 becomes scratch X)
       float* t = Uprev; Uprev = Ucur; Ucur = X; X = t;
+      first = false;
       ++total;
       if (sqrtf(s1) < cfg.tol || s2 == 0.f) break;
     }
@@ -274,6 +276,7 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
     if (tid == 0 && stage < 6) info[stage] = its;
     ++stage;
     if (hungarian) break;            // :374-376
+    if (cfg.max_stages > 0 && stage >= cfg.max_stages) break;
     if (tau > cfg.min_tau) tau *= cfg.gamma;   // :377-379
     else hungarian = true;           // :382-383
     __syncthreads();
@@ -289,7 +292,7 @@ static size_t ga_fixed_lds_bytes(int cmaxp, int GA_WAVES) {
          GA_WAVES * ((lap_scratch_bytes(NU, cmaxp) + 15) & ~(size_t)15);
 }
 
-extern "C" size_t ttdg_gagm_workspace_bytes(int M) { return (size_t)5 * M * NU * sizeof(float); }
+extern "C" size_t ttdg_gagm_workspace_bytes(int M) { return (size_t)6 * M * NU * sizeof(float); }
 
 extern "C" int ttdg_gagm_solve(const float* Apack, const float* W, const float* U0, ttdg_graphs_t gr,
                                ttdg_gagm_cfg_t cfg, float* U, int32_t* info, void* ws, ttdg_stream_t stream) {

@@ -126,11 +126,22 @@ def mha_adjacency(q, k, gr, sizes, scale, drop_p=0.0, seed=0, zero_diag=True):
     return apack
 
 
-def gagm_cfg(tau0=0.1, gamma=0.5, min_tau=1e-2, tol=1e-3, quad_weight=0.5, max_iter=200, sk_iter=20):
+def gagm_cfg(tau0=0.1, gamma=0.5, min_tau=1e-2, tol=1e-3, quad_weight=0.5, max_iter=200, sk_iter=20,
+             max_stages=0, start_hungarian=False):
     c = _lib.GagmCfg()
     c.tau0, c.gamma, c.min_tau, c.tol, c.quad_weight = tau0, gamma, min_tau, tol, quad_weight
     c.max_iter, c.sk_iter = int(max_iter), int(sk_iter)
+    c.max_stages, c.start_hungarian = int(max_stages), int(bool(start_hungarian))
     return c
+
+
+def gagm_one_step(apack, W, Ucur, gr, sizes, tau=None, quad_weight=0.5, sk_iter=20):
+    """One application of the solver's map U -> project(V(U)) (parity tests): Sinkhorn projector at ``tau``,
+    Hungarian projector when ``tau`` is None.  Returns (U_next, V)."""
+    cfg = gagm_cfg(tau0=(tau or 1.0), quad_weight=quad_weight, max_iter=1, sk_iter=sk_iter, max_stages=1,
+                   start_hungarian=tau is None)
+    U, info, V0 = gagm_solve(apack, W, Ucur, gr, sizes, cfg)
+    return U, V0
 
 
 def gagm_solve(apack, W, U0, gr, sizes, cfg=None):
@@ -142,6 +153,7 @@ def gagm_solve(apack, W, U0, gr, sizes, cfg=None):
     U = torch.empty(M, UNIV, device=W.device, dtype=torch.float32)
     info = torch.zeros(16, device=W.device, dtype=torch.int32)
     call("ttdg_gagm_solve", ptr(apack), ptr(W), ptr(U0), gr, cfg, ptr(U), ptr(info), ptr(ws), stream())
+    gagm_solve.last_U1 = ws[M * UNIV:2 * M * UNIV].view(M, UNIV)   # first projected U (debug / parity tests)
     return U, info, ws[:M * UNIV].view(M, UNIV)
 
 
@@ -195,7 +207,10 @@ class MatchingLossFn(torch.autograd.Function):
         k = linear_raw(X, Wk, bk)
         apack = mha_adjacency(q, k, gr, sizes, DIM ** -0.5, opts.get("drop_p", 0.0), opts.get("seed", 0))
         U0 = linear_raw(X, U)
-        Ub, info, V0 = gagm_solve(apack, Wds, U0, gr, sizes, opts.get("gagm_cfg"))
+        if opts.get("forced_U") is not None:      # parity tests: pseudo-labels supplied by the caller
+            Ub, info, V0 = opts["forced_U"].contiguous(), None, None
+        else:
+            Ub, info, V0 = gagm_solve(apack, Wds, U0, gr, sizes, opts.get("gagm_cfg"))
         loss, dWds, flag = perm_loss_fwd_bwd(Wds, Ub, gr, G)
         ctx.save_for_backward(X, Xs, Xt, P, Q, W1, w2f, b2, Psr, Ptg, part, pot, dWds)
         ctx.meta = (sizes, tau, iters)
