@@ -179,6 +179,16 @@ typedef struct {
 int ttdg_sgd_multi_tensor(const ttdg_sgd_tensor_t* table, const int32_t* chunk_tensor, const int64_t* chunk_off,
                           int nchunks, int chunk, float lr, float momentum, ttdg_stream_t stream);
 
+/* ---- detection helpers of the torch-native Mask R-CNN stand-in (stands in for the
+ *      un-vendored detectron2 ROIAlignV2 / torchvision nms [3P]); forward-only on the TTA path -------------
+ * rois (R,5) = (batch idx, x1,y1,x2,y2) image coords; feat (B,C,H,W); out (R,C,P,P); aligned, adaptive sampling. */
+int ttdg_roi_align_fwd(const float* feat, int B, int C, int H, int W, const float* rois, int R, float scale, int P,
+                       float* out, ttdg_stream_t stream);
+/* greedy NMS over boxes (N,4) pre-sorted by descending score; boxes with different group ids never interact.
+ * mask_ws: N*ceil(N/64) uint64 of scratch; keep (N) receives kept indices, nkeep their count. */
+int ttdg_nms(const float* boxes, const int32_t* group, int N, float thr, void* mask_ws, int32_t* keep,
+             int32_t* nkeep, ttdg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -137,6 +137,8 @@ class MGM3_unsup(nn.Module):
             aff.project_sr.weight, aff.project_tg.weight,
             att.linear_q.weight, att.linear_q.bias, att.linear_k.weight, att.linear_k.bias,
             U.detach().contiguous(), sizes, opts)
+        if trace is not None and trace.get("info") is not None:
+            self.ga_mgmc.last_info = trace["info"]
         if self.check_range:
             assert int(flag.item()) == 0, "pred_dsmat / gt_perm left [0, 1]"
         return loss

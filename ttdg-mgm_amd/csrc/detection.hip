@@ -1,0 +1,104 @@
+// Detection helpers the torch-native Mask R-CNN stand-in needs (torchvision is absent):
+// ROIAlign (aligned, adaptive sampling — detectron2 ROIAlignV2 semantics [3P]) forward, and greedy NMS
+// (IoU bit-mask matrix + one-wavefront sequential sweep).  Both are forward-only on the TTA path: proposals
+// and detections carry no gradient (rcnn.py:333-345 feeds them to the node sampler as constants).
+#include "common.h"
+
+// rois: (R, 5) = (batch index, x1, y1, x2, y2) in image coordinates; feat: (B, C, H, W); out: (R, C, P, P)
+__global__ __launch_bounds__(256) void roi_align_fwd_kernel(const float* __restrict__ feat, int C, int H, int W,
+                                                            const float* __restrict__ rois, int R, float scale, int P,
+                                                            float* __restrict__ out) {
+  const long total = (long)R * C * P * P;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int pw = idx % P, ph = (idx / P) % P, c = (idx / ((long)P * P)) % C;
+    const int r = idx / ((long)P * P * C);
+    const float* roi = rois + (size_t)r * 5;
+    const int b = (int)roi[0];
+    const float x1 = roi[1] * scale - 0.5f, y1 = roi[2] * scale - 0.5f;
+    const float rw = roi[3] * scale - 0.5f - x1, rh = roi[4] * scale - 0.5f - y1;
+    const float bw = rw / P, bh = rh / P;
+    const int gh = max(1, (int)ceilf(rh / P)), gw = max(1, (int)ceilf(rw / P));
+    const float* f = feat + ((size_t)b * C + c) * H * W;
+    float acc = 0.f;
+    for (int iy = 0; iy < gh; ++iy) {
+      float y = y1 + ph * bh + (iy + 0.5f) * bh / gh;
+      for (int ix = 0; ix < gw; ++ix) {
+        float x = x1 + pw * bw + (ix + 0.5f) * bw / gw;
+        if (y < -1.f || y > H || x < -1.f || x > W) continue;
+        float yy = fmaxf(y, 0.f), xx = fmaxf(x, 0.f);
+        int y0 = (int)yy, x0 = (int)xx, y1i, x1i;
+        if (y0 >= H - 1) { y0 = y1i = H - 1; yy = (float)y0; } else y1i = y0 + 1;
+        if (x0 >= W - 1) { x0 = x1i = W - 1; xx = (float)x0; } else x1i = x0 + 1;
+        const float ly = yy - y0, lx = xx - x0, hy = 1.f - ly, hx = 1.f - lx;
+        acc += hy * hx * f[y0 * W + x0] + hy * lx * f[y0 * W + x1i] + ly * hx * f[y1i * W + x0] + ly * lx * f[y1i * W + x1i];
+      }
+    }
+    out[idx] = acc / (float)(gh * gw);
+  }
+}
+
+extern "C" int ttdg_roi_align_fwd(const float* feat, int B, int C, int H, int W, const float* rois, int R, float scale,
+                                  int P, float* out, ttdg_stream_t stream) {
+  TTDG_REQUIRE(feat && rois && out && R >= 0 && C > 0 && P > 0, "roi_align: bad arguments");
+  if (R == 0) return 0;
+  const long total = (long)R * C * P * P;
+  const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  hipLaunchKernelGGL(roi_align_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, feat, C, H, W, rois, R, scale, P, out);
+  return ttdg_launch_status("roi_align_fwd");
+}
+
+// ---- NMS: boxes (N,4) sorted by descending score; group ids make it "batched" (boxes of different groups never
+// suppress each other).  mask[i][w] bit j: box 64w+j (j>i) overlaps box i above the threshold.
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float* __restrict__ boxes, const int32_t* __restrict__ group,
+                                                      int N, float thr, unsigned long long* __restrict__ mask, int words) {
+  const int i = blockIdx.x, w = blockIdx.y, lane = threadIdx.x;
+  const int j = w * 64 + lane;
+  bool hit = false;
+  if (j < N && j > i && group[i] == group[j]) {
+    const float4 a = reinterpret_cast<const float4*>(boxes)[i], b = reinterpret_cast<const float4*>(boxes)[j];
+    const float iw = fminf(a.z, b.z) - fmaxf(a.x, b.x), ih = fminf(a.w, b.w) - fmaxf(a.y, b.y);
+    const float inter = fmaxf(iw, 0.f) * fmaxf(ih, 0.f);
+    const float ua = (a.z - a.x) * (a.w - a.y) + (b.z - b.x) * (b.w - b.y) - inter;
+    hit = inter > thr * ua;
+  }
+  const unsigned long long m = __ballot(hit);
+  if (lane == 0) mask[(size_t)i * words + w] = m;
+}
+
+// one wavefront: removed-set lives in registers (lane l owns words l, l+64, ...), boxes visited in score order
+__global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long* __restrict__ mask, int N, int words,
+                                                       int32_t* __restrict__ keep, int32_t* __restrict__ nkeep) {
+  const int lane = threadIdx.x;
+  unsigned long long rem[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // up to 8*64*64 = 32768 boxes
+  int cnt = 0;
+  for (int i = 0; i < N; ++i) {
+    const int w = i >> 6, owner = w & 63, slot = w >> 6;
+    unsigned long long word = 0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) if (s == slot) word = rem[s];
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)word, owner), hi = __builtin_amdgcn_readlane((unsigned)(word >> 32), owner);
+    const unsigned long long ow = ((unsigned long long)hi << 32) | lo;
+    if ((ow >> (i & 63)) & 1ull) continue;
+    if (lane == 0) keep[cnt] = i;
+    ++cnt;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int ww = lane + 64 * s;
+      if (ww < words) rem[s] |= mask[(size_t)i * words + ww];
+    }
+  }
+  if (lane == 0) *nkeep = cnt;
+}
+
+extern "C" int ttdg_nms(const float* boxes, const int32_t* group, int N, float thr, void* mask_ws, int32_t* keep,
+                        int32_t* nkeep, ttdg_stream_t stream) {
+  TTDG_REQUIRE(boxes && group && keep && nkeep && N >= 0, "nms: bad arguments");
+  TTDG_LIMIT(N <= 32768, "nms: more than 32768 boxes");
+  hipStream_t st = (hipStream_t)stream;
+  if (N == 0) { TTDG_HIP(hipMemsetAsync(nkeep, 0, sizeof(int32_t), st)); return 0; }
+  TTDG_REQUIRE(mask_ws, "nms: null workspace");
+  const int words = (N + 63) / 64;
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(N, words), dim3(64), 0, st, boxes, group, N, thr, (unsigned long long*)mask_ws, words);
+  hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(64), 0, st, (const unsigned long long*)mask_ws, N, words, keep, nkeep);
+  return ttdg_launch_status("nms");
+}

@@ -1,0 +1,65 @@
+"""Synthetic test datasets + test loader (reference data/build.py:122-154: InferenceSampler shard per rank,
+BatchSampler(TEST.BATCH, drop_last=False), trivial collate)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .. import synth
+
+_REGISTRY = {}
+
+
+def register_synthetic(name, num_images, size=512, cfg_id=2, kind="fundus", num_cls=2):
+    _REGISTRY[name] = dict(n=num_images, size=size, cfg_id=cfg_id, kind=kind, num_cls=num_cls)
+
+
+def dataset_dicts(name):
+    """List of dicts: image (3,H,W) uint8, height, width, image_id, annotations [{bbox xyxy, category_id, mask bool}]."""
+    spec = _REGISTRY[name]
+    out = []
+    for i in range(spec["n"]):
+        seed = 1000 * spec["cfg_id"] + i
+        gen = synth.fundus_image if spec["kind"] == "fundus" else synth.polyp_image
+        img, boxes, classes, masks = gen(seed, spec["size"]) if spec["kind"] == "fundus" else gen(seed, spec["size"], spec["num_cls"])
+        anns = [dict(bbox=boxes[k], category_id=int(classes[k]), mask=masks[k]) for k in range(len(classes))]
+        out.append(dict(image=img, height=int(img.shape[1]), width=int(img.shape[2]), image_id=i, annotations=anns, seed=seed))
+    return out
+
+
+def map_for_test(d, min_size=800, max_size=1333):
+    """DatasetMapper(is_train=False) equivalent: resize the shorter edge to ``min_size`` (bilinear) and carry the
+    teacher-forced detections (GT boxes jittered +-2 px, in resized coordinates)."""
+    h, w = d["height"], d["width"]
+    s = min(min_size / min(h, w), max_size / max(h, w))
+    nh, nw = int(round(h * s)), int(round(w * s))
+    img = F.interpolate(d["image"][None].float(), size=(nh, nw), mode="bilinear", align_corners=False)[0]
+    boxes = torch.stack([a["bbox"] for a in d["annotations"]]) if d["annotations"] else torch.zeros(0, 4)
+    tf = synth.jitter_boxes(d["seed"] + 500000, boxes) * torch.tensor([nw / w, nh / h, nw / w, nh / h])
+    return dict(image=img.round().clamp(0, 255).to(torch.uint8), height=h, width=w, image_id=d["image_id"],
+                tf_boxes=tf, tf_classes=torch.tensor([a["category_id"] for a in d["annotations"]], dtype=torch.int64),
+                dataset_dict=d)
+
+
+class TestLoader:
+    """Iterable over lists of mapped dicts; rank r sees the contiguous shard detectron2's InferenceSampler gives it."""
+
+    def __init__(self, dicts, batch, rank=0, world=1, device=None, min_size=800, max_size=1333):
+        n = len(dicts)
+        shard = (n - 1) // world + 1 if n else 0
+        self.items = [map_for_test(d, min_size, max_size) for d in dicts[shard * rank:min(shard * (rank + 1), n)]]
+        if device is not None:                                   # keep inputs resident in HBM (bench)
+            for it in self.items:
+                it["image"] = it["image"].to(device)
+        self.batch = batch
+
+    def __len__(self):
+        return (len(self.items) + self.batch - 1) // self.batch
+
+    def __iter__(self):
+        for i in range(0, len(self.items), self.batch):
+            yield self.items[i:i + self.batch]
+
+
+def build_detection_test_loader(cfg, dataset_name, rank=0, world=1, device=None):
+    return TestLoader(dataset_dicts(dataset_name), cfg.TEST.BATCH, rank, world, device,
+                      cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)

@@ -1,0 +1,99 @@
+"""BaselineTrainer — mirror of the reference trainer surface ``train_net.py --eval-only`` uses
+(engine/trainer.py:430-529 ``test``; :1230-1360 ``inference_on_dataset``; build_* classmethods).
+
+``test`` keeps the reference's order: for every dataset, one adaptation step per batch
+(``loss = model(inputs, branch='TTT')``; skip on None; zero_grad / backward / step), THEN the Dice pass over the
+same loader with the adapted weights; model and optimizer state carry over between datasets (continual TTA)."""
+import logging
+import time
+from collections import OrderedDict, defaultdict
+
+import torch
+
+from ..data import build_detection_test_loader
+from ..evaluation import DiceEvaluator
+from ..modeling import build_model
+from ..optim import FusedSGD
+
+
+def inference_on_dataset(model, data_loader, evaluator, cfg=None):
+    """Eval-mode, no-grad pass (reference :1230-1360); returns (results, evaluator)."""
+    was_training = model.training
+    model.eval()
+    evaluator.reset()
+    with torch.no_grad():
+        for inputs in data_loader:
+            outputs = model(inputs)
+            evaluator.process(inputs, outputs)
+    model.train(was_training)
+    results = evaluator.evaluate()
+    return (results if results is not None else {}), evaluator
+
+
+class BaselineTrainer:
+    rank, world = 0, 1            # set by the launcher (one process per GPU)
+    device = None                 # inputs are kept resident on this device when set
+
+    @classmethod
+    def build_model(cls, cfg):
+        return build_model(cfg)
+
+    @classmethod
+    def build_optimizer(cls, cfg, model):
+        """detectron2.solver.build_optimizer [3P]: SGD(momentum), one group per tensor, no weight decay on norms."""
+        groups = []
+        for name, p in model.named_parameters():
+            if not p.requires_grad:
+                continue
+            wd = cfg.SOLVER.WEIGHT_DECAY_NORM if (".norm." in name or "layer_norm" in name) else cfg.SOLVER.WEIGHT_DECAY
+            groups.append({"params": [p], "weight_decay": wd})
+        return FusedSGD(groups, lr=cfg.SOLVER.BASE_LR, momentum=cfg.SOLVER.MOMENTUM)
+
+    @classmethod
+    def build_test_loader(cls, cfg, dataset_name):
+        return build_detection_test_loader(cfg, dataset_name, cls.rank, cls.world, cls.device)
+
+    @classmethod
+    def tta_step(cls, model, optimizer, inputs):
+        """One adaptation step (reference :476-482).  Returns the loss tensor or None when skipped."""
+        loss, _, _, _ = model(inputs, branch='TTT')
+        if loss is None:
+            return None
+        optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        optimizer.step()
+        return loss
+
+    @classmethod
+    def test(cls, cfg, model, optimizer=None, evaluators=None, timers=None):
+        logger = logging.getLogger(__name__)
+        results = OrderedDict()
+        for idx, dataset_name in enumerate(cfg.DATASETS.TEST):
+            data_loader = cls.build_test_loader(cfg, dataset_name)
+            t0 = time.perf_counter()
+            if cfg.TEST.TTT:
+                for bidx, inputs in enumerate(data_loader):
+                    if cfg.TEST.MIN_BATCH_NUM is not None and bidx >= cfg.TEST.MIN_BATCH_NUM:
+                        break
+                    cls.tta_step(model, optimizer, inputs)
+            if timers is not None:
+                torch.cuda.synchronize()
+                timers.setdefault("tta_s", 0.0)
+                timers["tta_s"] += time.perf_counter() - t0
+            t1 = time.perf_counter()
+            dice = evaluators[idx] if evaluators is not None else DiceEvaluator(dataset_name, cfg.TEST.DICE_THRES)
+            results_i, _ = inference_on_dataset(model, data_loader, dice, cfg)
+            if timers is not None:
+                torch.cuda.synchronize()
+                timers.setdefault("eval_s", 0.0)
+                timers["eval_s"] += time.perf_counter() - t1
+            results[dataset_name] = results_i
+            assert isinstance(results_i, dict), "Evaluator must return a dict on the main process. Got {} instead.".format(results_i)
+            logger.info("Evaluation results for {}: {}".format(dataset_name, results_i))
+        fam = defaultdict(lambda: defaultdict(list))
+        for key, value in results.items():
+            for m in ("Dice Coefficient", "Enhanced Alignment Metric", "Structural Similarity Metric"):
+                fam[key.split('_')[0]][m].append(value[m])
+        for dname, metrics in fam.items():
+            results[f"{dname}_mean"] = {m: sum(v) / len(v) for m, v in metrics.items()}
+        return results

@@ -1,0 +1,109 @@
+"""ResNet-50 + FPN (p2..p6, 256 ch) with FrozenBN; stem and res2 frozen (detectron2 defaults [3P], SURVEY.md App. C:
+FREEZE_AT 2, NORM FrozenBN, STRIDE_IN_1X1 True, FPN top block LastLevelMaxPool).  Module/parameter names follow
+detectron2 (``bottom_up.stem.conv1.norm.weight``, ``fpn_lateral2`` ...)."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+class FrozenBatchNorm2d(nn.Module):
+    def __init__(self, c, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.register_buffer("weight", torch.ones(c))
+        self.register_buffer("bias", torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c) - eps)
+
+    def forward(self, x):
+        scale = self.weight * (self.running_var + self.eps).rsqrt()
+        shift = self.bias - self.running_mean * scale
+        return x * scale.view(1, -1, 1, 1).to(x.dtype) + shift.view(1, -1, 1, 1).to(x.dtype)
+
+
+class ConvNorm(nn.Conv2d):
+    """Conv2d carrying its FrozenBN as ``.norm`` (detectron2 Conv2d wrapper layout)."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, norm=True):
+        super().__init__(cin, cout, k, stride=stride, padding=padding, bias=not norm)
+        self.norm = FrozenBatchNorm2d(cout) if norm else None
+        nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
+
+    def forward(self, x):
+        x = super().forward(x)
+        return self.norm(x) if self.norm is not None else x
+
+
+class Stem(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1 = ConvNorm(3, 64, 7, stride=2, padding=3)
+
+    def forward(self, x):
+        return F.max_pool2d(F.relu_(self.conv1(x)), kernel_size=3, stride=2, padding=1)
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, cin, cout, mid, stride):
+        super().__init__()
+        self.shortcut = ConvNorm(cin, cout, 1, stride=stride) if cin != cout else None
+        self.conv1 = ConvNorm(cin, mid, 1, stride=stride)          # STRIDE_IN_1X1
+        self.conv2 = ConvNorm(mid, mid, 3, padding=1)
+        self.conv3 = ConvNorm(mid, cout, 1)
+
+    def forward(self, x):
+        out = F.relu_(self.conv1(x))
+        out = F.relu_(self.conv2(out))
+        out = self.conv3(out)
+        return F.relu_(out + (self.shortcut(x) if self.shortcut is not None else x))
+
+
+class ResNet50(nn.Module):
+    def __init__(self, freeze_at=2):
+        super().__init__()
+        self.stem = Stem()
+        cfgs = [("res2", 3, 64, 256, 64, 1), ("res3", 4, 256, 512, 128, 2), ("res4", 6, 512, 1024, 256, 2), ("res5", 3, 1024, 2048, 512, 2)]
+        for name, n, cin, cout, mid, stride in cfgs:
+            blocks = [Bottleneck(cin if i == 0 else cout, cout, mid, stride if i == 0 else 1) for i in range(n)]
+            setattr(self, name, nn.Sequential(*blocks))
+        frozen = [self.stem] + [getattr(self, "res%d" % i) for i in range(2, freeze_at + 1)]
+        for m in frozen[:freeze_at]:
+            for p in m.parameters():
+                p.requires_grad_(False)
+
+    def forward(self, x):
+        x = self.stem(x)
+        c2 = self.res2(x)
+        c3 = self.res3(c2)
+        c4 = self.res4(c3)
+        c5 = self.res5(c4)
+        return c2, c3, c4, c5
+
+
+class FPN(nn.Module):
+    size_divisibility = 32
+    out_channels = 256
+    strides = (4, 8, 16, 32, 64)
+    _out_feature_channels = {"p2": 256, "p3": 256, "p4": 256, "p5": 256, "p6": 256, "res4": 1024, "vgg4": 512}
+
+    def __init__(self, freeze_at=2):
+        super().__init__()
+        self.bottom_up = ResNet50(freeze_at)
+        for i, c in zip((2, 3, 4, 5), (256, 512, 1024, 2048)):
+            lat, out = nn.Conv2d(c, 256, 1), nn.Conv2d(256, 256, 3, padding=1)
+            for m in (lat, out):
+                nn.init.kaiming_uniform_(m.weight, a=1)
+                nn.init.constant_(m.bias, 0)
+            setattr(self, "fpn_lateral%d" % i, lat)
+            setattr(self, "fpn_output%d" % i, out)
+
+    def forward(self, x):
+        c2, c3, c4, c5 = self.bottom_up(x)
+        prev = self.fpn_lateral5(c5)
+        p5 = self.fpn_output5(prev)
+        outs = [p5]
+        for i, c in ((4, c4), (3, c3), (2, c2)):
+            prev = getattr(self, "fpn_lateral%d" % i)(c) + F.interpolate(prev, scale_factor=2.0, mode="nearest")
+            outs.insert(0, getattr(self, "fpn_output%d" % i)(prev))
+        outs.append(F.max_pool2d(p5, kernel_size=1, stride=2, padding=0))
+        return dict(zip(("p2", "p3", "p4", "p5", "p6"), outs))

@@ -1,0 +1,268 @@
+"""RPN and ROI heads of the Mask R-CNN stand-in — mirrors of the reference's ``PseudoLabRPN``
+(proposal_generator/rpn.py:10-56) and ``StandardROIHeadsPseudoLab`` (roi_heads/roi_heads.py:22-205) inference
+paths, with the detectron2 internals they inherit [3P] written out in torch (defaults from SURVEY.md App. C).
+Proposals and detections are produced without gradient, as on the reference's TTT branch."""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from .structures import Boxes, Instances
+
+_SCALE_CLAMP = math.log(1000.0 / 16)
+_backend = ops    # provider of nms / roi_align: the HIP operators.  (Test harnesses may point a CPU copy of the
+                  # model at their own reference implementation; the product never does.)
+
+
+def apply_deltas(deltas, boxes, weights):
+    """detectron2 Box2BoxTransform.apply_deltas [3P]; deltas (N, 4k), boxes (N, 4)."""
+    boxes = boxes.to(deltas.dtype)
+    w, h = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+    cx, cy = boxes[:, 0] + 0.5 * w, boxes[:, 1] + 0.5 * h
+    wx, wy, ww, wh = weights
+    dx, dy = deltas[:, 0::4] / wx, deltas[:, 1::4] / wy
+    dw, dh = (deltas[:, 2::4] / ww).clamp(max=_SCALE_CLAMP), (deltas[:, 3::4] / wh).clamp(max=_SCALE_CLAMP)
+    pcx, pcy = dx * w[:, None] + cx[:, None], dy * h[:, None] + cy[:, None]
+    pw, ph = torch.exp(dw) * w[:, None], torch.exp(dh) * h[:, None]
+    return torch.stack((pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph), dim=-1).reshape(deltas.shape)
+
+
+class RPNHead(nn.Module):
+    def __init__(self, c=256, num_anchors=3):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, padding=1)
+        self.objectness_logits = nn.Conv2d(c, num_anchors, 1)
+        self.anchor_deltas = nn.Conv2d(c, num_anchors * 4, 1)
+        for l in (self.conv, self.objectness_logits, self.anchor_deltas):
+            nn.init.normal_(l.weight, std=0.01)
+            nn.init.constant_(l.bias, 0)
+
+    def forward(self, feats):
+        logits, deltas = [], []
+        for x in feats:
+            t = F.relu(self.conv(x))
+            logits.append(self.objectness_logits(t))
+            deltas.append(self.anchor_deltas(t))
+        return logits, deltas
+
+
+class PseudoLabRPN(nn.Module):
+    """forward(images, features, gt_instances=None, compute_loss=True) -> (proposals, losses); only the
+    ``compute_loss=False`` path of the reference (rpn.py:16-56) exists here (the one TTA uses)."""
+
+    def __init__(self, sizes=(32, 64, 128, 256, 512), ratios=(0.5, 1.0, 2.0), strides=(4, 8, 16, 32, 64),
+                 pre_nms_topk=(2000, 1000), post_nms_topk=(1000, 1000), nms_thresh=0.7):
+        super().__init__()
+        self.rpn_head = RPNHead(256, len(ratios))
+        self.sizes, self.ratios, self.strides = sizes, ratios, strides
+        self.pre_nms_topk = {True: pre_nms_topk[0], False: pre_nms_topk[1]}
+        self.post_nms_topk = {True: post_nms_topk[0], False: post_nms_topk[1]}
+        self.nms_thresh = nms_thresh
+        self.in_features = ("p2", "p3", "p4", "p5", "p6")
+        self._anchor_cache = {}
+
+    def _anchors(self, shapes, device):
+        key = (tuple(shapes), str(device))
+        if key not in self._anchor_cache:
+            out = []
+            for (h, w), s, stride in zip(shapes, self.sizes, self.strides):
+                base = []
+                for r in self.ratios:
+                    aw = math.sqrt(s * s / r)
+                    ah = aw * r
+                    base.append([-aw / 2, -ah / 2, aw / 2, ah / 2])
+                base = torch.tensor(base, device=device, dtype=torch.float32)
+                ys, xs = torch.meshgrid(torch.arange(h, device=device, dtype=torch.float32) * stride,
+                                        torch.arange(w, device=device, dtype=torch.float32) * stride, indexing="ij")
+                sh = torch.stack((xs, ys, xs, ys), dim=-1).reshape(-1, 1, 4)
+                out.append((sh + base[None]).reshape(-1, 4))
+            self._anchor_cache[key] = out
+        return self._anchor_cache[key]
+
+    @torch.no_grad()
+    def forward(self, images, features, gt_instances=None, compute_loss=True, danchor=False):
+        if compute_loss:
+            raise NotImplementedError("RPN losses belong to source training, not to test-time adaptation")
+        feats = [features[f].detach() for f in self.in_features]
+        logits, deltas = self.rpn_head(feats)
+        anchors = self._anchors([f.shape[-2:] for f in feats], feats[0].device)
+        N = feats[0].shape[0]
+        pre, post = self.pre_nms_topk[self.training], self.post_nms_topk[self.training]
+        tb, ts, tl = [], [], []
+        for lvl, (lg, dl, an) in enumerate(zip(logits, deltas, anchors)):
+            lg = lg.permute(0, 2, 3, 1).reshape(N, -1)
+            dl = dl.view(N, -1, 4, dl.shape[-2], dl.shape[-1]).permute(0, 3, 4, 1, 2).reshape(N, -1, 4)
+            k = min(pre, lg.shape[1])
+            sc, idx = lg.topk(k, dim=1)
+            bx = apply_deltas(dl.gather(1, idx[..., None].expand(-1, -1, 4)).reshape(-1, 4),
+                              an[idx.reshape(-1)], (1.0, 1.0, 1.0, 1.0)).reshape(N, k, 4)
+            tb.append(bx), ts.append(sc), tl.append(torch.full((k,), lvl, dtype=torch.int32, device=lg.device))
+        tb, ts, tl = torch.cat(tb, 1), torch.cat(ts, 1), torch.cat(tl, 0)
+        proposals = []
+        for n, size in enumerate(images.image_sizes):
+            b = Boxes(tb[n])
+            s, l = ts[n], tl
+            ok = torch.isfinite(b.tensor).all(1) & torch.isfinite(s)
+            b.clip(size)
+            ok &= b.nonempty(0.0)
+            bt, s, l = b.tensor[ok], s[ok], l[ok]
+            keep = _backend.nms(bt, s, self.nms_thresh, l)[:post]
+            proposals.append(Instances(size, proposal_boxes=Boxes(bt[keep]), objectness_logits=s[keep]))
+        return proposals, {}
+
+
+class ROIPooler:
+    def __init__(self, out_size, scales=(1 / 4, 1 / 8, 1 / 16, 1 / 32), canonical_box_size=224, canonical_level=4):
+        self.P, self.scales = out_size, scales
+        self.min_level, self.max_level = 2, 2 + len(scales) - 1
+        self.cbs, self.cl = canonical_box_size, canonical_level
+
+    def __call__(self, feats, box_lists):
+        rois = torch.cat([torch.cat((b.tensor.new_full((len(b), 1), float(i)), b.tensor), 1) for i, b in enumerate(box_lists)], 0)
+        R = rois.shape[0]
+        out = feats[0].new_zeros((R, feats[0].shape[1], self.P, self.P), dtype=torch.float32)
+        if R == 0:
+            return out
+        area = (rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2])
+        lvl = torch.floor(self.cl + torch.log2(torch.sqrt(area.clamp(min=0)) / self.cbs + 1e-8)).clamp(self.min_level, self.max_level).long() - self.min_level
+        for l, (f, s) in enumerate(zip(feats, self.scales)):
+            idx = torch.nonzero(lvl == l).squeeze(1)
+            if idx.numel():
+                out[idx] = _backend.roi_align(f, rois[idx], s, self.P)
+        return out
+
+
+class FastRCNNConvFCHead(nn.Module):
+    def __init__(self, cin=256, P=7, fc=1024):
+        super().__init__()
+        self.fc1 = nn.Linear(cin * P * P, fc)
+        self.fc2 = nn.Linear(fc, fc)
+
+    def forward(self, x):
+        return F.relu(self.fc2(F.relu(self.fc1(x.flatten(1)))))
+
+
+class FastRCNNOutputLayers(nn.Module):
+    def __init__(self, num_classes, fc=1024):
+        super().__init__()
+        self.cls_score = nn.Linear(fc, num_classes + 1)
+        self.bbox_pred = nn.Linear(fc, num_classes * 4)
+        nn.init.normal_(self.cls_score.weight, std=0.01)
+        nn.init.normal_(self.bbox_pred.weight, std=0.001)
+        for l in (self.cls_score, self.bbox_pred):
+            nn.init.constant_(l.bias, 0)
+
+    def forward(self, x):
+        return self.cls_score(x), self.bbox_pred(x)
+
+
+class MaskRCNNConvUpsampleHead(nn.Module):
+    def __init__(self, num_classes, c=256):
+        super().__init__()
+        for i in range(1, 5):
+            setattr(self, "mask_fcn%d" % i, nn.Conv2d(c, c, 3, padding=1))
+        self.deconv = nn.ConvTranspose2d(c, c, 2, stride=2)
+        self.predictor = nn.Conv2d(c, num_classes, 1)
+        nn.init.normal_(self.predictor.weight, std=0.001)
+        nn.init.constant_(self.predictor.bias, 0)
+
+    def forward(self, x):
+        for i in range(1, 5):
+            x = F.relu(getattr(self, "mask_fcn%d" % i)(x))
+        return self.predictor(F.relu(self.deconv(x)))
+
+
+class StandardROIHeadsPseudoLab(nn.Module):
+    """forward(images, features, proposals, targets=None, compute_loss=True, branch="") — only the inference paths
+    exist: ``branch == 'TTT'`` returns box predictions without masks (roi_heads.py:108-110), otherwise boxes + masks."""
+
+    def __init__(self, num_classes, score_thresh=0.05, nms_thresh=0.5, topk_per_image=100):
+        super().__init__()
+        self.num_classes = num_classes
+        self.box_in_features = self.mask_in_features = ("p2", "p3", "p4", "p5")
+        self.box_pooler = ROIPooler(7)
+        self.mask_pooler = ROIPooler(14)
+        self.box_head = FastRCNNConvFCHead()
+        self.box_predictor = FastRCNNOutputLayers(num_classes)
+        self.mask_head = MaskRCNNConvUpsampleHead(num_classes)
+        self.score_thresh, self.nms_thresh, self.topk = score_thresh, nms_thresh, topk_per_image
+        self.bbox_weights = (10.0, 10.0, 5.0, 5.0)
+
+    @torch.no_grad()
+    def _forward_box(self, feats, proposals):
+        x = self.box_pooler(feats, [p.proposal_boxes for p in proposals])
+        logits, deltas = self.box_predictor(self.box_head(x))
+        out, start = [], 0
+        for p in proposals:
+            n = len(p)
+            lg, dl = logits[start:start + n], deltas[start:start + n]
+            start += n
+            scores = F.softmax(lg, dim=-1)[:, :-1]
+            boxes = apply_deltas(dl, p.proposal_boxes.tensor, self.bbox_weights).view(n, self.num_classes, 4)
+            h, w = p.image_size
+            boxes = torch.stack((boxes[..., 0].clamp(0, w), boxes[..., 1].clamp(0, h), boxes[..., 2].clamp(0, w), boxes[..., 3].clamp(0, h)), -1)
+            ok = torch.isfinite(boxes).all(-1).all(-1) & torch.isfinite(scores).all(-1)
+            boxes, scores = boxes[ok], scores[ok]
+            fm = scores > self.score_thresh
+            idx = fm.nonzero()
+            bsel, ssel = boxes[fm], scores[fm]
+            keep = _backend.nms(bsel, ssel, self.nms_thresh, idx[:, 1])[:self.topk]
+            out.append(Instances(p.image_size, pred_boxes=Boxes(bsel[keep]), scores=ssel[keep], pred_classes=idx[keep, 1]))
+        return out
+
+    @torch.no_grad()
+    def forward_with_given_boxes(self, features, instances):
+        feats = [features[f].detach() for f in self.mask_in_features]
+        x = self.mask_pooler(feats, [i.pred_boxes for i in instances])
+        logits = self.mask_head(x)
+        start = 0
+        for inst in instances:
+            n = len(inst)
+            lg = logits[start:start + n]
+            start += n
+            inst.pred_masks = lg[torch.arange(n, device=lg.device), inst.pred_classes].sigmoid()[:, None]
+        return instances
+
+    def forward(self, images, features, proposals, targets=None, compute_loss=True, branch=""):
+        if compute_loss:
+            raise NotImplementedError("ROI-head losses belong to source training, not to test-time adaptation")
+        feats = [features[f].detach() for f in self.box_in_features]
+        pred = self._forward_box(feats, proposals)
+        if branch == 'TTT':
+            return pred, None
+        return self.forward_with_given_boxes(features, pred), {}
+
+
+def paste_masks_in_image(masks, boxes, image_shape, threshold=0.5):
+    """detectron2 paste_masks_in_image [3P] (grid-sample variant): (R,1,M,M) soft masks -> (R,H,W) bool."""
+    H, W = image_shape
+    R = masks.shape[0]
+    if R == 0:
+        return masks.new_zeros((0, H, W), dtype=torch.bool)
+    out = []
+    ys = torch.arange(H, device=masks.device, dtype=torch.float32) + 0.5
+    xs = torch.arange(W, device=masks.device, dtype=torch.float32) + 0.5
+    for s in range(0, R, 16):
+        b = boxes[s:s + 16]
+        x0, y0, x1, y1 = b[:, 0:1], b[:, 1:2], b[:, 2:3], b[:, 3:4]
+        gy = (ys[None] - y0) / (y1 - y0) * 2 - 1
+        gx = (xs[None] - x0) / (x1 - x0) * 2 - 1
+        grid = torch.stack((gx[:, None, :].expand(-1, H, -1), gy[:, :, None].expand(-1, -1, W)), dim=3)
+        out.append(F.grid_sample(masks[s:s + 16].float(), grid, align_corners=False)[:, 0] >= threshold)
+    return torch.cat(out, 0)
+
+
+def detector_postprocess(results, out_h, out_w, mask_threshold=0.5):
+    """Rescale boxes to the original image size and paste masks (detectron2 detector_postprocess [3P])."""
+    sx, sy = out_w / results.image_size[1], out_h / results.image_size[0]
+    boxes = Boxes(results.pred_boxes.tensor.clone())
+    boxes.scale(sx, sy)
+    boxes.clip((out_h, out_w))
+    keep = boxes.nonempty()
+    res = Instances((out_h, out_w), pred_boxes=Boxes(boxes.tensor[keep]), scores=results.scores[keep],
+                    pred_classes=results.pred_classes[keep])
+    if results.has("pred_masks"):
+        res.pred_masks = paste_masks_in_image(results.pred_masks[keep], res.pred_boxes.tensor, (out_h, out_w), mask_threshold)
+    return res

@@ -1,0 +1,102 @@
+"""DAobjTwoStagePseudoLabGeneralizedRCNN — mirror of the reference meta-architecture (meta_arch/rcnn.py:67-359)
+for the two branches ``train_net.py --eval-only`` uses: ``branch='TTT'`` (:331-357) and eval-mode inference
+(:179-182 -> detectron2 GeneralizedRCNN.inference [3P]).  Attribute names (backbone, proposal_generator, roi_heads,
+D_img, graph_generator, multi_matching_sup, multi_matching_unsup) are the checkpoint contract."""
+import torch
+import torch.nn as nn
+
+from ..GModule import MGM3_unsup, PrototypeComputation, U_sup
+from .backbone import FPN
+from .detector import PseudoLabRPN, StandardROIHeadsPseudoLab, detector_postprocess
+from .structures import Boxes, ImageList, Instances
+
+
+class FCDiscriminator_img(nn.Module):
+    """Image-level domain discriminator (rcnn.py:30-49); parameters only — the adversarial branch is training-time."""
+
+    def __init__(self, num_classes, ndf1=256, ndf2=128):
+        super().__init__()
+        self.conv1 = nn.Conv2d(num_classes, ndf1, 3, padding=1)
+        self.conv2 = nn.Conv2d(ndf1, ndf2, 3, padding=1)
+        self.conv3 = nn.Conv2d(ndf2, ndf2, 3, padding=1)
+        self.classifier = nn.Conv2d(ndf2, 1, 3, padding=1)
+
+
+class DAobjTwoStagePseudoLabGeneralizedRCNN(nn.Module):
+    def __init__(self, *, backbone, proposal_generator, roi_heads, pixel_mean, pixel_std, input_format=None,
+                 vis_period=0, dis_type="p2"):
+        super().__init__()
+        self.backbone = backbone
+        self.proposal_generator = proposal_generator
+        self.roi_heads = roi_heads
+        self.input_format, self.vis_period, self.dis_type = input_format, vis_period, dis_type
+        self.register_buffer("pixel_mean", torch.tensor(pixel_mean, dtype=torch.float32).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor(pixel_std, dtype=torch.float32).view(-1, 1, 1), False)
+        self.D_img = FCDiscriminator_img(self.backbone._out_feature_channels[self.dis_type])
+        sample_dist, univ_size = 10, 32                                            # rcnn.py:115-116
+        self.graph_generator = PrototypeComputation(self.roi_heads.num_classes, sample_dist)
+        self.multi_matching_sup = U_sup(self.roi_heads.num_classes, univ_size)
+        self.multi_matching_unsup = MGM3_unsup(self.roi_heads.num_classes, univ_size)
+        self.teacher_forced = False     # synthetic runs: replace detections by the jittered GT boxes the inputs carry
+        self.autocast_backbone = False  # cfg-5: bf16 autocast for the backbone only
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    def preprocess_image(self, batched_inputs):
+        images = [(x["image"].to(self.device, non_blocking=True).float() - self.pixel_mean) / self.pixel_std for x in batched_inputs]
+        return ImageList.from_tensors(images, self.backbone.size_divisibility)
+
+    def _backbone(self, x):
+        if self.autocast_backbone:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                f = self.backbone(x)
+            return {k: v.float() for k, v in f.items()}
+        return self.backbone(x)
+
+    def forward(self, batched_inputs, branch=None, given_proposals=None, val_mode=False):
+        if not self.training and not val_mode:
+            return self.inference(batched_inputs)
+        images = self.preprocess_image(batched_inputs)
+        features = self._backbone(images.tensor)
+        if branch == "TTT":
+            proposals_rpn, _ = self.proposal_generator(images, features, None, compute_loss=False)
+            proposals_roih, _ = self.roi_heads(images, features, proposals_rpn, targets=None, compute_loss=False, branch=branch)
+            if self.teacher_forced:
+                proposals_roih = [self._forced(x, sz) for x, sz in zip(batched_inputs, images.image_sizes)]
+            feats = [features[k] for k in ("p2", "p3", "p4", "p5", "p6")]
+            nodes, labels = self.graph_generator(feats, proposals_roih)
+            loss = self.multi_matching_unsup(nodes, labels, self.multi_matching_sup.U)
+            return loss, [], [], feats
+        raise NotImplementedError("branch {!r} is a source-training branch; only 'TTT' and eval inference are on the "
+                                  "test-time-adaptation path".format(branch))
+
+    def _forced(self, x, size):
+        b = x["tf_boxes"].to(self.device).float()
+        return Instances(size, pred_boxes=Boxes(b), scores=torch.ones(len(b), device=self.device),
+                         pred_classes=x["tf_classes"].to(self.device))
+
+    @torch.no_grad()
+    def inference(self, batched_inputs, do_postprocess=True):
+        images = self.preprocess_image(batched_inputs)
+        features = self._backbone(images.tensor)
+        proposals, _ = self.proposal_generator(images, features, None, compute_loss=False)
+        results, _ = self.roi_heads(images, features, proposals, None, compute_loss=False, branch="")
+        if not do_postprocess:
+            return results
+        out = []
+        for r, x in zip(results, batched_inputs):
+            out.append({"instances": detector_postprocess(r, x.get("height", r.image_size[0]), x.get("width", r.image_size[1]))})
+        return out
+
+
+def build_model(cfg):
+    """Trainer.build_model(cfg) equivalent for the keys test_segment.yaml sets (config.py:5-64, Base-RCNN-FPN.yaml)."""
+    m = DAobjTwoStagePseudoLabGeneralizedRCNN(
+        backbone=FPN(freeze_at=2),
+        proposal_generator=PseudoLabRPN(),
+        roi_heads=StandardROIHeadsPseudoLab(cfg.MODEL.ROI_HEADS.NUM_CLASSES),
+        pixel_mean=cfg.MODEL.PIXEL_MEAN, pixel_std=cfg.MODEL.PIXEL_STD, input_format=cfg.INPUT.FORMAT,
+        dis_type=cfg.SEMISUPNET.DIS_TYPE)
+    return m.to(torch.device(cfg.MODEL.DEVICE))

@@ -12,6 +12,9 @@ from ._lib import call, check_f32, graphs, ptr, stream
 
 DIM, HID, UNIV = 256, 512, 32
 
+# bench.py sets this to a list to have HIP events recorded (on the launch stream) around the dominant kernel
+KERNEL_TIMERS = None
+
 
 # ------------------------------------------------------------------------------------------- GEMM
 def gemm(A, sam, sak, B, sbn, sbk, Cout, scm, scn, M, N, K, bias=None, alpha=1.0, beta=0.0,
@@ -152,7 +155,14 @@ def gagm_solve(apack, W, U0, gr, sizes, cfg=None):
     ws = torch.empty(nbytes // 4, device=W.device, dtype=torch.float32)
     U = torch.empty(M, UNIV, device=W.device, dtype=torch.float32)
     info = torch.zeros(16, device=W.device, dtype=torch.int32)
+    timers = KERNEL_TIMERS
+    if timers is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     call("ttdg_gagm_solve", ptr(apack), ptr(W), ptr(U0), gr, cfg, ptr(U), ptr(info), ptr(ws), stream())
+    if timers is not None:
+        e1.record()
+        timers.append(("gagm", e0, e1, list(sizes), info))
     gagm_solve.last_U1 = ws[M * UNIV:2 * M * UNIV].view(M, UNIV)   # first projected U (debug / parity tests)
     return U, info, ws[:M * UNIV].view(M, UNIV)
 
@@ -304,3 +314,33 @@ def node_select(labels, lv, sample_dist, cap):
     count = torch.empty(B, device=labels.device, dtype=torch.int32)
     call("ttdg_node_select", ptr(labels), B, lv, int(sample_dist), int(cap), ptr(sel_idx), ptr(sel_lab), ptr(count), stream())
     return sel_idx, sel_lab, count
+
+
+# ------------------------------------------------------------------------------------------- detection helpers
+def roi_align(feat, rois, scale, P):
+    """feat (B,C,H,W) fp32 contiguous, rois (R,5) -> (R,C,P,P); forward only."""
+    feat = feat.detach()
+    if feat.dtype != torch.float32 or not feat.is_contiguous():
+        feat = feat.float().contiguous()
+    rois = rois.detach().float().contiguous()
+    R = rois.shape[0]
+    B, Cc, H, W = feat.shape
+    out = torch.empty(R, Cc, P, P, device=feat.device, dtype=torch.float32)
+    call("ttdg_roi_align_fwd", ptr(feat), B, Cc, H, W, ptr(rois), R, float(scale), int(P), ptr(out), stream())
+    return out
+
+
+def nms(boxes, scores, thr, group=None):
+    """Greedy NMS; returns kept indices (into the input order) sorted by descending score."""
+    N = boxes.shape[0]
+    if N == 0:
+        return torch.empty(0, dtype=torch.int64, device=boxes.device)
+    order = torch.argsort(scores.detach(), descending=True)
+    b = boxes.detach().float()[order].contiguous()
+    g = (torch.zeros(N, dtype=torch.int32, device=boxes.device) if group is None else group[order].to(torch.int32)).contiguous()
+    words = (N + 63) // 64
+    ws = torch.empty(N * words, dtype=torch.int64, device=boxes.device)
+    keep = torch.empty(N, dtype=torch.int32, device=boxes.device)
+    nk = torch.empty(1, dtype=torch.int32, device=boxes.device)
+    call("ttdg_nms", ptr(b), ptr(g), N, float(thr), ptr(ws), ptr(keep), ptr(nk), stream())
+    return order[keep[:int(nk.item())].long()]
