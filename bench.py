@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--cpu-threads", type=int, default=64)
     ap.add_argument("--free-running", action="store_true", help="use the detector's own boxes instead of teacher forcing")
     ap.add_argument("--bf16-backbone", action="store_true", help="cfg-5 style: bf16 autocast for the backbone only")
     return ap.parse_args()
@@ -59,7 +60,10 @@ def build(cfg_id, n_images, args, device, rank, world):
     opt = BaselineTrainer.build_optimizer(cfg, model)
     BaselineTrainer.rank, BaselineTrainer.world, BaselineTrainer.device = rank, world, device
     loader = BaselineTrainer.build_test_loader(cfg, name)
-    return cfg, model, opt, list(loader), name
+    batches = list(loader)
+    from ttdg_mgm_amd.modeling import calibrate_frozen_bn
+    calibrate_frozen_bn(model, batches[0])
+    return cfg, model, opt, batches, name
 
 
 def gpu_run(args, rank, world, device):
@@ -144,10 +148,14 @@ def roofline_from_stamps(run, K):
 
 def cpu_baseline(args):
     from oracle import tta_cpu
-    cores = os.cpu_count() or 1
+    # intra-op threads: all host cores up to 64 (beyond that torch's CPU conv/GEMM kernels stop scaling on the
+    # small tensors of this path and thread wake-ups dominate); `cores` reports what was actually used
+    cores = min(os.cpu_count() or 1, args.cpu_threads)
     torch.set_num_threads(cores)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     t = tta_cpu.time_steps(args.cpu_steps, args.batch, args.size, teacher_forced=not args.free_running)
-    return {"value": args.cpu_steps * args.batch / t, "unit": "adapted images/s", "cores": cores, "kind": "port",
+    return {"value": args.cpu_steps * args.batch / t, "unit": "adapted images/s", "cores": cores,
+            "host_cores": os.cpu_count(), "kind": "port",
             "sample": "%d TTA step(s) + eval pass on %d synthetic %dx%d images, torch-CPU model + oracle GModule, %d threads"
                       % (args.cpu_steps, args.cpu_steps * args.batch, args.size, args.size, cores), "seconds": t}
 

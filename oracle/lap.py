@@ -12,7 +12,7 @@ _SO = os.path.join(_HERE, "_build", "liboracle_lap.so")
 def build():
     src = os.path.join(_HERE, "lap.c")
     if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+        subprocess.check_call(["make", "-C", _HERE, "-s", "_build/liboracle_lap.so"])
     return _SO
 
 

@@ -28,8 +28,10 @@ def _model_and_batches(n_steps, batch, size, teacher_forced):
     torch.manual_seed(0)
     model = build_model(cfg)
     model.teacher_forced = teacher_forced
-    loader = data.build_detection_test_loader(cfg, name)
-    return cfg, model, list(loader), detector, name
+    batches = list(data.build_detection_test_loader(cfg, name))
+    from ttdg_mgm_amd.modeling import calibrate_frozen_bn
+    calibrate_frozen_bn(model, batches[0])
+    return cfg, model, batches, detector, name
 
 
 def tta_step(model, inputs, bufs, cfg):

@@ -528,3 +528,30 @@ def test_fused_sgd_vs_oracle(dev):
             bufs[i] = b[0]
     for p, r in zip(dp, ref_p):
         assert maxerr(p, r) <= 1e-6
+
+
+# ------------------------------------------------------------------------------------------- detection helpers (N1)
+def test_nms_vs_oracle(dev):
+    from oracle import detection as od
+    from ttdg_mgm_amd import ops
+    for seed, n in ((1, 1), (2, 77), (3, 2000), (4, 8400)):
+        g = synth.gen(seed)
+        xy = g.uniform(0, 700, size=(n, 2)); wh = g.uniform(5, 200, size=(n, 2))
+        b = torch.from_numpy(np.concatenate([xy, xy + wh], 1).astype(np.float32))
+        s = torch.from_numpy(g.permutation(n).astype(np.float32))          # distinct scores: unique order
+        grp = torch.from_numpy(g.integers(0, 5, size=n).astype(np.int32))
+        ref = od.nms(b, s, 0.7, grp)
+        got = ops.nms(b.to(dev), s.to(dev), 0.7, grp.to(dev))
+        assert torch.equal(got.cpu(), ref), (seed, n)
+    assert ops.nms(torch.zeros(0, 4, device=dev), torch.zeros(0, device=dev), 0.5).numel() == 0
+
+
+def test_roi_align_vs_oracle(dev):
+    from oracle import detection as od
+    from ttdg_mgm_amd import ops
+    g = synth.gen(11)
+    f = synth.normal(g, (2, 16, 50, 50))
+    rois = torch.tensor([[0, 10., 12., 120., 90.], [1, 0., 0., 399., 399.], [1, 30., 30., 31., 31.], [0, -20., -30., 500., 460.],
+                         [1, 200., 100., 260., 390.]])
+    for P, scale in ((7, 0.125), (14, 0.125), (7, 0.03125)):
+        assert maxerr(ops.roi_align(f.to(dev), rois.to(dev), scale, P), od.roi_align(f, rois, scale, P)) <= 1e-5

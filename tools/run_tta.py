@@ -16,6 +16,8 @@ model.teacher_forced = "--free" not in sys.argv
 opt = BaselineTrainer.build_optimizer(cfg, model)
 BaselineTrainer.device = torch.device("cuda:0")
 loader = BaselineTrainer.build_test_loader(cfg, "synthfundus_a")
+from ttdg_mgm_amd.modeling import calibrate_frozen_bn
+calibrate_frozen_bn(model, next(iter(loader)))
 for i, inputs in enumerate(loader):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     loss = BaselineTrainer.tta_step(model, opt, inputs)

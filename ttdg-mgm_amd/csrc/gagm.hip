@@ -239,13 +239,19 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
         } else {
           const bool tr = n > NU;
           const int nr = tr ? NU : n, nc = tr ? n : NU;
-          LapScratch sc = lap_carve(lapb + wave * lap_stride, nr, nc);
           for (int e = lane; e < n * NU; e += 64) Ub[e] = 0.f;
-          lap_wave_solve(nr, nc, Vb, tr ? 1 : NU, tr ? NU : 1, sc);
-          wave_sync();
-          for (int a = lane; a < nr; a += 64) {
-            const int b = sc.col4row[a];
-            if (tr) Ub[b * NU + a] = 1.f; else Ub[a * NU + b] = 1.f;
+          if (CWMAX == 1 || nc <= 64) {
+            const int b = lap_wave_solve_reg(nr, nc, Vb, tr ? 1 : NU, tr ? NU : 1);
+            wave_sync();
+            if (lane < nr) { if (tr) Ub[b * NU + lane] = 1.f; else Ub[lane * NU + b] = 1.f; }
+          } else {
+            LapScratch sc = lap_carve(lapb + wave * lap_stride, nr, nc);
+            lap_wave_solve(nr, nc, Vb, tr ? 1 : NU, tr ? NU : 1, sc);
+            wave_sync();
+            for (int a = lane; a < nr; a += 64) {
+              const int b = sc.col4row[a];
+              if (tr) Ub[b * NU + a] = 1.f; else Ub[a * NU + b] = 1.f;
+            }
           }
         }
       }

@@ -10,6 +10,12 @@ __global__ __launch_bounds__(64) void lap_batched_kernel(const float* __restrict
   for (int e = lane; e < R * C; e += 64) o[e] = 0.f;
   const bool tr = C < R;  // tall matrices are solved transposed (scipy does the same)
   const int nr = tr ? C : R, nc = tr ? R : C;
+  if (nc <= 64) {   // register-resident solver
+    const int j = lap_wave_solve_reg(nr, nc, m, tr ? 1 : C, tr ? C : 1);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (lane < nr) { if (tr) o[(size_t)j * C + lane] = 1.f; else o[(size_t)lane * C + j] = 1.f; }
+    return;
+  }
   LapScratch sc = lap_carve(lap_smem, nr, nc);
   lap_wave_solve(nr, nc, m, tr ? 1 : C, tr ? C : 1, sc);
   wave_sync();

@@ -116,3 +116,102 @@ __device__ __forceinline__ void lap_wave_solve(int nr, int nc, const float* val,
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Register-resident variant for nc <= 64 (every graph of <= 64 nodes against the 32-slot universe).
+// Lane j owns column j (dual v_j, shortest-path cost, predecessor, owner row, position in scipy's `remaining`
+// list); lane i also owns row i (dual u_i, assigned column).  No LDS traffic besides the cost reads; the scan's
+// arg-min runs on DPP row operations instead of ds_bpermute shuffles.  Same steps, same tie rules, same fp64
+// evaluation order as lap_wave_solve above (and as oracle/lap.c / scipy).
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROWMASK, 0xf, false); }
+
+#define TTDG_DPP_REDUCE(OP)                                            \
+  OP(0xB1, 0xf)  /* quad_perm [1,0,3,2] */                             \
+  OP(0x4E, 0xf)  /* quad_perm [2,3,0,1] */                             \
+  OP(0x141, 0xf) /* row_half_mirror     */                             \
+  OP(0x140, 0xf) /* row_mirror          */                             \
+  OP(0x142, 0xa) /* row_bcast15 -> rows 1,3 */                         \
+  OP(0x143, 0xc) /* row_bcast31 -> rows 2,3 */
+
+__device__ __forceinline__ double wave_min_f64_dpp(double v) {
+#define OP(C, R)                                                                           \
+  {                                                                                        \
+    const int lo = dpp_mov<C, R>(__double2loint(v)), hi = dpp_mov<C, R>(__double2hiint(v)); \
+    v = fmin(v, __hiloint2double(hi, lo));                                                 \
+  }
+  TTDG_DPP_REDUCE(OP)
+#undef OP
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int wave_min_i32_dpp(int v) {
+#define OP(C, R) v = min(v, dpp_mov<C, R>(v));
+  TTDG_DPP_REDUCE(OP)
+#undef OP
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_max_i32_dpp(int v) {
+#define OP(C, R) v = max(v, dpp_mov<C, R>(v));
+  TTDG_DPP_REDUCE(OP)
+#undef OP
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// returns this lane's assigned column (valid for lanes < nr)
+__device__ __forceinline__ int lap_wave_solve_reg(int nr, int nc, const float* val, int si, int sj) {
+  const int lane = threadIdx.x & 63;
+  double u = 0.0, v = 0.0, spc = INFINITY;
+  int col4row = -1, row4col = -1, path = -1, pos = 0;
+  const bool is_col = lane < nc;
+  for (int cur = 0; cur < nr; ++cur) {
+    double minVal = 0.0;
+    int nrem = nc, i = cur, sink = -1;
+    bool active = is_col, SC = false, SR = false;
+    pos = nc - 1 - lane;
+    spc = INFINITY;
+    while (sink == -1) {
+      if (lane == i) SR = true;
+      const double ui = readlane_f64(u, i);
+      if (active) {
+        const double r = minVal + (-(double)val[i * si + lane * sj]) - ui - v;
+        if (r < spc) { path = i; spc = r; }
+      }
+      const double gmin = wave_min_f64_dpp(active ? spc : INFINITY);
+      const bool is_min = active && spc == gmin;
+      const bool un = is_min && row4col == -1;
+      int selpos;
+      if (__ballot(un) != 0ull) selpos = wave_max_i32_dpp(un ? pos : -1);
+      else selpos = wave_min_i32_dpp(is_min ? pos : 0x7fffffff);
+      const unsigned long long selmask = __ballot(active && pos == selpos);
+      const int jsel = __builtin_ctzll(selmask);
+      minVal = gmin;
+      const int owner = __builtin_amdgcn_readlane(row4col, jsel);
+      if (lane == jsel) { SC = true; active = false; }
+      else if (active && pos == nrem - 1) pos = selpos;
+      --nrem;
+      if (owner == -1) sink = jsel; else i = owner;
+    }
+    // dual updates (u of the rows on the alternating tree, v of the scanned columns)
+    const int c4r = (col4row >= 0) ? col4row : 0;
+    const double spc_of_my_col = __shfl(spc, c4r, 64);
+    if (lane == cur) u += minVal;
+    else if (SR) u += minVal - spc_of_my_col;
+    if (SC) v -= minVal - spc;
+    // augment
+    int j = sink;
+    for (;;) {
+      const int r = __builtin_amdgcn_readlane(path, j);
+      const int t = __builtin_amdgcn_readlane(col4row, r);
+      if (lane == j) row4col = r;
+      if (lane == r) col4row = j;
+      j = t;
+      if (r == cur) break;
+    }
+  }
+  return col4row;
+}

@@ -91,6 +91,30 @@ class DAobjTwoStagePseudoLabGeneralizedRCNN(nn.Module):
         return out
 
 
+@torch.no_grad()
+def calibrate_frozen_bn(model, batched_inputs):
+    """Synthetic-weights helper (no pretrained checkpoints exist offline): give every FrozenBN the statistics a
+    trained network would carry, by one forward pass that sets running_mean/var to the batch statistics layer by
+    layer.  Without it random-init activations grow to ~1e3 through the 50 frozen-BN layers and the detector
+    emits non-finite boxes.  Deterministic given the weights and the calibration batch."""
+    from .backbone import FrozenBatchNorm2d
+    hooks = []
+
+    def pre(mod, args):
+        x = args[0].float()
+        mod.running_mean.copy_(x.mean(dim=(0, 2, 3)))
+        mod.running_var.copy_(x.var(dim=(0, 2, 3), unbiased=False).clamp_min(1e-6))
+
+    for m in model.modules():
+        if isinstance(m, FrozenBatchNorm2d):
+            hooks.append(m.register_forward_pre_hook(pre))
+    images = model.preprocess_image(batched_inputs)
+    model.backbone(images.tensor)
+    for h in hooks:
+        h.remove()
+    return model
+
+
 def build_model(cfg):
     """Trainer.build_model(cfg) equivalent for the keys test_segment.yaml sets (config.py:5-64, Base-RCNN-FPN.yaml)."""
     m = DAobjTwoStagePseudoLabGeneralizedRCNN(
