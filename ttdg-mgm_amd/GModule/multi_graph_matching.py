@@ -4,6 +4,8 @@ Class names, constructor signatures, hyper-parameters and state-dict keys follow
 (:119-134, :191-221, :451-474); the forward of MGM3_unsup is one fused device pipeline
 (ops.MatchingLossFn) instead of per-pair Python loops, and GA_GM.forward is one persistent kernel
 instead of up to 1200 iterations of small launches and host round-trips."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -30,7 +32,8 @@ class GA_GM(nn.Module):
         if self.projector0[0] != 'sinkhorn':
             raise NameError('Unknown projecter name: {}'.format(self.projector0[0]))
         return ops.gagm_cfg(tau0=self.sk_tau0[0], gamma=self.sk_gamma, min_tau=self.min_tau[0], tol=self.converge_tol,
-                            quad_weight=quad_weight, max_iter=self.mgm_iter[0], sk_iter=self.sk_iter)
+                            quad_weight=quad_weight, max_iter=self.mgm_iter[0], sk_iter=self.sk_iter,
+                            profile=bool(os.environ.get("TTDG_GAGM_PROFILE")))
 
     def solve_packed(self, apack, W, U0, sizes, quad_weight=1.):
         U, info, V0 = ops.gagm_solve(apack, W.detach().contiguous(), U0.detach().contiguous(), ops.graphs(sizes), sizes,

@@ -143,9 +143,50 @@ __device__ __forceinline__ float block_sum2(float a, float b, float* red, float&
   return sa;
 }
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// V rows [i0, i0+32): (2q * B S + W U) / G on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
+//   W U : A operand = W^T stored [k][i] (leading dimension Mp, zero padded) -> the 32 lanes of a half-wave read 32
+//         consecutive words; B operand = U[k][u].
+//   B S : A operand = B^T stored [v][i] (leading dimension Mp + 1); B operand = S[v][u].
+__device__ __forceinline__ void v_row_tile(int i0, int M, int Mp, const float* WT, const float* Ucur, const float* BT,
+                                           const float* S, float qw2, float invG, float* V, float* V0snap) {
+  const int lane = threadIdx.x & 63, li = lane & 31, kh = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 4
+  for (int k0 = 0; k0 < M; k0 += 2) {
+    const int k = k0 + kh;
+    const bool ok = k < M;
+    const float a = ok ? WT[(size_t)k * Mp + i0 + li] : 0.f;
+    const float b = ok ? Ucur[k * NU + li] : 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+  const int ldb = Mp + 1;
+#pragma unroll 4
+  for (int k0 = 0; k0 < NU; k0 += 2) {
+    const int k = k0 + kh;
+    const float a = (i0 + li < M) ? BT[k * ldb + i0 + li] * qw2 : 0.f;
+    const float b = S[k * NU + li];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+    if (row < M) {
+      const float val = acc[r] * invG;
+      V[row * NU + li] = val;
+      if (V0snap) V0snap[row * NU + li] = val;
+    }
+  }
+}
+
 // 512 threads (8 wavefronts, 2 per SIMD): the register-resident Sinkhorn block needs the 256-VGPR budget.
 // CWMAX 1: graphs up to 64 nodes; CWMAX 2: up to 128 nodes.
-template <bool kLds, int GA_THREADS, int CWMAX>
+// kLds: solver state (U, lastU, lastU2/B^T, V) in LDS; kWLds: W^T and the packed A blocks in LDS as well
+// (both are constants of the solve: staged once, read every iteration).
+template <bool kLds, bool kWLds, int GA_THREADS, int CWMAX>
 __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restrict__ Apack, const float* __restrict__ W,
                                                           const float* __restrict__ U0, ttdg_graphs_t gr,
                                                           ttdg_gagm_cfg_t cfg, float* __restrict__ Uout,
@@ -155,16 +196,25 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
   const int M = gr.off[gr.G], G = gr.G;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int MU = M * NU;
-  // workspace (global): [V0 snapshot MU][first projected U, MU][state 4*MU when !kLds]
+  const int Mp = (M + 31) & ~31;
+  const int SB = NU * (Mp + 1);              // one state buffer: M x 32 row-major, or 32 x (Mp+1) for B^T
+  int asz = 0;
+  for (int g = 0; g < G; ++g) { const int n = gr.off[g + 1] - gr.off[g]; asz += n * n; }
+  // workspace (global): [V0 snapshot MU][first projected U, MU][W^T: M x Mp][state 4*SB when !kLds]
   float* V0snap = ws;
   float* U1snap = ws + MU;
-  float* base = kLds ? ga_smem : ws + 2 * MU;
+  float* WTg = ws + 2 * MU;
+  float* lds = ga_smem;
+  float* base = kLds ? lds : WTg + (size_t)M * Mp;
+  if (kLds) lds += 4 * SB;
   float* Ucur = base;
-  float* Uprev = base + MU;
-  float* X = base + 2 * MU;
-  float* V = base + 3 * MU;
-  float* sm = kLds ? ga_smem + 4 * MU : ga_smem;   // always-LDS part
-  float* S = sm;                 // 1024
+  float* Uprev = base + SB;
+  float* X = base + 2 * SB;
+  float* V = base + 3 * SB;
+  const float* WT = WTg;
+  const float* Ap = Apack;
+  if (kWLds) { WT = lds; lds += M * Mp; Ap = lds; lds += (asz + 3) & ~3; }
+  float* S = lds;                // 1024
   float* red = S + NU * NU;      // 64
   float* wex = red + 64;         // GA_WAVES * (40 + cmaxp)
   const int wex_stride = 40 + cmaxp;
@@ -181,6 +231,17 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
   }
   for (int r = tid; r < M; r += GA_THREADS) s_gid[r] = (short)graph_of(gr, r);
   for (int e = tid; e < MU; e += GA_THREADS) { Ucur[e] = U0[e]; Uprev[e] = 0.f; }   // lastU = zeros (:305)
+  {  // W^T[k][i] = W[i][k], zero padded to Mp columns; A blocks
+    float* wt = kWLds ? const_cast<float*>(WT) : WTg;
+    for (int e = tid; e < M * Mp; e += GA_THREADS) {
+      const int k = e / Mp, i = e - k * Mp;
+      wt[e] = (i < M) ? W[(size_t)i * M + k] : 0.f;
+    }
+    if (kWLds) {
+      float* ap = const_cast<float*>(Ap);
+      for (int e = tid; e < asz; e += GA_THREADS) ap[e] = Apack[e];
+    }
+  }
   __syncthreads();
 
   float tau = cfg.tau0;
@@ -188,43 +249,45 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
   int stage = 0, total = 0;
   const float qw2 = cfg.quad_weight * 2.f, invG = 1.f / (float)G;
   bool first = true;
+  const int ldb = Mp + 1;
+  long long tick = 0, tph[5] = {0, 0, 0, 0, 0};
+#define GA_PHASE(k)                                                    \
+  if (cfg.profile && tid == 0) {                                       \
+    const long long now = (long long)__builtin_readcyclecounter();     \
+    tph[k] += now - tick;                                              \
+    tick = now;                                                        \
+  }
+  if (cfg.profile && tid == 0) tick = (long long)__builtin_readcyclecounter();
 
   for (;;) {   // stages (:311)
     int i = 0;
     for (; i < cfg.max_iter; ++i) {   // :312
-      // ---- B = A U, block diagonal (X <- B) ----
+      // ---- B = A U, block diagonal, stored transposed: X[u][row] ----
       for (int e = tid; e < MU; e += GA_THREADS) {
         const int row = e >> 5, u = e & 31;
         const int g = s_gid[row];
         const int o = s_off[g], n = s_off[g + 1] - o;
-        const float* arow = Apack + s_aoff[g] + (size_t)(row - o) * n;
+        const float* arow = Ap + s_aoff[g] + (size_t)(row - o) * n;
         float acc = 0.f;
         for (int j = 0; j < n; ++j) acc = fmaf(arow[j], Ucur[(o + j) * NU + u], acc);
-        X[e] = acc;
+        X[u * ldb + row] = acc;
       }
       __syncthreads();
+      GA_PHASE(0)
       // ---- S = U^T B ----
       for (int e = tid; e < NU * NU; e += GA_THREADS) {
         const int u = e >> 5, v = e & 31;
         float acc = 0.f;
-        for (int r = 0; r < M; ++r) acc = fmaf(Ucur[r * NU + u], X[r * NU + v], acc);
+        for (int r = 0; r < M; ++r) acc = fmaf(Ucur[r * NU + u], X[v * ldb + r], acc);
         S[e] = acc;
       }
       __syncthreads();
-      // ---- V = (2q B S + W U) / G ----
-      for (int e = tid; e < MU; e += GA_THREADS) {
-        const int row = e >> 5, u = e & 31;
-        float q = 0.f;
-#pragma unroll 8
-        for (int v = 0; v < NU; ++v) q = fmaf(X[row * NU + v], S[v * NU + u], q);
-        const float* wrow = W + (size_t)row * M;
-        float lin = 0.f;
-        for (int j = 0; j < M; ++j) lin = fmaf(wrow[j], Ucur[j * NU + u], lin);
-        const float val = (q * qw2 + lin) * invG;
-        V[e] = val;
-        if (first) V0snap[e] = val;
-      }
+      GA_PHASE(1)
+      // ---- V = (2q B S + W U) / G : one wavefront per 32-row tile, MFMA ----
+      for (int t = wave; t * 32 < M; t += GA_WAVES)
+        v_row_tile(t * 32, M, Mp, WT, Ucur, X, S, qw2, invG, V, first ? V0snap : nullptr);
       __syncthreads();
+      GA_PHASE(2)
       // ---- projection (X <- projected U), one wavefront per graph ----
       for (int g = wave; g < G; g += GA_WAVES) {
         const int o = s_off[g], n = s_off[g + 1] - o;
@@ -256,6 +319,7 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
         }
       }
       __syncthreads();
+      GA_PHASE(3)
       if (G == 2) {   // :358-359
         const int n0 = s_off[1];
         for (int e = tid; e < n0 * NU; e += GA_THREADS) X[e] = ((e >> 5) == (e & 31)) ? 1.f : 0.f;
@@ -272,6 +336,7 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
       }
       float s2;
       const float s1 = block_sum2<GA_WAVES>(d1, d2, red, s2);
+      GA_PHASE(4)
       // rotate: lastU2 <- lastU, lastU <- U, U <- new  (buffers rotate; the old lastU2 becomes scratch X)
       float* t = Uprev; Uprev = Ucur; Ucur = X; X = t;
       first = false;
@@ -289,16 +354,25 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
   }
   __syncthreads();
   for (int e = tid; e < MU; e += GA_THREADS) Uout[e] = Ucur[e];
-  if (tid == 0) { info[6] = total; info[7] = stage; info[8] = 0; }
+  if (tid == 0) {
+    info[6] = total; info[7] = stage; info[8] = 0;
+    for (int k = 0; k < 5; ++k) info[9 + k] = (int32_t)(tph[k] >> 6);   // cycle counter ticks / 64 per phase
+  }
+#undef GA_PHASE
 }
 
 static size_t ga_fixed_lds_bytes(int cmaxp, int GA_WAVES) {
-  // + static LDS: s_off, s_aoff (2 x 65 ints) and s_gid (4096 shorts) ~ 8.8 KB
+  // + static LDS: s_off, s_aoff and s_gid ~ 8.8 KB
   return (size_t)9 * 1024 + (size_t)(NU * NU + 64 + GA_WAVES * (40 + cmaxp)) * sizeof(float) +
          GA_WAVES * ((lap_scratch_bytes(NU, cmaxp) + 15) & ~(size_t)15);
 }
 
-extern "C" size_t ttdg_gagm_workspace_bytes(int M) { return (size_t)6 * M * NU * sizeof(float); }
+static inline int ga_mp(int M) { return (M + 31) & ~31; }
+
+extern "C" size_t ttdg_gagm_workspace_bytes(int M) {
+  const int Mp = ga_mp(M);
+  return ((size_t)2 * M * NU + (size_t)M * Mp + (size_t)4 * NU * (Mp + 1)) * sizeof(float);
+}
 
 extern "C" int ttdg_gagm_solve(const float* Apack, const float* W, const float* U0, ttdg_graphs_t gr,
                                ttdg_gagm_cfg_t cfg, float* U, int32_t* info, void* ws, ttdg_stream_t stream) {
@@ -306,25 +380,34 @@ extern "C" int ttdg_gagm_solve(const float* Apack, const float* W, const float* 
   if (int e = ttdg_validate_graphs(gr)) return e;
   TTDG_REQUIRE(cfg.max_iter >= 1 && cfg.sk_iter >= 0 && cfg.tau0 > 0.f && cfg.gamma > 0.f && cfg.gamma < 1.f,
                "gagm: bad configuration");
-  int cmax = NU;
-  for (int g = 0; g < gr.G; ++g) cmax = gr.off[g + 1] - gr.off[g] > cmax ? gr.off[g + 1] - gr.off[g] : cmax;
+  int cmax = NU, asz = 0;
+  for (int g = 0; g < gr.G; ++g) {
+    const int n = gr.off[g + 1] - gr.off[g];
+    cmax = n > cmax ? n : cmax;
+    asz += n * n;
+  }
   TTDG_LIMIT(cmax <= 128, "gagm: graphs with more than 128 nodes need the multi-workgroup solver (not built yet)");
   TTDG_LIMIT(gr.off[gr.G] <= 4096, "gagm: more than 4096 nodes in total");
   const int cmaxp = (cmax + 63) & ~63;
-  const int M = gr.off[gr.G];
+  const int M = gr.off[gr.G], Mp = ga_mp(M);
   const int waves = 8;
   const size_t fixed = ga_fixed_lds_bytes(cmaxp, waves);
-  const size_t state = (size_t)4 * M * NU * sizeof(float);
-  const bool lds = fixed + state <= 158 * 1024;
-  const size_t bytes = lds ? fixed + state : fixed;
+  const size_t state = (size_t)4 * NU * (Mp + 1) * sizeof(float);
+  const size_t wa = ((size_t)M * Mp + ((asz + 3) & ~3)) * sizeof(float);
+  const size_t cap = 158 * 1024;
+  const int mode = (fixed + state + wa <= cap) ? 2 : (fixed + state <= cap ? 1 : 0);
+  const size_t bytes = fixed + (mode >= 1 ? state : 0) + (mode == 2 ? wa : 0);
   hipStream_t st = (hipStream_t)stream;
-#define GA_LAUNCH(L, T, C)                                                                                         \
-  do {                                                                                                             \
-    TTDG_ALLOW_LDS((gagm_kernel<L, T, C>), bytes);                                                                 \
-    hipLaunchKernelGGL((gagm_kernel<L, T, C>), dim3(1), dim3(T), bytes, st, Apack, W, U0, gr, cfg, U, info, (float*)ws, cmaxp); \
+#define GA_LAUNCH(L, WL, T, C)                                                                                      \
+  do {                                                                                                              \
+    TTDG_ALLOW_LDS((gagm_kernel<L, WL, T, C>), bytes);                                                              \
+    hipLaunchKernelGGL((gagm_kernel<L, WL, T, C>), dim3(1), dim3(T), bytes, st, Apack, W, U0, gr, cfg, U, info, (float*)ws, cmaxp); \
   } while (0)
-  if (cmax <= 64) { if (lds) GA_LAUNCH(true, 512, 1); else GA_LAUNCH(false, 512, 1); }
-  else            { if (lds) GA_LAUNCH(true, 512, 2);  else GA_LAUNCH(false, 512, 2); }
+  if (cmax <= 64) {
+    if (mode == 2) GA_LAUNCH(true, true, 512, 1); else if (mode == 1) GA_LAUNCH(true, false, 512, 1); else GA_LAUNCH(false, false, 512, 1);
+  } else {
+    if (mode == 2) GA_LAUNCH(true, true, 512, 2); else if (mode == 1) GA_LAUNCH(true, false, 512, 2); else GA_LAUNCH(false, false, 512, 2);
+  }
 #undef GA_LAUNCH
   return ttdg_launch_status("gagm");
 }
