@@ -61,21 +61,23 @@ __device__ __forceinline__ void sk_wave_project(const float* Vb, int n, float sc
   for (int it = 0; it < iters; ++it) {
     if ((it & 1) == 0) {
       // rows: f_p = lse_q(L_pq - g_q), lane-local over the lane's half row, then combine the two halves
-      float m = NEG_BIG;
+      float m0 = NEG_BIG, m1 = NEG_BIG, m2 = NEG_BIG, m3 = NEG_BIG;
 #pragma unroll
       for (int k = 0; k < 32 * CW; k += 4) {
         const float4 g4 = *reinterpret_cast<const float4*>(gbuf + qbase + k);
-        m = fmaxf(m, fmaxf(fmaxf(Lr[k] - g4.x, Lr[k + 1] - g4.y), fmaxf(Lr[k + 2] - g4.z, Lr[k + 3] - g4.w)));
+        m0 = fmaxf(m0, Lr[k] - g4.x); m1 = fmaxf(m1, Lr[k + 1] - g4.y); m2 = fmaxf(m2, Lr[k + 2] - g4.z); m3 = fmaxf(m3, Lr[k + 3] - g4.w);
       }
+      float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
       m = fmaxf(m, __shfl_xor(m, 32, 64));
       const float ms = (m == NEG_BIG) ? 0.f : m;   // rows >= r hold no finite entry
-      float s = 0.f;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
       for (int k = 0; k < 32 * CW; k += 4) {
         const float4 g4 = *reinterpret_cast<const float4*>(gbuf + qbase + k);
-        s += fast_exp2(Lr[k] - g4.x - ms) + fast_exp2(Lr[k + 1] - g4.y - ms) + fast_exp2(Lr[k + 2] - g4.z - ms) +
-             fast_exp2(Lr[k + 3] - g4.w - ms);
+        s0 += fast_exp2(Lr[k] - g4.x - ms); s1 += fast_exp2(Lr[k + 1] - g4.y - ms);
+        s2 += fast_exp2(Lr[k + 2] - g4.z - ms); s3 += fast_exp2(Lr[k + 3] - g4.w - ms);
       }
+      float s = (s0 + s1) + (s2 + s3);
       s += __shfl_xor(s, 32, 64);
       if (lane < 32) fbuf[lane] = (lane < r) ? ms + fast_log2(s) : 0.f;
       if (mult > 0) {
@@ -95,20 +97,23 @@ __device__ __forceinline__ void sk_wave_project(const float* Vb, int n, float sc
       const float td = (mult > 0) ? D - fbuf[32] : NEG_BIG;
 #pragma unroll
       for (int w = 0; w < CW; ++w) {
-        float m = td;
+        float m0 = td, m1 = NEG_BIG, m2 = NEG_BIG, m3 = NEG_BIG;
 #pragma unroll
         for (int p = 0; p < NU; p += 4) {
           const float4 f4 = *reinterpret_cast<const float4*>(fbuf + p);
-          m = fmaxf(m, fmaxf(fmaxf(Lc[w][p] - f4.x, Lc[w][p + 1] - f4.y), fmaxf(Lc[w][p + 2] - f4.z, Lc[w][p + 3] - f4.w)));
+          m0 = fmaxf(m0, Lc[w][p] - f4.x); m1 = fmaxf(m1, Lc[w][p + 1] - f4.y);
+          m2 = fmaxf(m2, Lc[w][p + 2] - f4.z); m3 = fmaxf(m3, Lc[w][p + 3] - f4.w);
         }
+        const float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
         const float ms = (m == NEG_BIG) ? 0.f : m;
-        float s = (mult > 0) ? (float)mult * fast_exp2(td - ms) : 0.f;
+        float s0 = (mult > 0) ? (float)mult * fast_exp2(td - ms) : 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
         for (int p = 0; p < NU; p += 4) {
           const float4 f4 = *reinterpret_cast<const float4*>(fbuf + p);
-          s += fast_exp2(Lc[w][p] - f4.x - ms) + fast_exp2(Lc[w][p + 1] - f4.y - ms) + fast_exp2(Lc[w][p + 2] - f4.z - ms) +
-               fast_exp2(Lc[w][p + 3] - f4.w - ms);
+          s0 += fast_exp2(Lc[w][p] - f4.x - ms); s1 += fast_exp2(Lc[w][p + 1] - f4.y - ms);
+          s2 += fast_exp2(Lc[w][p + 2] - f4.z - ms); s3 += fast_exp2(Lc[w][p + 3] - f4.w - ms);
         }
+        const float s = (s0 + s1) + (s2 + s3);
         const int q = lane + 64 * w;
         gq[w] = (q < c) ? ms + fast_log2(s) : 0.f;
         gbuf[q] = gq[w];
@@ -155,8 +160,20 @@ __device__ __forceinline__ void v_row_tile(int i0, int M, int Mp, const float* W
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 4
-  for (int k0 = 0; k0 < M; k0 += 2) {
+  // operands are fetched eight k-pairs ahead of the MFMAs that consume them (LDS / L2 latency off the chain)
+  int k0 = 0;
+  for (; k0 + 16 <= M; k0 += 16) {
+    float a[8], b[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int k = k0 + 2 * q + kh;
+      a[q] = WT[(size_t)k * Mp + i0 + li];
+      b[q] = Ucur[k * NU + li];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
+  }
+  for (; k0 < M; k0 += 2) {
     const int k = k0 + kh;
     const bool ok = k < M;
     const float a = ok ? WT[(size_t)k * Mp + i0 + li] : 0.f;
@@ -164,12 +181,17 @@ __device__ __forceinline__ void v_row_tile(int i0, int M, int Mp, const float* W
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
   }
   const int ldb = Mp + 1;
-#pragma unroll 4
-  for (int k0 = 0; k0 < NU; k0 += 2) {
-    const int k = k0 + kh;
-    const float a = (i0 + li < M) ? BT[k * ldb + i0 + li] * qw2 : 0.f;
-    const float b = S[k * NU + li];
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  {
+    float a[16], b[16];
+    const bool rok = i0 + li < M;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int k = 2 * q + kh;
+      a[q] = rok ? BT[k * ldb + i0 + li] * qw2 : 0.f;
+      b[q] = S[k * NU + li];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
   }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -215,7 +237,8 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
   const float* Ap = Apack;
   if (kWLds) { WT = lds; lds += M * Mp; Ap = lds; lds += (asz + 3) & ~3; }
   float* S = lds;                // 1024
-  float* red = S + NU * NU;      // 64
+  float* Spart = S + NU * NU;    // 4 x 1024 partial tiles of S
+  float* red = Spart + 4 * NU * NU;  // 64
   float* wex = red + 64;         // GA_WAVES * (40 + cmaxp)
   const int wex_stride = 40 + cmaxp;
   unsigned char* lapb = (unsigned char*)(wex + GA_WAVES * wex_stride);
@@ -263,24 +286,53 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
     int i = 0;
     for (; i < cfg.max_iter; ++i) {   // :312
       // ---- B = A U, block diagonal, stored transposed: X[u][row] ----
-      for (int e = tid; e < MU; e += GA_THREADS) {
-        const int row = e >> 5, u = e & 31;
+      for (int e = tid; e < M * 8; e += GA_THREADS) {
+        const int row = e >> 3, u = (e & 7) * 4;
         const int g = s_gid[row];
         const int o = s_off[g], n = s_off[g + 1] - o;
         const float* arow = Ap + s_aoff[g] + (size_t)(row - o) * n;
-        float acc = 0.f;
-        for (int j = 0; j < n; ++j) acc = fmaf(arow[j], Ucur[(o + j) * NU + u], acc);
-        X[u * ldb + row] = acc;
+        const float* ub = Ucur + o * NU + u;
+        float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
+        int j = 0;
+        for (; j + 2 <= n; j += 2) {
+          const float a0 = arow[j], a1 = arow[j + 1];
+          const float4 x0 = *reinterpret_cast<const float4*>(ub + j * NU), x1 = *reinterpret_cast<const float4*>(ub + (j + 1) * NU);
+          c0.x = fmaf(a0, x0.x, c0.x); c0.y = fmaf(a0, x0.y, c0.y); c0.z = fmaf(a0, x0.z, c0.z); c0.w = fmaf(a0, x0.w, c0.w);
+          c1.x = fmaf(a1, x1.x, c1.x); c1.y = fmaf(a1, x1.y, c1.y); c1.z = fmaf(a1, x1.z, c1.z); c1.w = fmaf(a1, x1.w, c1.w);
+        }
+        if (j < n) {
+          const float a0 = arow[j];
+          const float4 x0 = *reinterpret_cast<const float4*>(ub + j * NU);
+          c0.x = fmaf(a0, x0.x, c0.x); c0.y = fmaf(a0, x0.y, c0.y); c0.z = fmaf(a0, x0.z, c0.z); c0.w = fmaf(a0, x0.w, c0.w);
+        }
+        X[(u + 0) * ldb + row] = c0.x + c1.x;
+        X[(u + 1) * ldb + row] = c0.y + c1.y;
+        X[(u + 2) * ldb + row] = c0.z + c1.z;
+        X[(u + 3) * ldb + row] = c0.w + c1.w;
       }
       __syncthreads();
       GA_PHASE(0)
-      // ---- S = U^T B ----
-      for (int e = tid; e < NU * NU; e += GA_THREADS) {
-        const int u = e >> 5, v = e & 31;
-        float acc = 0.f;
-        for (int r = 0; r < M; ++r) acc = fmaf(Ucur[r * NU + u], X[v * ldb + r], acc);
-        S[e] = acc;
+      // ---- S = U^T B : 32x32 output, K = M split over the first four wavefronts (MFMA), partials summed in LDS ----
+      if (wave < 4) {
+        const int li = lane & 31, kh = lane >> 5;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const int chunk = ((M + 7) / 8) * 2;              // rows per wavefront, even
+        const int rbeg = wave * chunk, rend = min(M, rbeg + chunk);
+        for (int r0 = rbeg; r0 < rend; r0 += 2) {
+          const int r = r0 + kh;
+          const bool ok = r < rend;
+          const float a = ok ? Ucur[r * NU + li] : 0.f;      // (u = li, k = r)
+          const float b = ok ? X[li * ldb + r] : 0.f;        // (k = r, v = li)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Spart[wave * NU * NU + ((r & 3) + 8 * (r >> 2) + 4 * kh) * NU + li] = acc[r];
       }
+      __syncthreads();
+      for (int e = tid; e < NU * NU; e += GA_THREADS)
+        S[e] = (Spart[e] + Spart[NU * NU + e]) + (Spart[2 * NU * NU + e] + Spart[3 * NU * NU + e]);
       __syncthreads();
       GA_PHASE(1)
       // ---- V = (2q B S + W U) / G : one wavefront per 32-row tile, MFMA ----
@@ -363,7 +415,7 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
 
 static size_t ga_fixed_lds_bytes(int cmaxp, int GA_WAVES) {
   // + static LDS: s_off, s_aoff and s_gid ~ 8.8 KB
-  return (size_t)9 * 1024 + (size_t)(NU * NU + 64 + GA_WAVES * (40 + cmaxp)) * sizeof(float) +
+  return (size_t)9 * 1024 + (size_t)(5 * NU * NU + 64 + GA_WAVES * (40 + cmaxp)) * sizeof(float) +
          GA_WAVES * ((lap_scratch_bytes(NU, cmaxp) + 15) & ~(size_t)15);
 }
 

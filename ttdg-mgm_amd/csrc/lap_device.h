@@ -183,12 +183,18 @@ __device__ __forceinline__ int lap_wave_solve_reg(int nr, int nc, const float* v
       }
       const double gmin = wave_min_f64_dpp(active ? spc : INFINITY);
       const bool is_min = active && spc == gmin;
-      const bool un = is_min && row4col == -1;
-      int selpos;
-      if (__ballot(un) != 0ull) selpos = wave_max_i32_dpp(un ? pos : -1);
-      else selpos = wave_min_i32_dpp(is_min ? pos : 0x7fffffff);
-      const unsigned long long selmask = __ballot(active && pos == selpos);
-      const int jsel = __builtin_ctzll(selmask);
+      const unsigned long long minmask = __ballot(is_min);
+      int jsel;
+      if (__builtin_popcountll(minmask) == 1) {
+        jsel = __builtin_ctzll(minmask);               // unique minimum: no tie rule needed (the common case)
+      } else {
+        const bool un = is_min && row4col == -1;
+        int selpos;
+        if (__ballot(un) != 0ull) selpos = wave_max_i32_dpp(un ? pos : -1);
+        else selpos = wave_min_i32_dpp(is_min ? pos : 0x7fffffff);
+        jsel = __builtin_ctzll(__ballot(active && pos == selpos));
+      }
+      const int selpos = __builtin_amdgcn_readlane(pos, jsel);
       minVal = gmin;
       const int owner = __builtin_amdgcn_readlane(row4col, jsel);
       if (lane == jsel) { SC = true; active = false; }
