@@ -68,7 +68,7 @@ __device__ __forceinline__ void sk_wave_project(const float* Vb, int n, float sc
         m0 = fmaxf(m0, Lr[k] - g4.x); m1 = fmaxf(m1, Lr[k + 1] - g4.y); m2 = fmaxf(m2, Lr[k + 2] - g4.z); m3 = fmaxf(m3, Lr[k + 3] - g4.w);
       }
       float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      m = fmaxf(m, other_half(m));
       const float ms = (m == NEG_BIG) ? 0.f : m;   // rows >= r hold no finite entry
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
@@ -78,18 +78,18 @@ __device__ __forceinline__ void sk_wave_project(const float* Vb, int n, float sc
         s2 += fast_exp2(Lr[k + 2] - g4.z - ms); s3 += fast_exp2(Lr[k + 3] - g4.w - ms);
       }
       float s = (s0 + s1) + (s2 + s3);
-      s += __shfl_xor(s, 32, 64);
+      s += other_half(s);
       if (lane < 32) fbuf[lane] = (lane < r) ? ms + fast_log2(s) : 0.f;
       if (mult > 0) {
         // dummy row: fd = D + lse_q(-g_q) over the c real columns
         float dm = NEG_BIG;
 #pragma unroll
         for (int w = 0; w < CW; ++w) if (lane + 64 * w < c) dm = fmaxf(dm, -gq[w]);
-        dm = wave_max(dm);
+        dm = wave_max_f32_dpp(dm);
         float ds = 0.f;
 #pragma unroll
         for (int w = 0; w < CW; ++w) if (lane + 64 * w < c) ds += fast_exp2(-gq[w] - dm);
-        ds = wave_sum(ds);
+        ds = wave_sum_f32_dpp(ds);
         if (lane == 0) fbuf[32] = D + dm + fast_log2(ds);
       }
     } else {
@@ -135,8 +135,8 @@ __device__ __forceinline__ void sk_wave_project(const float* Vb, int n, float sc
 
 template <int GA_WAVES>
 __device__ __forceinline__ float block_sum2(float a, float b, float* red, float& outb) {
-  a = wave_sum(a);
-  b = wave_sum(b);
+  a = wave_sum_f32_dpp(a);
+  b = wave_sum_f32_dpp(b);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __syncthreads();
   if (lane == 0) { red[wave] = a; red[GA_WAVES + wave] = b; }

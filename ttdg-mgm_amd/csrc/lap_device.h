@@ -157,6 +157,26 @@ __device__ __forceinline__ int wave_max_i32_dpp(int v) {
 #undef OP
   return __builtin_amdgcn_readlane(v, 63);
 }
+// fp32 wavefront reductions on DPP (result broadcast through lane 63); sum uses 0 as the fill for masked rows
+__device__ __forceinline__ float wave_max_f32_dpp(float v) {
+#define OP(C, R) v = fmaxf(v, __int_as_float(dpp_mov<C, R>(__float_as_int(v))));
+  TTDG_DPP_REDUCE(OP)
+#undef OP
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_sum_f32_dpp(float v) {
+#define OP(C, R) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), C, R, 0xf, false));
+  TTDG_DPP_REDUCE(OP)
+#undef OP
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// value held by the lane 32 positions away (v_permlane32_swap)
+__device__ __forceinline__ float other_half(float v) {
+  const int x = __float_as_int(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  return __int_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
+
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
   return __hiloint2double(hi, lo);
