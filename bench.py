@@ -143,6 +143,7 @@ def roofline_from_stamps(run, K):
     return {"kernel": "gagm_kernel", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
             "traffic": None, "launches": len(ev), "avg_launch_ms": tot_t / len(ev) * 1e3,
             "avg_iterations_per_launch": tot_it / len(ev), "us_per_iteration": tot_t / max(tot_it, 1) * 1e6,
+            "avg_nodes_per_launch": sum(sum(e[1]) for e in ev) / len(ev), "graphs_per_launch": len(ev[0][1]),
             "note": "single-workgroup latency-bound solver; fp32 VALU peak == fp32 MFMA peak"}
 
 

@@ -15,6 +15,14 @@ class _CpuBackend:
     nms = staticmethod(odet.nms)
     roi_align = staticmethod(odet.roi_align)
 
+    @staticmethod
+    def nms_launch(boxes, scores, thr, group=None):
+        return odet.nms(boxes, scores, thr, group)
+
+    @staticmethod
+    def nms_collect(launched):
+        return list(launched)
+
 
 def _model_and_batches(n_steps, batch, size, teacher_forced):
     from ttdg_mgm_amd import data

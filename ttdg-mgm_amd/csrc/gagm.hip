@@ -206,9 +206,9 @@ __device__ __forceinline__ void v_row_tile(int i0, int M, int Mp, const float* W
 
 // 512 threads (8 wavefronts, 2 per SIMD): the register-resident Sinkhorn block needs the 256-VGPR budget.
 // CWMAX 1: graphs up to 64 nodes; CWMAX 2: up to 128 nodes.
-// kLds: solver state (U, lastU, lastU2/B^T, V) in LDS; kWLds: W^T and the packed A blocks in LDS as well
+// kLds: solver state (U, lastU, lastU2/B^T, V) in LDS; kWLds / kALds: W^T / the packed A blocks in LDS as well
 // (both are constants of the solve: staged once, read every iteration).
-template <bool kLds, bool kWLds, int GA_THREADS, int CWMAX>
+template <bool kLds, bool kWLds, bool kALds, int GA_THREADS, int CWMAX>
 __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restrict__ Apack, const float* __restrict__ W,
                                                           const float* __restrict__ U0, ttdg_graphs_t gr,
                                                           ttdg_gagm_cfg_t cfg, float* __restrict__ Uout,
@@ -235,24 +235,25 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
   float* V = base + 3 * SB;
   const float* WT = WTg;
   const float* Ap = Apack;
-  if (kWLds) { WT = lds; lds += M * Mp; Ap = lds; lds += (asz + 3) & ~3; }
+  if (kWLds) { WT = lds; lds += M * Mp; }
+  if (kALds) { Ap = lds; lds += (asz + 3) & ~3; }
   float* S = lds;                // 1024
   float* Spart = S + NU * NU;    // 4 x 1024 partial tiles of S
   float* red = Spart + 4 * NU * NU;  // 64
   float* wex = red + 64;         // GA_WAVES * (40 + cmaxp)
   const int wex_stride = 40 + cmaxp;
-  unsigned char* lapb = (unsigned char*)(wex + GA_WAVES * wex_stride);
-  const size_t lap_stride = (lap_scratch_bytes(NU, cmaxp) + 15) & ~(size_t)15;
+  unsigned char* lapb = (unsigned char*)(wex + GA_WAVES * wex_stride);   // LDS LAP scratch: CWMAX == 2 only
+  const size_t lap_stride = (CWMAX == 2) ? ((lap_scratch_bytes(NU, cmaxp) + 15) & ~(size_t)15) : 0;
+  unsigned char* s_gid = lapb + GA_WAVES * lap_stride;                    // node -> graph, M bytes
 
-  __shared__ int s_off[TTDG_MAX_GRAPHS + 4];     // sized so the static LDS total stays a multiple of 16 B (dynamic base alignment)
+  __shared__ int s_off[TTDG_MAX_GRAPHS + 4];     // 2 x 68 ints: the static LDS total stays a multiple of 16 B (dynamic base alignment)
   __shared__ int s_aoff[TTDG_MAX_GRAPHS + 4];   // start of graph g's block in Apack
-  __shared__ short s_gid[4096];                 // node -> graph (M <= 4096 on this solver)
   if (tid <= G) s_off[tid] = gr.off[tid];
   if (tid == 0) {
     int a = 0;
     for (int g = 0; g < G; ++g) { s_aoff[g] = a; const int n = gr.off[g + 1] - gr.off[g]; a += n * n; }
   }
-  for (int r = tid; r < M; r += GA_THREADS) s_gid[r] = (short)graph_of(gr, r);
+  for (int r = tid; r < M; r += GA_THREADS) s_gid[r] = (unsigned char)graph_of(gr, r);
   for (int e = tid; e < MU; e += GA_THREADS) { Ucur[e] = U0[e]; Uprev[e] = 0.f; }   // lastU = zeros (:305)
   {  // W^T[k][i] = W[i][k], zero padded to Mp columns; A blocks
     float* wt = kWLds ? const_cast<float*>(WT) : WTg;
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
       const int k = e / Mp, i = e - k * Mp;
       wt[e] = (i < M) ? W[(size_t)i * M + k] : 0.f;
     }
-    if (kWLds) {
+    if (kALds) {
       float* ap = const_cast<float*>(Ap);
       for (int e = tid; e < asz; e += GA_THREADS) ap[e] = Apack[e];
     }
@@ -413,10 +414,11 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
 #undef GA_PHASE
 }
 
-static size_t ga_fixed_lds_bytes(int cmaxp, int GA_WAVES) {
-  // + static LDS: s_off, s_aoff and s_gid ~ 8.8 KB
-  return (size_t)9 * 1024 + (size_t)(5 * NU * NU + 64 + GA_WAVES * (40 + cmaxp)) * sizeof(float) +
-         GA_WAVES * ((lap_scratch_bytes(NU, cmaxp) + 15) & ~(size_t)15);
+static size_t ga_fixed_lds_bytes(int cmaxp, int GA_WAVES, int cwmax, int M) {
+  // static LDS (s_off, s_aoff) ~ 0.6 KB + S, 4 partial S tiles, reduction scratch, per-wave potentials, optional LDS-LAP
+  // scratch, node->graph bytes
+  const size_t lap = cwmax == 2 ? GA_WAVES * ((lap_scratch_bytes(NU, cmaxp) + 15) & ~(size_t)15) : 0;
+  return (size_t)1024 + (size_t)(5 * NU * NU + 64 + GA_WAVES * (40 + cmaxp)) * sizeof(float) + lap + ((M + 15) & ~15);
 }
 
 static inline int ga_mp(int M) { return (M + 31) & ~31; }
@@ -443,23 +445,29 @@ extern "C" int ttdg_gagm_solve(const float* Apack, const float* W, const float* 
   const int cmaxp = (cmax + 63) & ~63;
   const int M = gr.off[gr.G], Mp = ga_mp(M);
   const int waves = 8;
-  const size_t fixed = ga_fixed_lds_bytes(cmaxp, waves);
+  const int cw = cmax <= 64 ? 1 : 2;
+  const size_t fixed = ga_fixed_lds_bytes(cmaxp, waves, cw, M);
   const size_t state = (size_t)4 * NU * (Mp + 1) * sizeof(float);
-  const size_t wa = ((size_t)M * Mp + ((asz + 3) & ~3)) * sizeof(float);
+  const size_t wb = (size_t)M * Mp * sizeof(float), ab = (size_t)((asz + 3) & ~3) * sizeof(float);
   const size_t cap = 158 * 1024;
-  const int mode = (fixed + state + wa <= cap) ? 2 : (fixed + state <= cap ? 1 : 0);
-  const size_t bytes = fixed + (mode >= 1 ? state : 0) + (mode == 2 ? wa : 0);
+  // what fits decides what is staged: state, then W^T (largest per-iteration reader), then the A blocks
+  const int mode = (fixed + state + wb + ab <= cap) ? 3 : (fixed + state + wb <= cap) ? 2 : (fixed + state <= cap) ? 1 : 0;
+  const size_t bytes = fixed + (mode >= 1 ? state : 0) + (mode >= 2 ? wb : 0) + (mode >= 3 ? ab : 0);
   hipStream_t st = (hipStream_t)stream;
-#define GA_LAUNCH(L, WL, T, C)                                                                                      \
-  do {                                                                                                              \
-    TTDG_ALLOW_LDS((gagm_kernel<L, WL, T, C>), bytes);                                                              \
-    hipLaunchKernelGGL((gagm_kernel<L, WL, T, C>), dim3(1), dim3(T), bytes, st, Apack, W, U0, gr, cfg, U, info, (float*)ws, cmaxp); \
+#define GA_LAUNCH(L, WL, AL, C)                                                                                      \
+  do {                                                                                                               \
+    TTDG_ALLOW_LDS((gagm_kernel<L, WL, AL, 512, C>), bytes);                                                         \
+    hipLaunchKernelGGL((gagm_kernel<L, WL, AL, 512, C>), dim3(1), dim3(512), bytes, st, Apack, W, U0, gr, cfg, U, info, (float*)ws, cmaxp); \
   } while (0)
-  if (cmax <= 64) {
-    if (mode == 2) GA_LAUNCH(true, true, 512, 1); else if (mode == 1) GA_LAUNCH(true, false, 512, 1); else GA_LAUNCH(false, false, 512, 1);
-  } else {
-    if (mode == 2) GA_LAUNCH(true, true, 512, 2); else if (mode == 1) GA_LAUNCH(true, false, 512, 2); else GA_LAUNCH(false, false, 512, 2);
-  }
+#define GA_MODES(C)                                             \
+  do {                                                          \
+    if (mode == 3) GA_LAUNCH(true, true, true, C);              \
+    else if (mode == 2) GA_LAUNCH(true, true, false, C);        \
+    else if (mode == 1) GA_LAUNCH(true, false, false, C);       \
+    else GA_LAUNCH(false, false, false, C);                     \
+  } while (0)
+  if (cw == 1) GA_MODES(1); else GA_MODES(2);
+#undef GA_MODES
 #undef GA_LAUNCH
   return ttdg_launch_status("gagm");
 }

@@ -30,8 +30,14 @@ class ConvNorm(nn.Conv2d):
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
 
     def forward(self, x):
-        x = super().forward(x)
-        return self.norm(x) if self.norm is not None else x
+        if self.norm is None:
+            return super().forward(x)
+        # frozen statistics: fold the per-channel scale into the filter and pass the shift as the conv bias
+        # (same arithmetic as conv -> x*scale+shift, one activation-sized pass less in forward and backward)
+        n = self.norm
+        scale = n.weight * (n.running_var + n.eps).rsqrt()
+        shift = n.bias - n.running_mean * scale
+        return F.conv2d(x, self.weight * scale.view(-1, 1, 1, 1).to(self.weight.dtype), shift.to(x.dtype), self.stride, self.padding)
 
 
 class Stem(nn.Module):

@@ -100,7 +100,7 @@ class PseudoLabRPN(nn.Module):
                               an[idx.reshape(-1)], (1.0, 1.0, 1.0, 1.0)).reshape(N, k, 4)
             tb.append(bx), ts.append(sc), tl.append(torch.full((k,), lvl, dtype=torch.int32, device=lg.device))
         tb, ts, tl = torch.cat(tb, 1), torch.cat(ts, 1), torch.cat(tl, 0)
-        proposals = []
+        pend = []
         for n, size in enumerate(images.image_sizes):
             b = Boxes(tb[n])
             s, l = ts[n], tl
@@ -108,7 +108,11 @@ class PseudoLabRPN(nn.Module):
             b.clip(size)
             ok &= b.nonempty(0.0)
             bt, s, l = b.tensor[ok], s[ok], l[ok]
-            keep = _backend.nms(bt, s, self.nms_thresh, l)[:post]
+            pend.append((size, bt, s, _backend.nms_launch(bt, s, self.nms_thresh, l)))
+        keeps = _backend.nms_collect([p[3] for p in pend])       # one host sync for the whole batch
+        proposals = []
+        for (size, bt, s, _), keep in zip(pend, keeps):
+            keep = keep[:post]
             proposals.append(Instances(size, proposal_boxes=Boxes(bt[keep]), objectness_logits=s[keep]))
         return proposals, {}
 
@@ -194,7 +198,7 @@ class StandardROIHeadsPseudoLab(nn.Module):
     def _forward_box(self, feats, proposals):
         x = self.box_pooler(feats, [p.proposal_boxes for p in proposals])
         logits, deltas = self.box_predictor(self.box_head(x))
-        out, start = [], 0
+        pend, start = [], 0
         for p in proposals:
             n = len(p)
             lg, dl = logits[start:start + n], deltas[start:start + n]
@@ -208,8 +212,12 @@ class StandardROIHeadsPseudoLab(nn.Module):
             fm = scores > self.score_thresh
             idx = fm.nonzero()
             bsel, ssel = boxes[fm], scores[fm]
-            keep = _backend.nms(bsel, ssel, self.nms_thresh, idx[:, 1])[:self.topk]
-            out.append(Instances(p.image_size, pred_boxes=Boxes(bsel[keep]), scores=ssel[keep], pred_classes=idx[keep, 1]))
+            pend.append((p.image_size, bsel, ssel, idx, _backend.nms_launch(bsel, ssel, self.nms_thresh, idx[:, 1])))
+        keeps = _backend.nms_collect([q[4] for q in pend])
+        out = []
+        for (size, bsel, ssel, idx, _), keep in zip(pend, keeps):
+            keep = keep[:self.topk]
+            out.append(Instances(size, pred_boxes=Boxes(bsel[keep]), scores=ssel[keep], pred_classes=idx[keep, 1]))
         return out
 
     @torch.no_grad()

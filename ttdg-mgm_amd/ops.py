@@ -330,17 +330,31 @@ def roi_align(feat, rois, scale, P):
     return out
 
 
+def nms_launch(boxes, scores, thr, group=None):
+    """Enqueue greedy NMS; returns (order, keep, nkeep) device tensors without synchronising:
+    the kept indices (into the input order, by descending score) are ``order[keep[:nkeep]]``."""
+    N = boxes.shape[0]
+    dev = boxes.device
+    order = torch.argsort(scores.detach(), descending=True)
+    keep = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+    nk = torch.zeros(1, dtype=torch.int32, device=dev)
+    if N > 0:
+        b = boxes.detach().float()[order].contiguous()
+        g = (torch.zeros(N, dtype=torch.int32, device=dev) if group is None else group[order].to(torch.int32)).contiguous()
+        words = (N + 63) // 64
+        ws = torch.empty(N * words, dtype=torch.int64, device=dev)
+        call("ttdg_nms", ptr(b), ptr(g), N, float(thr), ptr(ws), ptr(keep), ptr(nk), stream())
+    return order, keep, nk
+
+
+def nms_collect(launched):
+    """Resolve a list of nms_launch() results with ONE host synchronisation; returns the kept-index tensors."""
+    if not launched:
+        return []
+    counts = torch.cat([nk for _, _, nk in launched]).tolist()
+    return [order[keep[:c].long()] for (order, keep, _), c in zip(launched, counts)]
+
+
 def nms(boxes, scores, thr, group=None):
     """Greedy NMS; returns kept indices (into the input order) sorted by descending score."""
-    N = boxes.shape[0]
-    if N == 0:
-        return torch.empty(0, dtype=torch.int64, device=boxes.device)
-    order = torch.argsort(scores.detach(), descending=True)
-    b = boxes.detach().float()[order].contiguous()
-    g = (torch.zeros(N, dtype=torch.int32, device=boxes.device) if group is None else group[order].to(torch.int32)).contiguous()
-    words = (N + 63) // 64
-    ws = torch.empty(N * words, dtype=torch.int64, device=boxes.device)
-    keep = torch.empty(N, dtype=torch.int32, device=boxes.device)
-    nk = torch.empty(1, dtype=torch.int32, device=boxes.device)
-    call("ttdg_nms", ptr(b), ptr(g), N, float(thr), ptr(ws), ptr(keep), ptr(nk), stream())
-    return order[keep[:int(nk.item())].long()]
+    return nms_collect([nms_launch(boxes, scores, thr, group)])[0]
