@@ -15,9 +15,21 @@ class FrozenBatchNorm2d(nn.Module):
         self.register_buffer("running_mean", torch.zeros(c))
         self.register_buffer("running_var", torch.ones(c) - eps)
 
+        self._fold = None
+
+    def folded(self):
+        """(scale (C,1,1,1), shift (C,)) of the frozen affine map; cached until a buffer is modified in place."""
+        key = (self.weight._version, self.bias._version, self.running_mean._version, self.running_var._version,
+               self.weight.device, self.weight.data_ptr())
+        if self._fold is None or self._fold[0] != key:
+            with torch.no_grad():
+                scale = self.weight * (self.running_var + self.eps).rsqrt()
+                shift = self.bias - self.running_mean * scale
+            self._fold = (key, scale.view(-1, 1, 1, 1), shift)
+        return self._fold[1], self._fold[2]
+
     def forward(self, x):
-        scale = self.weight * (self.running_var + self.eps).rsqrt()
-        shift = self.bias - self.running_mean * scale
+        scale, shift = self.folded()
         return x * scale.view(1, -1, 1, 1).to(x.dtype) + shift.view(1, -1, 1, 1).to(x.dtype)
 
 
@@ -34,10 +46,8 @@ class ConvNorm(nn.Conv2d):
             return super().forward(x)
         # frozen statistics: fold the per-channel scale into the filter and pass the shift as the conv bias
         # (same arithmetic as conv -> x*scale+shift, one activation-sized pass less in forward and backward)
-        n = self.norm
-        scale = n.weight * (n.running_var + n.eps).rsqrt()
-        shift = n.bias - n.running_mean * scale
-        return F.conv2d(x, self.weight * scale.view(-1, 1, 1, 1).to(self.weight.dtype), shift.to(x.dtype), self.stride, self.padding)
+        scale, shift = self.norm.folded()
+        return F.conv2d(x, self.weight * scale, shift.to(x.dtype), self.stride, self.padding)
 
 
 class Stem(nn.Module):
