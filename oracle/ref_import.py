@@ -57,3 +57,25 @@ class FakeInstances:
 
     def __len__(self):
         return len(self.pred_classes)
+
+
+def load_dice_metric():
+    """Import the reference's evaluation/dice_metric.py (pure-numpy E-/S-measure + Dice loop) with stub modules for
+    its absent third-party imports (detectron2.evaluation / detectron2.data / pycocotools)."""
+    if not available():
+        raise RuntimeError("reference tree not present at %s" % REF)
+    import importlib.util
+    stubs = {"detectron2": {}, "detectron2.evaluation": {"DatasetEvaluator": object},
+             "detectron2.data": {"MetadataCatalog": None, "DatasetCatalog": None}, "pycocotools": {}, "pycocotools.mask": {}}
+    for name, attrs in stubs.items():
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__path__ = []
+            for k, v in attrs.items():
+                setattr(m, k, v)
+            sys.modules[name] = m
+    sys.modules["pycocotools"].mask = sys.modules["pycocotools.mask"]
+    spec = importlib.util.spec_from_file_location("_ref_dice_metric", os.path.join(REF, "adapteacher", "evaluation", "dice_metric.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod

@@ -136,3 +136,15 @@ def proto_inputs(ci):
     boxes = [torch.tensor([b[:4] for b in bx], dtype=torch.float32).reshape(-1, 4) for bx in per_img]
     classes = [torch.tensor([b[4] for b in bx], dtype=torch.int64) for bx in per_img]
     return name, feats, boxes, classes
+
+
+def dice_mask_pairs():
+    """(pred, gt) boolean 96x80 mask pairs: overlapping ellipses, shifted, empty prediction, full GT, empty GT."""
+    yy, xx = np.mgrid[0:96, 0:80]
+
+    def ell(cy, cx, a, b):
+        return ((yy - cy) / a) ** 2 + ((xx - cx) / b) ** 2 <= 1.0
+    full, empty = np.ones((96, 80), bool), np.zeros((96, 80), bool)
+    return [(ell(48, 40, 20, 18), ell(50, 42, 22, 17)), (ell(30, 30, 12, 12), ell(60, 50, 15, 10)),
+            (empty, ell(48, 40, 20, 18)), (ell(48, 40, 20, 18), full), (ell(48, 40, 20, 18), empty),
+            (ell(48, 40, 30, 25), ell(48, 40, 12, 10))]

@@ -212,8 +212,22 @@ def gold_proto(bg):
     np.savez_compressed(os.path.join(OUT, "proto.npz"), **out)
 
 
+def gold_dice():
+    """Dice / E-measure / S-measure of the reference's own numpy functions (evaluation/dice_metric.py:54-66,110-240)."""
+    dm = ref_import.load_dice_metric()
+    np.bool = bool     # the reference still uses the removed numpy alias; harmless here
+    out = {}
+    for i, (p, g) in enumerate(dice_mask_pairs()):
+        inter = np.logical_and(p, g).sum()
+        out[f"c{i}_dice"] = np.float64(2 * inter / (p.sum() + g.sum() + 1e-6))
+        out[f"c{i}_ea"] = np.float64(dm.enhanced_align(p, g))
+        out[f"c{i}_sm"] = np.float64(dm.Structure_measure().get_score(p, g))
+    np.savez_compressed(os.path.join(OUT, "dice.npz"), **out)
+
+
 def main():
     mgm, bg = ref_import.load()
+    gold_dice()
     gold_affinity(mgm)
     gold_mha(mgm)
     gold_hungarian(mgm)

@@ -1,0 +1,115 @@
+"""CPU tests of the host logic around the kernels: config reader, synthetic data + loader mapping, Dice / E- / S-
+measure against goldens from the reference's own numpy functions, trainer bookkeeping (family means), model
+construction / state-dict contract."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from ttdg_mgm_amd import data, synth
+from ttdg_mgm_amd.config import add_ateacher_config, get_cfg
+from ttdg_mgm_amd.evaluation import DiceEvaluator, dice_coefficient, enhanced_align, structure_measure
+
+
+def test_config_reads_the_reference_yaml_keys(tmp_path):
+    cfg = add_ateacher_config(get_cfg())
+    cfg.merge_from_file("configs/test_segment.yaml")
+    assert cfg.TEST.TTT is True and cfg.TEST.BATCH == 4 and cfg.TEST.DICE_THRES == 0.9
+    assert cfg.SOLVER.BASE_LR == 0.005 and cfg.MODEL.ROI_HEADS.NUM_CLASSES == 2 and cfg.SEMISUPNET.Trainer == "baseline"
+    cfg.merge_from_list(["TEST.BATCH", "2", "MODEL.DEVICE", "cpu"])
+    assert cfg.TEST.BATCH == 2 and cfg.MODEL.DEVICE == "cpu"
+    c2 = cfg.clone()
+    c2.TEST.BATCH = 8
+    assert cfg.TEST.BATCH == 2
+
+
+@pytest.mark.parametrize("i", range(6))
+def test_dice_e_s_measures_vs_reference_golden(golden, i):
+    gold = golden("dice")
+    p, g = (torch.from_numpy(m) for m in cases.dice_mask_pairs()[i])
+    assert abs(dice_coefficient(p, g) - float(gold[f"c{i}_dice"])) <= 1e-9
+    assert abs(enhanced_align(p, g) - float(gold[f"c{i}_ea"])) <= 1e-9
+    assert abs(structure_measure(p, g) - float(gold[f"c{i}_sm"])) <= 1e-6   # the reference mixes float32/float64 here
+
+
+def test_synthetic_images_are_deterministic_and_well_formed():
+    a = synth.fundus_image(2007)
+    b = synth.fundus_image(2007)
+    assert torch.equal(a[0], b[0]) and a[0].dtype == torch.uint8 and a[0].shape == (3, 512, 512)
+    img, boxes, classes, masks = a
+    assert classes.tolist() == [0, 1] and masks.shape == (2, 512, 512)
+    assert bool((masks[1] & ~masks[0]).sum() == 0)                       # cup inside disc
+    for m, bx in zip(masks, boxes):
+        ys, xs = torch.nonzero(m, as_tuple=True)
+        assert [xs.min(), ys.min(), xs.max() + 1, ys.max() + 1] == bx.long().tolist()
+    pi, pb, pc, pm = synth.polyp_image(5003, 384, 3)
+    assert pi.shape == (3, 384, 384) and 1 <= len(pc) <= 3 and int(pc.max()) < 3
+
+
+def test_loader_resizes_like_the_reference_test_mapper():
+    cfg = get_cfg()
+    cfg.TEST.BATCH = 3
+    data.register_synthetic("host_ds", 4, size=128)
+    batches = list(data.build_detection_test_loader(cfg, "host_ds"))
+    assert [len(b) for b in batches] == [3, 1]
+    it = batches[0][0]
+    assert it["image"].shape == (3, 800, 800) and it["image"].dtype == torch.uint8 and (it["height"], it["width"]) == (128, 128)
+    gt = torch.stack([a["bbox"] for a in it["dataset_dict"]["annotations"]]) * 800 / 128
+    assert float((it["tf_boxes"] - gt).abs().max()) <= 2.0 * 800 / 128 + 1e-4       # +-2 px jitter in original pixels
+
+
+def test_dice_evaluator_semantics():
+    data.register_synthetic("host_ds2", 2, size=64)
+    dd = data.dataset_dicts("host_ds2")
+    ev = DiceEvaluator("host_ds2", 0.9)
+    from ttdg_mgm_amd.modeling.structures import Boxes, Instances
+    outs = []
+    for d in dd:
+        gm = torch.stack([a["mask"] for a in d["annotations"]])
+        inst = Instances((64, 64), pred_boxes=Boxes(torch.zeros(3, 4)), scores=torch.tensor([0.95, 0.5, 0.99]),
+                         pred_classes=torch.tensor([0, 1, 1]), pred_masks=torch.stack([gm[0], gm[1], ~gm[1]]))
+        outs.append({"instances": inst})
+    ev.process([{"image_id": d["image_id"]} for d in dd], outs)
+    res = ev.evaluate()
+    assert len(ev.dice_scores) == 4                                   # score 0.5 filtered out
+    assert abs(ev.dice_scores[0] - 100.0) < 1e-3 and ev.dice_scores[1] < 50
+    assert set(res) == {"Dice Coefficient", "Enhanced Alignment Metric", "Structural Similarity Metric"}
+    ev.reset()
+    assert math.isnan(ev.evaluate()["Dice Coefficient"])             # np.mean([]) in the reference
+
+
+def test_model_state_dict_contract_and_frozen_stages():
+    from ttdg_mgm_amd.engine import BaselineTrainer
+    cfg = get_cfg()
+    cfg.MODEL.DEVICE = "cpu"
+    m = BaselineTrainer.build_model(cfg)
+    sd = m.state_dict()
+    for k in ("backbone.bottom_up.stem.conv1.weight", "backbone.bottom_up.stem.conv1.norm.running_var",
+              "backbone.bottom_up.res5.2.conv3.norm.bias", "backbone.fpn_lateral2.weight", "backbone.fpn_output5.bias",
+              "proposal_generator.rpn_head.anchor_deltas.weight", "roi_heads.box_head.fc1.weight",
+              "roi_heads.box_predictor.cls_score.bias", "roi_heads.mask_head.mask_fcn4.weight", "roi_heads.mask_head.deconv.weight",
+              "D_img.classifier.weight", "multi_matching_sup.U", "multi_matching_sup.Net_U.f2g.wq.weight",
+              "multi_matching_unsup.node_affinity.fc_M.0.weight", "multi_matching_unsup.intra_domain_graph.layer_norm.bias"):
+        assert k in sd, k
+    assert sd["multi_matching_sup.U"].shape == (32, 256) and sd["roi_heads.box_predictor.bbox_pred.weight"].shape == (8, 1024)
+    frozen = [n for n, p in m.named_parameters() if not p.requires_grad]
+    assert frozen and all(n.startswith(("backbone.bottom_up.stem", "backbone.bottom_up.res2")) for n in frozen)
+    opt = BaselineTrainer.build_optimizer(cfg, m)
+    wds = {g["weight_decay"] for g in opt.param_groups}
+    assert wds == {1e-4, 0.0} and all(len(g["params"]) == 1 for g in opt.param_groups)
+    with pytest.raises(NotImplementedError):
+        m.train()
+        m([{"image": torch.zeros(3, 32, 32, dtype=torch.uint8)}], branch="supervised_source")
+
+
+def test_family_means_like_the_reference_trainer():
+    from collections import OrderedDict, defaultdict
+    results = OrderedDict(a_1={"Dice Coefficient": 1.0, "Enhanced Alignment Metric": 2.0, "Structural Similarity Metric": 3.0},
+                          a_2={"Dice Coefficient": 3.0, "Enhanced Alignment Metric": 4.0, "Structural Similarity Metric": 5.0})
+    fam = defaultdict(lambda: defaultdict(list))
+    for key, value in results.items():
+        for k, v in value.items():
+            fam[key.split('_')[0]][k].append(v)
+    assert {k: sum(v) / len(v) for k, v in fam["a"].items()}["Dice Coefficient"] == 2.0
