@@ -116,7 +116,8 @@ class MGM3_unsup(nn.Module):
         self.criterion = PermutationLoss()
         self.dropout_seed = 0          # Philox key of the train-mode attention dropout; bumped every call
         self.check_range = False       # True: sync and raise like losses.py:437-442 when Wds leaves [0,1]
-        self.last = None               # intermediates of the last forward (when trace is requested)
+        self.keep_trace = False        # True: keep the intermediates of the last forward in ``self.last``
+        self.last = None
 
     def forward(self, nodes, labels, U, trace=None, forced_U=None):
         """nodes: list of (n_g, dim) tensors, labels: list of (n_g,) -> scalar loss, or None when there are
@@ -127,6 +128,8 @@ class MGM3_unsup(nn.Module):
         sizes = [len(l) for l in labels]
         if sizes != [int(x.shape[0]) for x in nodes]:
             raise ValueError("nodes and labels disagree on the graph sizes")
+        if trace is None and self.keep_trace:
+            trace = {}
         X = torch.cat(list(nodes), dim=0).float().contiguous()
         aff, att = self.node_affinity, self.intra_domain_graph
         self.dropout_seed += 1
@@ -142,6 +145,9 @@ class MGM3_unsup(nn.Module):
             U.detach().contiguous(), sizes, opts)
         if trace is not None and trace.get("info") is not None:
             self.ga_mgmc.last_info = trace["info"]
+        if self.keep_trace:
+            trace["X"], trace["sizes"] = X.detach(), sizes
+            self.last = trace
         if self.check_range:
             assert int(flag.item()) == 0, "pred_dsmat / gt_perm left [0, 1]"
         return loss
