@@ -113,6 +113,7 @@ typedef struct {
   int32_t max_iter, sk_iter;
   int32_t max_stages;        /* 0 = run the full schedule; k > 0 stops after k stages (parity tests) */
   int32_t start_hungarian;   /* non-zero: the first stage already uses the Hungarian projector (parity tests) */
+  int32_t no_cycle_skip;     /* non-zero: disable the exact Hungarian-stage cycle shortcut (parity tests) */
   int32_t profile;           /* non-zero: info[9..13] receive cycle-counter ticks/64 spent in B, S, V, projection, convergence */
 } ttdg_gagm_cfg_t;
 size_t ttdg_gagm_workspace_bytes(int M);

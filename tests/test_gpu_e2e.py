@@ -89,7 +89,13 @@ def test_eval_pass_and_dice_run_on_device(setup):
     from ttdg_mgm_amd.evaluation import DiceEvaluator
     cfg, cpu, gpu, batch = setup
     ev = DiceEvaluator("e2e_ds", 0.0)               # threshold 0: exercise the Dice / E / S code on real predictions
+    gpu.eval()
+    with torch.no_grad():
+        outs = gpu(batch)
+    counts = [len(o["instances"]) for o in outs]
+    assert sum(counts) > 0, counts
+    assert all(o["instances"].pred_masks.shape[1:] == (256, 256) and o["instances"].pred_masks.dtype == torch.bool for o in outs)
     res, _ = inference_on_dataset(gpu, [batch], ev, cfg)
-    assert len(ev.dice_scores) > 0 and all(0 <= v <= 100 for v in ev.dice_scores)
+    assert len(ev.dice_scores) == sum(counts) and all(0 <= v <= 100 for v in ev.dice_scores)
     assert set(res) == {"Dice Coefficient", "Enhanced Alignment Metric", "Structural Similarity Metric"}
     assert gpu.training is True or gpu.training is False

@@ -558,3 +558,34 @@ def test_roi_align_vs_oracle(dev):
                          [1, 200., 100., 260., 390.]])
     for P, scale in ((7, 0.125), (14, 0.125), (7, 0.03125)):
         assert maxerr(ops.roi_align(f.to(dev), rois.to(dev), scale, P), od.roi_align(f, rois, scale, P)) <= 1e-5
+
+
+@pytest.mark.parametrize("name,sizes,seed", cases.GAGM_CASES)
+def test_gagm_cycle_shortcut_is_exact(dev, name, sizes, seed):
+    """The Hungarian-stage cycle shortcut must return exactly what running every iteration returns."""
+    from ttdg_mgm_amd import ops
+    A, W, U0 = cases.gagm_inputs(sizes, seed)
+    args = (_pack(A, sizes).to(dev), W.to(dev), U0.to(dev), ops.graphs(sizes), list(sizes))
+    U1, i1, _ = ops.gagm_solve(*args, ops.gagm_cfg())
+    U2, i2, _ = ops.gagm_solve(*args, ops.gagm_cfg(no_cycle_skip=True))
+    assert torch.equal(U1, U2)
+    assert i1.cpu().tolist()[:8] == i2.cpu().tolist()[:8]
+
+
+def test_gagm_cycle_shortcut_on_feature_derived_inputs(dev):
+    """Same check on solver inputs that come from node features (random weights: the regime with long Hungarian cycles)."""
+    from ttdg_mgm_amd import ops
+    from ttdg_mgm_amd.GModule import MGM3_unsup
+    hits = 0
+    for seed, sizes in ((700, (22, 22, 22)), (704, (22, 35, 28, 40)), (711, (30, 27, 33, 25)), (705, (18, 25))):
+        nodes, labels = synth.node_sets(seed, sizes, scale=0.5)
+        m = MGM3_unsup(2, 32).to(dev).eval()
+        m.load_state_dict(synth.mgm3_params(seed + 50))
+        tr = {}
+        with torch.no_grad():
+            m([x.to(dev) for x in nodes], [l.to(dev) for l in labels], synth.universe(seed + 70).to(dev), trace=tr)
+        U2, i2, _ = ops.gagm_solve(tr["apack"], tr["Wds"], tr["U0"], ops.graphs(sizes), list(sizes), ops.gagm_cfg(no_cycle_skip=True))
+        assert torch.equal(tr["Ub"], U2)
+        assert tr["info"].cpu().tolist()[:8] == i2.cpu().tolist()[:8]
+        hits += int(i2.cpu().tolist()[5] == 200)
+    assert hits >= 1      # at least one case actually exercised a capped Hungarian stage

@@ -25,7 +25,7 @@ class Graphs(C.Structure):
 class GagmCfg(C.Structure):
     _fields_ = [("tau0", C.c_float), ("gamma", C.c_float), ("min_tau", C.c_float), ("tol", C.c_float),
                 ("quad_weight", C.c_float), ("max_iter", C.c_int32), ("sk_iter", C.c_int32),
-                ("max_stages", C.c_int32), ("start_hungarian", C.c_int32), ("profile", C.c_int32)]
+                ("max_stages", C.c_int32), ("start_hungarian", C.c_int32), ("no_cycle_skip", C.c_int32), ("profile", C.c_int32)]
 
 
 class Levels(C.Structure):

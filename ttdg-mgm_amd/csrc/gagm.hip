@@ -16,6 +16,7 @@
 #include "lap_device.h"
 
 #define NU TTDG_UNIV
+#define GA_HIST 64
 #define NEG_BIG (-INFINITY)
 
 
@@ -245,6 +246,8 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
   unsigned char* lapb = (unsigned char*)(wex + GA_WAVES * wex_stride);   // LDS LAP scratch: CWMAX == 2 only
   const size_t lap_stride = (CWMAX == 2) ? ((lap_scratch_bytes(NU, cmaxp) + 15) & ~(size_t)15) : 0;
   unsigned char* s_gid = lapb + GA_WAVES * lap_stride;                    // node -> graph, M bytes
+  unsigned char* hist = s_gid + ((M + 15) & ~15);                         // GA_HIST x M state codes (cycle shortcut)
+  unsigned long long* hmatch = (unsigned long long*)(hist + ((GA_HIST * M + 15) & ~15));
 
   __shared__ int s_off[TTDG_MAX_GRAPHS + 4];     // 2 x 68 ints: the static LDS total stays a multiple of 16 B (dynamic base alignment)
   __shared__ int s_aoff[TTDG_MAX_GRAPHS + 4];   // start of graph g's block in Apack
@@ -395,6 +398,45 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
       first = false;
       ++total;
       if (sqrtf(s1) < cfg.tol || s2 == 0.f) break;
+      // ---- exact cycle shortcut (Hungarian stage) ----------------------------------------------------------
+      // The Hungarian-stage map U -> LAP(V(U)) is a deterministic map on a finite set, and the reference only
+      // detects periods 1 and 2 (:361): on longer cycles it burns all `max_iter` iterations and returns whatever
+      // state iteration max_iter-1 lands on.  We remember the last HIST states (one byte per node: its universe
+      // slot); when the new state equals the one p >= 3 iterations back, every remaining iteration is known:
+      // S(i + k) = S(i - p + k mod p).  Jump straight to the final state - bit-identical to running them all.
+      if (hungarian && !cfg.no_cycle_skip) {
+        const int slot = i % GA_HIST;
+        for (int r = tid; r < M; r += GA_THREADS) {
+          int code = 255;
+#pragma unroll
+          for (int u = 0; u < NU; ++u) if (Ucur[r * NU + u] != 0.f) code = u;
+          hist[slot * M + r] = (unsigned char)code;
+        }
+        if (tid == 0) { hmatch[0] = ~0ull; }
+        __syncthreads();
+        const int nh = min(i, GA_HIST - 1);          // comparable earlier iterations: i-1 .. i-nh
+        for (int r = tid; r < M; r += GA_THREADS) {
+          const unsigned char mine = hist[slot * M + r];
+          unsigned long long eq = 0;
+          for (int p = 1; p <= nh; ++p)
+            if (hist[((i - p) % GA_HIST) * M + r] == mine) eq |= 1ull << p;
+          atomicAnd(&hmatch[0], eq);
+        }
+        __syncthreads();
+        const unsigned long long mm = hmatch[0] & ~7ull;        // periods >= 3 (1 and 2 are the reference's own exits)
+        if (mm != 0ull) {
+          const int p = __builtin_ctzll(mm);
+          const int R = cfg.max_iter - 1 - i;                   // iterations the reference would still run
+          const int src = (i - p + (R % p)) % GA_HIST;          // history slot holding S(max_iter - 1)
+          __syncthreads();
+          for (int e = tid; e < MU; e += GA_THREADS) Ucur[e] = (hist[src * M + (e >> 5)] == (e & 31)) ? 1.f : 0.f;
+          total += R;
+          i = cfg.max_iter - 1;
+          __syncthreads();
+          ++i;
+          break;
+        }
+      }
     }
     const int its = (i < cfg.max_iter) ? i + 1 : cfg.max_iter;
     if (tid == 0 && stage < 6) info[stage] = its;
@@ -418,7 +460,8 @@ static size_t ga_fixed_lds_bytes(int cmaxp, int GA_WAVES, int cwmax, int M) {
   // static LDS (s_off, s_aoff) ~ 0.6 KB + S, 4 partial S tiles, reduction scratch, per-wave potentials, optional LDS-LAP
   // scratch, node->graph bytes
   const size_t lap = cwmax == 2 ? GA_WAVES * ((lap_scratch_bytes(NU, cmaxp) + 15) & ~(size_t)15) : 0;
-  return (size_t)1024 + (size_t)(5 * NU * NU + 64 + GA_WAVES * (40 + cmaxp)) * sizeof(float) + lap + ((M + 15) & ~15);
+  return (size_t)1024 + (size_t)(5 * NU * NU + 64 + GA_WAVES * (40 + cmaxp)) * sizeof(float) + lap + ((M + 15) & ~15) +
+         ((GA_HIST * M + 15) & ~15) + 16;
 }
 
 static inline int ga_mp(int M) { return (M + 31) & ~31; }

@@ -130,11 +130,12 @@ def mha_adjacency(q, k, gr, sizes, scale, drop_p=0.0, seed=0, zero_diag=True):
 
 
 def gagm_cfg(tau0=0.1, gamma=0.5, min_tau=1e-2, tol=1e-3, quad_weight=0.5, max_iter=200, sk_iter=20,
-             max_stages=0, start_hungarian=False, profile=False):
+             max_stages=0, start_hungarian=False, profile=False, no_cycle_skip=False):
     c = _lib.GagmCfg()
     c.tau0, c.gamma, c.min_tau, c.tol, c.quad_weight = tau0, gamma, min_tau, tol, quad_weight
     c.max_iter, c.sk_iter = int(max_iter), int(sk_iter)
     c.max_stages, c.start_hungarian, c.profile = int(max_stages), int(bool(start_hungarian)), int(bool(profile))
+    c.no_cycle_skip = int(bool(no_cycle_skip))
     return c
 
 
