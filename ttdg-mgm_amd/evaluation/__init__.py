@@ -6,68 +6,81 @@ import numpy as np
 import torch
 
 
-def dice_coefficient(p, g):
+# All three measures are written without host synchronisation (no .item(), no Python branch on a device value):
+# every data-dependent case of the reference becomes a torch.where, so a whole pass enqueues and syncs once.
+def _t(x, like):
+    return torch.as_tensor(x, dtype=torch.float64, device=like.device)
+
+
+def dice_tensor(p, g):
     inter = (p & g).sum().double()
-    return (2 * inter / (p.sum().double() + g.sum().double() + 1e-6)).item()
+    return 2 * inter / (p.sum().double() + g.sum().double() + 1e-6)
+
+
+def enhanced_align_tensor(pred, gt):
+    """dice_metric.py:110-143 (E-measure, IJCAI 2018) for boolean maps."""
+    p, g = pred.double(), gt.double()
+    th = torch.clamp(2 * p.mean(), max=1.0)
+    fm = (p >= th).double()
+    af, ag = fm - fm.mean(), g - g.mean()
+    general = ((2.0 * (ag * af) / (ag * ag + af * af + 1e-8)) + 1) ** 2 / 4
+    em = torch.where(g.sum() == 0, 1.0 - fm, torch.where((1 - g).sum() == 0, fm, general))
+    return em.sum() / (g.numel() - 1 + 1e-8)
+
+
+def _ssim_t(a, b):
+    n = a.numel()
+    if n == 0:
+        return _t(float("nan"), a)
+    x, y = a.mean(), b.mean()
+    sx, sy = a.var(unbiased=False), b.var(unbiased=False)
+    sxy = ((a - x) * (b - y)).sum() / (n - 1) if n > 1 else _t(float("nan"), a)
+    alpha, beta = 4 * x * y * sxy, (x * x + y * y) * (sx + sy)
+    return torch.where(alpha != 0, alpha / (beta + 1e-8), torch.where(beta == 0, _t(1.0, a), _t(0.0, a)))
+
+
+def _s_object_t(v, m):
+    w = m.double()
+    cnt = w.sum()
+    x = (v * w).sum() / cnt
+    sig = torch.sqrt((((v - x) ** 2) * w).sum() / cnt)
+    return 2 * x / (x * x + 1 + sig + 1e-8)
+
+
+def structure_measure_tensor(pred, gt, alpha=0.5, centroid=None):
+    """dice_metric.py:147-240 (S-measure, ICCV 2017) for boolean maps.  ``centroid`` = (cy, cx) of the GT (a host
+    constant of the dataset; computed here with one sync when not supplied)."""
+    p, g = pred.double(), gt > 0.5
+    gd = g.double()
+    y = gd.mean()
+    obj = y * _s_object_t(p * gd, g) + (1 - y) * _s_object_t((1 - p) * (1 - gd), ~g)
+    if centroid is None:
+        ys, xs = torch.nonzero(g, as_tuple=True)
+        centroid = (ys.double().mean().item(), xs.double().mean().item()) if ys.numel() else (0.0, 0.0)
+    h, w = g.shape
+    if centroid[0] != centroid[0]:            # NaN centroid of an empty GT: the general branch is not selected below
+        cy, cx = 1, 1
+    else:
+        cy, cx = int(round(centroid[0])) + 1, int(round(centroid[1])) + 1
+    reg = _t(0.0, p)
+    for (r0, r1, c0, c1) in ((0, cy, 0, cx), (0, cy, cx, w), (cy, h, 0, cx), (cy, h, cx, w)):
+        wgt = (r1 - r0) * (c1 - c0) / (h * w)
+        if wgt > 0:
+            reg = reg + wgt * _ssim_t(p[r0:r1, c0:c1], gd[r0:r1, c0:c1])
+    general = alpha * obj + (1 - alpha) * reg
+    return torch.where(y == 0, 1 - p.mean(), torch.where(y == 1, p.mean(), general))
+
+
+def dice_coefficient(p, g):
+    return dice_tensor(p, g).item()
 
 
 def enhanced_align(pred, gt):
-    """dice_metric.py:110-143 (E-measure, IJCAI 2018) for boolean maps."""
-    p = pred.double()
-    th = min(2 * p.mean().item(), 1.0)
-    fm = (p >= th).double()
-    g = gt.double()
-    if g.sum() == 0:
-        em = 1.0 - fm
-    elif (1 - g).sum() == 0:
-        em = fm
-    else:
-        af, ag = fm - fm.mean(), g - g.mean()
-        al = 2.0 * (ag * af) / (ag * ag + af * af + 1e-8)
-        em = (al + 1) ** 2 / 4
-    return (em.sum() / (g.numel() - 1 + 1e-8)).item()
-
-
-def _ssim(a, b):
-    b = b.double()
-    n = a.numel()
-    if n == 0:
-        return float("nan")
-    x, y = a.mean(), b.mean()
-    sx, sy = a.var(unbiased=False), b.var(unbiased=False)
-    sxy = ((a - x) * (b - y)).sum() / (n - 1) if n > 1 else torch.tensor(float("nan"), dtype=torch.float64)
-    alpha, beta = 4 * x * y * sxy, (x * x + y * y) * (sx + sy)
-    if alpha != 0:
-        return (alpha / (beta + 1e-8)).item()
-    return 1.0 if beta == 0 else 0.0
-
-
-def _s_object(v, m):
-    sel = v[m]
-    x, s = sel.mean(), sel.std(unbiased=False)
-    return (2 * x / (x * x + 1 + s + 1e-8)).item()
+    return enhanced_align_tensor(pred, gt).item()
 
 
 def structure_measure(pred, gt, alpha=0.5):
-    """dice_metric.py:147-240 (S-measure, ICCV 2017) for boolean maps."""
-    p, g = pred.double(), gt > 0.5
-    y = g.double().mean().item()
-    if y == 0:
-        return 1 - p.mean().item()
-    if y == 1:
-        return p.mean().item()
-    gd = g.double()
-    obj = y * _s_object(p * gd, g) + (1 - y) * _s_object((1 - p) * (1 - gd), ~g)
-    ys, xs = torch.nonzero(g, as_tuple=True)
-    cy, cx = int(round(ys.double().mean().item())) + 1, int(round(xs.double().mean().item())) + 1
-    h, w = g.shape
-    area = h * w
-    reg = 0.0
-    for (r0, r1, c0, c1) in ((0, cy, 0, cx), (0, cy, cx, w), (cy, h, 0, cx), (cy, h, cx, w)):
-        wgt = (r1 - r0) * (c1 - c0) / area
-        if wgt > 0:
-            reg += wgt * _ssim(p[r0:r1, c0:c1], gd[r0:r1, c0:c1])
-    return alpha * obj + (1 - alpha) * reg
+    return structure_measure_tensor(pred, gt, alpha).item()
 
 
 class DiceEvaluator:
@@ -77,33 +90,53 @@ class DiceEvaluator:
         self.dataset_dicts = dataset_dicts if dataset_dicts is not None else _dd(dataset_name)
         self._by_id = {d["image_id"]: d for d in self.dataset_dicts}
         self.score_threshold = thres
+        self._gt_cache = {}
         self.reset()
 
     def reset(self):
         self.dice_scores, self.ea_scores, self.sm_scores = [], [], []
+        self._pending = []
+
+    def _gt(self, image_id, dev):
+        key = (image_id, str(dev))
+        if key not in self._gt_cache:
+            out = []
+            for a in self._by_id[image_id]["annotations"]:
+                m = a["mask"]
+                ys, xs = torch.nonzero(m, as_tuple=True)
+                cen = (ys.double().mean().item(), xs.double().mean().item()) if ys.numel() else (float("nan"), float("nan"))
+                out.append((a["category_id"], m.to(dev), cen))
+            self._gt_cache[key] = out
+        return self._gt_cache[key]
 
     def process(self, inputs, outputs):
+        """Enqueues everything on the device; the only synchronisation is the class-id list of the kept predictions."""
         for inp, out in zip(inputs, outputs):
-            anns = self._by_id[inp["image_id"]]["annotations"]
             inst = out["instances"]
             keep = inst.scores >= self.score_threshold
             masks, classes = inst.pred_masks[keep], inst.pred_classes[keep]
-            dev = masks.device
-            gts = [(a["category_id"], a["mask"].to(dev)) for a in anns]
+            gts = self._gt(inp["image_id"], masks.device)
+            zero = torch.zeros((), dtype=torch.float64, device=masks.device)
             for pc, pm in zip(classes.tolist(), masks):
-                bd = be = bs = 0
-                for gc, gm in gts:
+                bd = be = bs = zero
+                for gc, gm, cen in gts:
                     if pc == gc:
-                        bd = max(bd, dice_coefficient(pm, gm))
-                        be = max(be, enhanced_align(pm, gm))
-                        bs = max(bs, structure_measure(pm, gm))
-                self.dice_scores.append(bd * 100)
-                self.ea_scores.append(be * 100)
-                self.sm_scores.append(bs * 100)
+                        bd = torch.maximum(bd, dice_tensor(pm, gm))
+                        be = torch.maximum(be, enhanced_align_tensor(pm, gm))
+                        bs = torch.maximum(bs, structure_measure_tensor(pm, gm, centroid=cen))
+                self._pending.append(torch.stack((bd, be, bs)) * 100)
+
+    def _flush(self):
+        if self._pending:
+            vals = torch.stack(self._pending).cpu().tolist()
+            self._pending = []
+            for d, e, s in vals:
+                self.dice_scores.append(d), self.ea_scores.append(e), self.sm_scores.append(s)
 
     def gather_scores(self):
         """All-gather of the per-rank score lists (the reference reports rank-local means)."""
         import torch.distributed as dist
+        self._flush()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
         parts = [None] * dist.get_world_size()
@@ -113,6 +146,7 @@ class DiceEvaluator:
         self.sm_scores = [x for p in parts for x in p[2]]
 
     def evaluate(self):
+        self._flush()
         mean = lambda v: float(np.mean(v)) if len(v) else float("nan")
         return {"Dice Coefficient": mean(self.dice_scores), "Enhanced Alignment Metric": mean(self.ea_scores),
                 "Structural Similarity Metric": mean(self.sm_scores)}

@@ -97,16 +97,17 @@ def calibrate_frozen_bn(model, batched_inputs):
     trained network would carry, by one forward pass that sets running_mean/var to the batch statistics layer by
     layer.  Without it random-init activations grow to ~1e3 through the 50 frozen-BN layers and the detector
     emits non-finite boxes.  Deterministic given the weights and the calibration batch."""
-    from .backbone import FrozenBatchNorm2d
+    import torch.nn.functional as F
+    from .backbone import ConvNorm
     hooks = []
 
-    def pre(mod, args):
-        x = args[0].float()
-        mod.running_mean.copy_(x.mean(dim=(0, 2, 3)))
-        mod.running_var.copy_(x.var(dim=(0, 2, 3), unbiased=False).clamp_min(1e-6))
+    def pre(mod, args):          # statistics of the raw convolution output, set before the folded conv runs
+        y = F.conv2d(args[0].float(), mod.weight, None, mod.stride, mod.padding)
+        mod.norm.running_mean.copy_(y.mean(dim=(0, 2, 3)))
+        mod.norm.running_var.copy_(y.var(dim=(0, 2, 3), unbiased=False).clamp_min(1e-6))
 
     for m in model.modules():
-        if isinstance(m, FrozenBatchNorm2d):
+        if isinstance(m, ConvNorm) and m.norm is not None:
             hooks.append(m.register_forward_pre_hook(pre))
     images = model.preprocess_image(batched_inputs)
     model.backbone(images.tensor)
