@@ -16,7 +16,7 @@
 #include "lap_device.h"
 
 #define NU TTDG_UNIV
-#define GA_HIST 64
+#define GA_HIST 48
 #define NEG_BIG (-INFINITY)
 
 
@@ -229,11 +229,17 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
   float* WTg = ws + 2 * MU;
   float* lds = ga_smem;
   float* base = kLds ? lds : WTg + (size_t)M * Mp;
-  if (kLds) lds += 4 * SB;
+  if (kLds) lds += 3 * SB;
+  // lastU2 is only touched by the convergence check, always by the same thread for the same element: it lives in
+  // registers (kLds: M <= 256 -> at most 16 values per thread) or in the workspace, never in LDS
   float* Ucur = base;
-  float* Uprev = base + SB;
-  float* X = base + 2 * SB;
-  float* V = base + 3 * SB;
+  float* X = base + SB;
+  float* V = base + 2 * SB;
+  float* Uprev_g = base + 3 * SB;             // used only when !kLds
+  constexpr int UPK = 16;
+  float uprev[UPK];
+#pragma unroll
+  for (int k = 0; k < UPK; ++k) uprev[k] = 0.f;
   const float* WT = WTg;
   const float* Ap = Apack;
   if (kWLds) { WT = lds; lds += M * Mp; }
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
     for (int g = 0; g < G; ++g) { s_aoff[g] = a; const int n = gr.off[g + 1] - gr.off[g]; a += n * n; }
   }
   for (int r = tid; r < M; r += GA_THREADS) s_gid[r] = (unsigned char)graph_of(gr, r);
-  for (int e = tid; e < MU; e += GA_THREADS) { Ucur[e] = U0[e]; Uprev[e] = 0.f; }   // lastU = zeros (:305)
+  for (int e = tid; e < MU; e += GA_THREADS) { Ucur[e] = U0[e]; if (!kLds) Uprev_g[e] = 0.f; }   // lastU = zeros (:305)
   {  // W^T[k][i] = W[i][k], zero padded to Mp columns; A blocks
     float* wt = kWLds ? const_cast<float*>(WT) : WTg;
     for (int e = tid; e < M * Mp; e += GA_THREADS) {
@@ -383,18 +389,34 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
       }
       // ---- convergence (:361) ----
       float d1 = 0.f, d2 = 0.f;
-      for (int e = tid; e < MU; e += GA_THREADS) {
-        const float un = X[e];
-        if (first) U1snap[e] = un;
-        const float a = un - Ucur[e], b = un - Uprev[e];
-        d1 = fmaf(a, a, d1);
-        d2 = fmaf(b, b, d2);
+      if (kLds) {
+#pragma unroll
+        for (int k = 0; k < UPK; ++k) {
+          const int e = tid + k * GA_THREADS;
+          if (e < MU) {
+            const float un = X[e], uc = Ucur[e];
+            if (first) U1snap[e] = un;
+            const float a = un - uc, b = un - uprev[k];
+            d1 = fmaf(a, a, d1);
+            d2 = fmaf(b, b, d2);
+            uprev[k] = uc;                       // lastU2 <- lastU
+          }
+        }
+      } else {
+        for (int e = tid; e < MU; e += GA_THREADS) {
+          const float un = X[e], uc = Ucur[e];
+          if (first) U1snap[e] = un;
+          const float a = un - uc, b = un - Uprev_g[e];
+          d1 = fmaf(a, a, d1);
+          d2 = fmaf(b, b, d2);
+          Uprev_g[e] = uc;
+        }
       }
       float s2;
       const float s1 = block_sum2<GA_WAVES>(d1, d2, red, s2);
       GA_PHASE(4)
-      // rotate: lastU2 <- lastU, lastU <- U, U <- new  (buffers rotate; the old lastU2 becomes scratch X)
-      float* t = Uprev; Uprev = Ucur; Ucur = X; X = t;
+      // lastU <- U, U <- new: the two LDS buffers swap (lastU2 was updated element-wise above)
+      float* t = Ucur; Ucur = X; X = t;
       first = false;
       ++total;
       if (sqrtf(s1) < cfg.tol || s2 == 0.f) break;
@@ -490,11 +512,12 @@ extern "C" int ttdg_gagm_solve(const float* Apack, const float* W, const float* 
   const int waves = 8;
   const int cw = cmax <= 64 ? 1 : 2;
   const size_t fixed = ga_fixed_lds_bytes(cmaxp, waves, cw, M);
-  const size_t state = (size_t)4 * NU * (Mp + 1) * sizeof(float);
+  const size_t state = (size_t)3 * NU * (Mp + 1) * sizeof(float);
   const size_t wb = (size_t)M * Mp * sizeof(float), ab = (size_t)((asz + 3) & ~3) * sizeof(float);
   const size_t cap = 158 * 1024;
   // what fits decides what is staged: state, then W^T (largest per-iteration reader), then the A blocks
-  const int mode = (fixed + state + wb + ab <= cap) ? 3 : (fixed + state + wb <= cap) ? 2 : (fixed + state <= cap) ? 1 : 0;
+  const bool regs_ok = (size_t)M * NU <= (size_t)16 * 512;   // lastU2 in registers: 16 values per thread
+  const int mode = !regs_ok ? 0 : (fixed + state + wb + ab <= cap) ? 3 : (fixed + state + wb <= cap) ? 2 : (fixed + state <= cap) ? 1 : 0;
   const size_t bytes = fixed + (mode >= 1 ? state : 0) + (mode >= 2 ? wb : 0) + (mode >= 3 ? ab : 0);
   hipStream_t st = (hipStream_t)stream;
 #define GA_LAUNCH(L, WL, AL, C)                                                                                      \
