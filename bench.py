@@ -125,12 +125,12 @@ def roofline_from_stamps(run, K):
     for nm, a, b, sizes, info in run["stamps"]:
         if nm == "gagm":
             it = info.cpu().tolist()
-            ev.append((a.elapsed_time(b) * 1e-3, sizes, sum(it[:5]), it[5], it[:6]))
+            ev.append((a.elapsed_time(b) * 1e-3, sizes, sum(it[:5]), it[5], it[:6], it[14], it[15]))
     if not ev:
         return None
     u, ksk = 32, 20
     tot_t, tot_f, tot_it = 0.0, 0.0, 0
-    for dt, sizes, iters_sk, iters_h, _ in ev:
+    for dt, sizes, iters_sk, iters_h, _, _, _ in ev:
         M = sum(sizes)
         tot_it += iters_sk + iters_h
         base = 2 * u * sum(n * n for n in sizes) + 4 * M * u * u + 2 * M * M * u
@@ -145,6 +145,7 @@ def roofline_from_stamps(run, K):
             "avg_iterations_per_launch": tot_it / len(ev), "us_per_iteration": tot_t / max(tot_it, 1) * 1e6,
             "avg_nodes_per_launch": sum(sum(e[1]) for e in ev) / len(ev), "graphs_per_launch": len(ev[0][1]),
             "avg_iterations_per_stage": [sum(e[4][k] for e in ev) / len(ev) for k in range(6)],
+            "hungarian_cycle_periods": [e[5] for e in ev], "hungarian_cycle_detected_at": [e[6] for e in ev],
             "note": "single-workgroup latency-bound solver; fp32 VALU peak == fp32 MFMA peak"}
 
 

@@ -16,7 +16,7 @@
 #include "lap_device.h"
 
 #define NU TTDG_UNIV
-#define GA_HIST 48
+#define GA_HIST 256   /* states remembered for the cycle shortcut (>= max_iter to cover a whole stage) */
 #define NEG_BIG (-INFINITY)
 
 
@@ -151,6 +151,12 @@ __device__ __forceinline__ float block_sum2(float a, float b, float* red, float&
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// workspace layout (floats): [V0: M*32][U1: M*32][W^T: M*Mp][state: 4*32*(Mp+1)][history: GA_HIST*M bytes]
+__host__ __device__ inline size_t ga_ws_hist_off(int M) {
+  const int Mp = (M + 31) & ~31;
+  return (size_t)2 * M * NU + (size_t)M * Mp + (size_t)4 * NU * (Mp + 1);
+}
+
 // V rows [i0, i0+32): (2q * B S + W U) / G on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
 //   W U : A operand = W^T stored [k][i] (leading dimension Mp, zero padded) -> the 32 lanes of a half-wave read 32
 //         consecutive words; B operand = U[k][u].
@@ -252,8 +258,8 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
   unsigned char* lapb = (unsigned char*)(wex + GA_WAVES * wex_stride);   // LDS LAP scratch: CWMAX == 2 only
   const size_t lap_stride = (CWMAX == 2) ? ((lap_scratch_bytes(NU, cmaxp) + 15) & ~(size_t)15) : 0;
   unsigned char* s_gid = lapb + GA_WAVES * lap_stride;                    // node -> graph, M bytes
-  unsigned char* hist = s_gid + ((M + 15) & ~15);                         // GA_HIST x M state codes (cycle shortcut)
-  unsigned long long* hmatch = (unsigned long long*)(hist + ((GA_HIST * M + 15) & ~15));
+  unsigned long long* hmatch = (unsigned long long*)(s_gid + ((M + 15) & ~15));   // 4 x 64 match bits
+  unsigned char* hist = (unsigned char*)(ws + ga_ws_hist_off(M));              // GA_HIST x M state codes, in the L2-resident workspace
 
   __shared__ int s_off[TTDG_MAX_GRAPHS + 4];     // 2 x 68 ints: the static LDS total stays a multiple of 16 B (dynamic base alignment)
   __shared__ int s_aoff[TTDG_MAX_GRAPHS + 4];   // start of graph g's block in Apack
@@ -426,36 +432,44 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
       // state iteration max_iter-1 lands on.  We remember the last HIST states (one byte per node: its universe
       // slot); when the new state equals the one p >= 3 iterations back, every remaining iteration is known:
       // S(i + k) = S(i - p + k mod p).  Jump straight to the final state - bit-identical to running them all.
-      if (hungarian && !cfg.no_cycle_skip) {
-        const int slot = i % GA_HIST;
+      if (hungarian && !cfg.no_cycle_skip && i < GA_HIST) {
         for (int r = tid; r < M; r += GA_THREADS) {
           int code = 255;
 #pragma unroll
           for (int u = 0; u < NU; ++u) if (Ucur[r * NU + u] != 0.f) code = u;
-          hist[slot * M + r] = (unsigned char)code;
+          hist[(size_t)i * M + r] = (unsigned char)code;
         }
-        if (tid == 0) { hmatch[0] = ~0ull; }
-        __syncthreads();
-        const int nh = min(i, GA_HIST - 1);          // comparable earlier iterations: i-1 .. i-nh
-        for (int r = tid; r < M; r += GA_THREADS) {
-          const unsigned char mine = hist[slot * M + r];
-          unsigned long long eq = 0;
-          for (int p = 1; p <= nh; ++p)
-            if (hist[((i - p) % GA_HIST) * M + r] == mine) eq |= 1ull << p;
-          atomicAnd(&hmatch[0], eq);
+        if (tid < 4) hmatch[tid] = ~0ull;
+        __syncthreads();                               // also orders the workspace writes within the workgroup
+        // bit q of hmatch[w] survives iff state (64 w + q) equals the new state on every row
+        for (int w = 0; w * 64 < i; ++w) {
+          for (int r = tid; r < M; r += GA_THREADS) {
+            const unsigned char mine = hist[(size_t)i * M + r];
+            unsigned long long eq = 0;
+            const int lim = min(64, i - w * 64);
+            for (int q = 0; q < lim; ++q)
+              if (hist[(size_t)(w * 64 + q) * M + r] == mine) eq |= 1ull << q;
+            atomicAnd(&hmatch[w], eq);
+          }
         }
         __syncthreads();
-        const unsigned long long mm = hmatch[0] & ~7ull;        // periods >= 3 (1 and 2 are the reference's own exits)
-        if (mm != 0ull) {
-          const int p = __builtin_ctzll(mm);
-          const int R = cfg.max_iter - 1 - i;                   // iterations the reference would still run
-          const int src = (i - p + (R % p)) % GA_HIST;          // history slot holding S(max_iter - 1)
+        int prev = -1;                                  // most recent earlier iteration with the same state
+        for (int w = (i - 1) / 64; w >= 0 && prev < 0; --w) {
+          unsigned long long mbits = hmatch[w];
+          const int lim = min(64, i - w * 64);
+          if (lim < 64) mbits &= (1ull << lim) - 1ull;
+          if (mbits) prev = w * 64 + 63 - __builtin_clzll(mbits);
+        }
+        const int p = (prev >= 0) ? i - prev : 0;
+        if (p >= 3) {                                   // periods 1 and 2 are the reference's own exits
+          const int R = cfg.max_iter - 1 - i;           // iterations the reference would still run
+          const int src = i - p + (R % p);              // iteration whose state equals S(max_iter - 1)
           __syncthreads();
-          for (int e = tid; e < MU; e += GA_THREADS) Ucur[e] = (hist[src * M + (e >> 5)] == (e & 31)) ? 1.f : 0.f;
+          for (int e = tid; e < MU; e += GA_THREADS) Ucur[e] = (hist[(size_t)src * M + (e >> 5)] == (e & 31)) ? 1.f : 0.f;
+          if (tid == 0) { info[14] = p; info[15] = i; }
           total += R;
-          i = cfg.max_iter - 1;
+          i = cfg.max_iter;
           __syncthreads();
-          ++i;
           break;
         }
       }
@@ -482,15 +496,15 @@ static size_t ga_fixed_lds_bytes(int cmaxp, int GA_WAVES, int cwmax, int M) {
   // static LDS (s_off, s_aoff) ~ 0.6 KB + S, 4 partial S tiles, reduction scratch, per-wave potentials, optional LDS-LAP
   // scratch, node->graph bytes
   const size_t lap = cwmax == 2 ? GA_WAVES * ((lap_scratch_bytes(NU, cmaxp) + 15) & ~(size_t)15) : 0;
-  return (size_t)1024 + (size_t)(5 * NU * NU + 64 + GA_WAVES * (40 + cmaxp)) * sizeof(float) + lap + ((M + 15) & ~15) +
-         ((GA_HIST * M + 15) & ~15) + 16;
+  return (size_t)1024 + (size_t)(5 * NU * NU + 64 + GA_WAVES * (40 + cmaxp)) * sizeof(float) + lap + ((M + 15) & ~15) + 64;
 }
 
 static inline int ga_mp(int M) { return (M + 31) & ~31; }
 
 extern "C" size_t ttdg_gagm_workspace_bytes(int M) {
   const int Mp = ga_mp(M);
-  return ((size_t)2 * M * NU + (size_t)M * Mp + (size_t)4 * NU * (Mp + 1)) * sizeof(float);
+  (void)Mp;
+  return ga_ws_hist_off(M) * sizeof(float) + (size_t)GA_HIST * M + 64;
 }
 
 extern "C" int ttdg_gagm_solve(const float* Apack, const float* W, const float* U0, ttdg_graphs_t gr,
