@@ -258,7 +258,8 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
   unsigned char* lapb = (unsigned char*)(wex + GA_WAVES * wex_stride);   // LDS LAP scratch: CWMAX == 2 only
   const size_t lap_stride = (CWMAX == 2) ? ((lap_scratch_bytes(NU, cmaxp) + 15) & ~(size_t)15) : 0;
   unsigned char* s_gid = lapb + GA_WAVES * lap_stride;                    // node -> graph, M bytes
-  unsigned long long* hmatch = (unsigned long long*)(s_gid + ((M + 15) & ~15));   // 4 x 64 match bits
+  unsigned long long* hmatch = (unsigned long long*)(s_gid + ((M + 15) & ~15));   // scratch words of the cycle shortcut
+  unsigned long long* hhash = hmatch + 4;                                         // GA_HIST state hashes
   unsigned char* hist = (unsigned char*)(ws + ga_ws_hist_off(M));              // GA_HIST x M state codes, in the L2-resident workspace
 
   __shared__ int s_off[TTDG_MAX_GRAPHS + 4];     // 2 x 68 ints: the static LDS total stays a multiple of 16 B (dynamic base alignment)
@@ -433,32 +434,38 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
       // slot); when the new state equals the one p >= 3 iterations back, every remaining iteration is known:
       // S(i + k) = S(i - p + k mod p).  Jump straight to the final state - bit-identical to running them all.
       if (hungarian && !cfg.no_cycle_skip && i < GA_HIST) {
+        // state code + 64-bit hash (xor of per-row mixes); the full state goes to the workspace, the hash stays in LDS
+        if (tid == 0) hmatch[0] = 0ull;
+        __syncthreads();
+        unsigned long long hx = 0;
         for (int r = tid; r < M; r += GA_THREADS) {
           int code = 255;
 #pragma unroll
           for (int u = 0; u < NU; ++u) if (Ucur[r * NU + u] != 0.f) code = u;
           hist[(size_t)i * M + r] = (unsigned char)code;
+          unsigned long long z = (unsigned long long)(r * 256 + code) + 0x9E3779B97F4A7C15ull;     // splitmix64
+          z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+          z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+          hx ^= z ^ (z >> 31);
         }
-        if (tid < 4) hmatch[tid] = ~0ull;
-        __syncthreads();                               // also orders the workspace writes within the workgroup
-        // bit q of hmatch[w] survives iff state (64 w + q) equals the new state on every row
-        for (int w = 0; w * 64 < i; ++w) {
-          for (int r = tid; r < M; r += GA_THREADS) {
-            const unsigned char mine = hist[(size_t)i * M + r];
-            unsigned long long eq = 0;
-            const int lim = min(64, i - w * 64);
-            for (int q = 0; q < lim; ++q)
-              if (hist[(size_t)(w * 64 + q) * M + r] == mine) eq |= 1ull << q;
-            atomicAnd(&hmatch[w], eq);
-          }
-        }
+        if (hx) atomicXor(&hmatch[0], hx);
         __syncthreads();
-        int prev = -1;                                  // most recent earlier iteration with the same state
-        for (int w = (i - 1) / 64; w >= 0 && prev < 0; --w) {
-          unsigned long long mbits = hmatch[w];
-          const int lim = min(64, i - w * 64);
-          if (lim < 64) mbits &= (1ull << lim) - 1ull;
-          if (mbits) prev = w * 64 + 63 - __builtin_clzll(mbits);
+        const unsigned long long hcur = hmatch[0];
+        __syncthreads();
+        if (tid == 0) { hhash[i] = hcur; hmatch[1] = 0ull; }
+        __syncthreads();
+        // most recent earlier iteration with the same hash (then verified exactly)
+        if (tid < i && hhash[tid] == hcur) atomicMax(&hmatch[1], (unsigned long long)(tid + 1));
+        __syncthreads();
+        int prev = (int)hmatch[1] - 1;
+        if (prev >= 0) {                                // exact check of the candidate (hash collisions must not jump)
+          __syncthreads();
+          if (tid == 0) hmatch[2] = 1ull;
+          __syncthreads();
+          for (int r = tid; r < M; r += GA_THREADS)
+            if (hist[(size_t)prev * M + r] != hist[(size_t)i * M + r]) hmatch[2] = 0ull;
+          __syncthreads();
+          if (hmatch[2] == 0ull) prev = -1;
         }
         const int p = (prev >= 0) ? i - prev : 0;
         if (p >= 3) {                                   // periods 1 and 2 are the reference's own exits
@@ -496,7 +503,7 @@ static size_t ga_fixed_lds_bytes(int cmaxp, int GA_WAVES, int cwmax, int M) {
   // static LDS (s_off, s_aoff) ~ 0.6 KB + S, 4 partial S tiles, reduction scratch, per-wave potentials, optional LDS-LAP
   // scratch, node->graph bytes
   const size_t lap = cwmax == 2 ? GA_WAVES * ((lap_scratch_bytes(NU, cmaxp) + 15) & ~(size_t)15) : 0;
-  return (size_t)1024 + (size_t)(5 * NU * NU + 64 + GA_WAVES * (40 + cmaxp)) * sizeof(float) + lap + ((M + 15) & ~15) + 64;
+  return (size_t)1024 + (size_t)(5 * NU * NU + 64 + GA_WAVES * (40 + cmaxp)) * sizeof(float) + lap + ((M + 15) & ~15) + 32 + GA_HIST * 8;
 }
 
 static inline int ga_mp(int M) { return (M + 31) & ~31; }
