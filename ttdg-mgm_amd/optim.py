@@ -35,13 +35,15 @@ class FusedSGD(torch.optim.Optimizer):
             for p in group["params"]:
                 if p.grad is None:
                     continue
-                if p.dtype != torch.float32 or not p.is_contiguous():
-                    raise TypeError("FusedSGD handles contiguous float32 parameters")
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+                if p.dtype != torch.float32 or not dense:
+                    raise TypeError("FusedSGD handles dense float32 parameters")
+                # the update is element-wise: any dense layout works as long as p, grad and buffer share it
+                g = p.grad if p.grad.stride() == p.stride() else torch.empty_like(p).copy_(p.grad)
                 st = self.state[p]
                 first = "momentum_buffer" not in st
                 if first:
-                    st["momentum_buffer"] = torch.empty_like(p)
+                    st["momentum_buffer"] = torch.empty_like(p)       # preserves p's strides
                 todo.append((p, g, st["momentum_buffer"], group["weight_decay"], first))
         if not todo:
             return None
