@@ -191,6 +191,12 @@ int ttdg_roi_align_fwd(const float* feat, int B, int C, int H, int W, const floa
 int ttdg_nms(const float* boxes, const int32_t* group, int N, float thr, void* mask_ws, int32_t* keep,
              int32_t* nkeep, ttdg_stream_t stream);
 
+/* grouped variant: boxes sorted by (group, descending score); seg (ngroups+1 device ints) delimits the groups;
+ * max_group = an upper bound of the largest group (sizes the launch and the N x ceil(max_group/64) uint64 scratch);
+ * flags (N bytes) receives 1 for kept boxes.  One wavefront per group: the groups are swept concurrently. */
+int ttdg_nms_grouped(const float* boxes, const int32_t* seg, int ngroups, int N, int max_group, float thr,
+                     void* mask_ws, unsigned char* flags, ttdg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,8 +16,9 @@ class _CpuBackend:
     roi_align = staticmethod(odet.roi_align)
 
     @staticmethod
-    def nms_launch(boxes, scores, thr, group=None):
-        return odet.nms(boxes, scores, thr, group)
+    def nms_launch(boxes, scores, thr, group=None, ngroups=None, max_group=None, topk=None):
+        keep = odet.nms(boxes, scores, thr, group)
+        return keep if topk is None else keep[:topk]
 
     @staticmethod
     def nms_collect(launched):

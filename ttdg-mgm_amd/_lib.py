@@ -68,6 +68,7 @@ SIGNATURES = {
     "ttdg_sgd_multi_tensor": (C.c_int, [_P, _P, _P, _I, _I, _F, _F, _S]),
     "ttdg_roi_align_fwd": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _F, _I, _P, _S]),
     "ttdg_nms": (C.c_int, [_P, _P, _I, _F, _P, _P, _P, _S]),
+    "ttdg_nms_grouped": (C.c_int, [_P, _P, _I, _I, _I, _F, _P, _P, _S]),
 }
 
 _lib = None

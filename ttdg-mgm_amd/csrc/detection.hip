@@ -133,3 +133,91 @@ extern "C" int ttdg_nms(const float* boxes, const int32_t* group, int N, float t
   hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(64), 0, st, (const unsigned long long*)mask_ws, N, words, keep, nkeep);
   return ttdg_launch_status("nms");
 }
+
+// ---- grouped NMS: boxes sorted by (group, descending score); seg[g]..seg[g+1] delimits group g (device array).
+// Groups never interact, so every group gets its own wavefront (own CU) for both phases - on the RPN path the five
+// FPN levels of an image are swept concurrently instead of one after another.  Output: keep flags per box.
+__global__ __launch_bounds__(64) void nms_group_mask_kernel(const float* __restrict__ boxes, const int32_t* __restrict__ seg,
+                                                            int words, float thr, unsigned long long* __restrict__ mask) {
+  const int g = blockIdx.z;
+  const int s0 = seg[g], n = seg[g + 1] - s0;
+  const int i = blockIdx.x, w = blockIdx.y, lane = threadIdx.x;
+  if (i >= n || w * 64 >= n) return;
+  const int j = w * 64 + lane;
+  bool hit = false;
+  if (j < n && j > i) {
+    const float4 a = reinterpret_cast<const float4*>(boxes)[s0 + i], b = reinterpret_cast<const float4*>(boxes)[s0 + j];
+    const float iw = fminf(a.z, b.z) - fmaxf(a.x, b.x), ih = fminf(a.w, b.w) - fmaxf(a.y, b.y);
+    const float inter = fmaxf(iw, 0.f) * fmaxf(ih, 0.f);
+    const float ua = (a.z - a.x) * (a.w - a.y) + (b.z - b.x) * (b.w - b.y) - inter;
+    hit = inter > thr * ua;
+  }
+  const unsigned long long m = __ballot(hit);
+  if (lane == 0) mask[(size_t)(s0 + i) * words + w] = m;
+}
+
+__global__ __launch_bounds__(64) void nms_group_sweep_kernel(const unsigned long long* __restrict__ mask,
+                                                             const int32_t* __restrict__ seg, int words,
+                                                             unsigned char* __restrict__ flags) {
+  const int g = blockIdx.x, lane = threadIdx.x;
+  const int s0 = seg[g], N = seg[g + 1] - s0;
+  const int nw = (N + 63) / 64;
+  const unsigned long long* mk = mask + (size_t)s0 * words;
+  unsigned long long rem[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int b = 0; b < nw; ++b) {
+    const int owner = b & 63, slot = b >> 6;
+    unsigned long long word = 0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) if (s == slot) word = rem[s];
+    const unsigned long long remw = ((unsigned long long)__builtin_amdgcn_readlane((unsigned)(word >> 32), owner) << 32) |
+                                    (unsigned)__builtin_amdgcn_readlane((unsigned)word, owner);
+    const int box = b * 64 + lane;
+    const unsigned long long diag = (box < N) ? mk[(size_t)box * words + b] : 0ull;
+    const int nbox = min(64, N - b * 64);
+    unsigned long long alive = ~remw;
+    if (nbox < 64) alive &= (1ull << nbox) - 1ull;
+    unsigned long long kept = 0;
+    while (alive) {
+      const int i = __builtin_ctzll(alive);
+      kept |= 1ull << i;
+      const unsigned long long d = ((unsigned long long)__builtin_amdgcn_readlane((unsigned)(diag >> 32), i) << 32) |
+                                   (unsigned)__builtin_amdgcn_readlane((unsigned)diag, i);
+      alive &= ~d;
+      alive &= ~(1ull << i);
+    }
+    if (box < N) flags[s0 + box] = (unsigned char)((kept >> lane) & 1ull);
+    unsigned long long k = kept;
+    while (k) {
+      int r[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { r[q] = k ? __builtin_ctzll(k) : -1; if (k) k &= k - 1; }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int w = lane + 64 * s;
+        if (64 * s >= nw) break;
+        if (w > b && w < nw) {
+          unsigned long long m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+          m0 = mk[(size_t)(b * 64 + r[0]) * words + w];
+          if (r[1] >= 0) m1 = mk[(size_t)(b * 64 + r[1]) * words + w];
+          if (r[2] >= 0) m2 = mk[(size_t)(b * 64 + r[2]) * words + w];
+          if (r[3] >= 0) m3 = mk[(size_t)(b * 64 + r[3]) * words + w];
+          rem[s] |= (m0 | m1) | (m2 | m3);
+        }
+      }
+    }
+  }
+}
+
+extern "C" int ttdg_nms_grouped(const float* boxes, const int32_t* seg, int ngroups, int N, int max_group, float thr,
+                                void* mask_ws, unsigned char* flags, ttdg_stream_t stream) {
+  TTDG_REQUIRE(boxes && seg && flags && N >= 0 && ngroups >= 1 && max_group >= 0, "nms_grouped: bad arguments");
+  if (N == 0) return 0;
+  TTDG_REQUIRE(mask_ws, "nms_grouped: null workspace");
+  TTDG_LIMIT(max_group <= 32768, "nms_grouped: more than 32768 boxes in one group");
+  const int words = (max_group + 63) / 64;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(nms_group_mask_kernel, dim3(max_group, words, ngroups), dim3(64), 0, st, boxes, seg, words, thr,
+                     (unsigned long long*)mask_ws);
+  hipLaunchKernelGGL(nms_group_sweep_kernel, dim3(ngroups), dim3(64), 0, st, (const unsigned long long*)mask_ws, seg, words, flags);
+  return ttdg_launch_status("nms_grouped");
+}

@@ -108,11 +108,10 @@ class PseudoLabRPN(nn.Module):
             b.clip(size)
             ok &= b.nonempty(0.0)
             bt, s, l = b.tensor[ok], s[ok], l[ok]
-            pend.append((size, bt, s, _backend.nms_launch(bt, s, self.nms_thresh, l)))
+            pend.append((size, bt, s, _backend.nms_launch(bt, s, self.nms_thresh, l, len(self.in_features), pre, post)))
         keeps = _backend.nms_collect([p[3] for p in pend])       # one host sync for the whole batch
         proposals = []
         for (size, bt, s, _), keep in zip(pend, keeps):
-            keep = keep[:post]
             proposals.append(Instances(size, proposal_boxes=Boxes(bt[keep]), objectness_logits=s[keep]))
         return proposals, {}
 
@@ -212,11 +211,10 @@ class StandardROIHeadsPseudoLab(nn.Module):
             fm = scores > self.score_thresh
             idx = fm.nonzero()
             bsel, ssel = boxes[fm], scores[fm]
-            pend.append((p.image_size, bsel, ssel, idx, _backend.nms_launch(bsel, ssel, self.nms_thresh, idx[:, 1])))
+            pend.append((p.image_size, bsel, ssel, idx, _backend.nms_launch(bsel, ssel, self.nms_thresh, idx[:, 1], self.num_classes, None, self.topk)))
         keeps = _backend.nms_collect([q[4] for q in pend])
         out = []
         for (size, bsel, ssel, idx, _), keep in zip(pend, keeps):
-            keep = keep[:self.topk]
             out.append(Instances(size, pred_boxes=Boxes(bsel[keep]), scores=ssel[keep], pred_classes=idx[keep, 1]))
         return out
 

@@ -331,31 +331,47 @@ def roi_align(feat, rois, scale, P):
     return out
 
 
-def nms_launch(boxes, scores, thr, group=None):
-    """Enqueue greedy NMS; returns (order, keep, nkeep) device tensors without synchronising:
-    the kept indices (into the input order, by descending score) are ``order[keep[:nkeep]]``."""
+def nms_launch(boxes, scores, thr, group=None, ngroups=None, max_group=None, topk=None):
+    """Enqueue greedy NMS without synchronising.  With ``group`` (ids in [0, ngroups)) the groups are independent
+    problems swept concurrently (one wavefront each); ``max_group`` bounds the largest group (default N).
+    Returns a handle for nms_collect: kept indices come back sorted by descending score, at most ``topk`` of them."""
     N = boxes.shape[0]
     dev = boxes.device
-    order = torch.argsort(scores.detach(), descending=True)
-    keep = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
-    nk = torch.zeros(1, dtype=torch.int32, device=dev)
-    if N > 0:
-        b = boxes.detach().float()[order].contiguous()
-        g = (torch.zeros(N, dtype=torch.int32, device=dev) if group is None else group[order].to(torch.int32)).contiguous()
-        words = (N + 63) // 64
-        ws = torch.empty(N * words, dtype=torch.int64, device=dev)
-        call("ttdg_nms", ptr(b), ptr(g), N, float(thr), ptr(ws), ptr(keep), ptr(nk), stream())
-    return order, keep, nk
+    sc = scores.detach().float()
+    if N == 0:
+        return ("empty", torch.empty(0, dtype=torch.int64, device=dev))
+    order = torch.argsort(sc, descending=True)
+    if group is None:
+        ngroups, seg = 1, torch.tensor([0, N], dtype=torch.int32, device=dev)
+        final = order
+    else:
+        gs = group[order].to(torch.int64)
+        o2 = torch.argsort(gs, stable=True)                      # (group, descending score)
+        final = order[o2]
+        seg = torch.searchsorted(gs[o2].contiguous(), torch.arange(ngroups + 1, device=dev, dtype=torch.int64)).to(torch.int32)
+    mg = N if max_group is None else min(int(max_group), N)
+    b = boxes.detach().float()[final].contiguous()
+    words = (mg + 63) // 64
+    ws = torch.empty(N * words, dtype=torch.int64, device=dev)
+    flags = torch.zeros(N, dtype=torch.uint8, device=dev)
+    call("ttdg_nms_grouped", ptr(b), ptr(seg), int(ngroups), N, mg, float(thr), ptr(ws), ptr(flags), stream())
+    keepf = flags.bool()
+    masked = torch.where(keepf, sc[final], sc.new_full((), float("-inf")))
+    k = N if topk is None else min(int(topk), N)
+    top = torch.topk(masked, k).indices                          # kept boxes first, by descending score
+    return ("grouped", final[top], keepf.sum().clamp(max=k).reshape(1).to(torch.int32))
 
 
 def nms_collect(launched):
-    """Resolve a list of nms_launch() results with ONE host synchronisation; returns the kept-index tensors."""
+    """Resolve a list of nms_launch() handles with ONE host synchronisation; returns the kept-index tensors."""
     if not launched:
         return []
-    counts = torch.cat([nk for _, _, nk in launched]).tolist()
-    return [order[keep[:c].long()] for (order, keep, _), c in zip(launched, counts)]
+    live = [h for h in launched if h[0] != "empty"]
+    counts = iter(torch.cat([h[2] for h in live]).tolist() if live else [])
+    return [h[1] if h[0] == "empty" else h[1][:next(counts)] for h in launched]
 
 
 def nms(boxes, scores, thr, group=None):
     """Greedy NMS; returns kept indices (into the input order) sorted by descending score."""
-    return nms_collect([nms_launch(boxes, scores, thr, group)])[0]
+    ng = None if group is None else int(group.max().item()) + 1 if group.numel() else 1
+    return nms_collect([nms_launch(boxes, scores, thr, group, ng)])[0]
