@@ -177,27 +177,31 @@ __device__ __forceinline__ float other_half(float v) {
   return __int_as_float((threadIdx.x & 32) ? r[0] : r[1]);
 }
 
-// Exact fp64 minimum over the wavefront on 32-bit DPP steps: doubles map to order-preserving 64-bit unsigned keys
-// (flip all bits of negatives, the sign bit of non-negatives); the minimum key is found as min(hi word), then
-// min(lo word) among the lanes that hold that hi word.  12 cheap u32 stages instead of 6 fp64 stages (each of which
-// costs two DPP moves, a canonicalising v_max_f64 and a v_min_f64).  `wide` = more than 32 participating lanes.
-__device__ __forceinline__ unsigned wave_min_u32_dpp(unsigned v, bool wide) {
-  int x = (int)v;
-#define OP(C, R) x = (int)min((unsigned)x, (unsigned)dpp_mov<C, R>(x));
-  OP(0xB1, 0xf) OP(0x4E, 0xf) OP(0x141, 0xf) OP(0x140, 0xf) OP(0x142, 0xa)
-  if (wide) { OP(0x143, 0xc) }
-#undef OP
-  return (unsigned)__builtin_amdgcn_readlane(x, wide ? 63 : 31);
-}
-__device__ __forceinline__ double wave_min_f64_keys(double v, bool wide) {
-  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-  const unsigned long long k = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-  const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
-  const unsigned hmin = wave_min_u32_dpp(hi, wide);
-  const unsigned lmin = wave_min_u32_dpp(hi == hmin ? lo : 0xffffffffu, wide);
-  const unsigned long long km = ((unsigned long long)hmin << 32) | lmin;
-  const unsigned long long bm = (km >> 63) ? (km & 0x7fffffffffffffffull) : ~km;
-  return __longlong_as_double((long long)bm);
+// Exact fp64 minimum over the wavefront, hand-scheduled: per stage one `s_nop 1` (VALU-write -> DPP-read hazard),
+// two v_mov_b32_dpp (lo/hi words; rows excluded by row_mask keep their own value) and one v_min_f64.  hipcc's own
+// lowering of the same reduction spends six instructions per stage (two plain moves and a canonicalising v_max_f64
+// on top).  `wide` = more than 32 participating lanes (otherwise the row_bcast31 stage is skipped, result in lane 31).
+#define TTDG_F64_MIN_STAGE(CTRL)                                                              \
+  {                                                                                           \
+    int lo = __double2loint(v), hi = __double2hiint(v);                                       \
+    int tlo = lo, thi = hi;                                                                   \
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %2 " CTRL "\n\tv_mov_b32_dpp %1, %3 " CTRL    \
+                 : "+v"(tlo), "+v"(thi) : "v"(lo), "v"(hi));                                  \
+    const double o = __hiloint2double(thi, tlo);                                              \
+    asm volatile("v_min_f64 %0, %1, %2" : "=v"(v) : "v"(v), "v"(o));                          \
+  }
+__device__ __forceinline__ double wave_min_f64_fast(double v, bool wide) {
+  TTDG_F64_MIN_STAGE("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+  TTDG_F64_MIN_STAGE("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+  TTDG_F64_MIN_STAGE("row_half_mirror row_mask:0xf bank_mask:0xf")
+  TTDG_F64_MIN_STAGE("row_mirror row_mask:0xf bank_mask:0xf")
+  TTDG_F64_MIN_STAGE("row_bcast:15 row_mask:0xa bank_mask:0xf")
+  if (wide) {
+    TTDG_F64_MIN_STAGE("row_bcast:31 row_mask:0xc bank_mask:0xf")
+  }
+  const int src = wide ? 63 : 31;
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
 }
 
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
@@ -224,7 +228,7 @@ __device__ __forceinline__ int lap_wave_solve_reg(int nr, int nc, const float* v
         const double r = minVal + (-(double)val[i * si + lane * sj]) - ui - v;
         if (r < spc) { path = i; spc = r; }
       }
-      const double gmin = wave_min_f64_keys(active ? spc : INFINITY, nc > 32);
+      const double gmin = wave_min_f64_fast(active ? spc : INFINITY, nc > 32);
       const bool is_min = active && spc == gmin;
       const unsigned long long minmask = __ballot(is_min);
       int jsel;
