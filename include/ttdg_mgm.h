@@ -124,6 +124,8 @@ int ttdg_gagm_solve(const float* Apack, const float* W, const float* U0, ttdg_gr
  * s (b, r, c) contiguous -> x (b, r, c) 0/1.  One wavefront per matrix, fp64 duals,
  * tie-breaking identical to scipy's rectangular LSAP. min(r,c) <= 64, max(r,c) <= 256. */
 int ttdg_lap_batched(const float* s, int b, int r, int c, float* x, ttdg_stream_t stream);
+/* benchmarking aid: 0 = compiler-lowered fp64 arg-min (default), 1 = hand-scheduled inline asm; affects ttdg_lap_batched only */
+int ttdg_debug_set_lap_variant(int v);
 
 /* ---- A8+A9 pseudo-label permutation loss (multi_graph_matching.py:535-564,
  *      utils/losses.py:83-103,419-455) ---------------------------------------------

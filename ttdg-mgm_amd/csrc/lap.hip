@@ -2,7 +2,10 @@
 // One wavefront (one 64-thread workgroup) per matrix; algorithm in lap_device.h.
 #include "lap_device.h"
 
-__global__ __launch_bounds__(64) void lap_batched_kernel(const float* __restrict__ s, int R, int C, float* __restrict__ x) {
+static int g_lap_variant = 0;   // 0 = compiler-lowered fp64 DPP min (default), 1 = hand-scheduled inline asm (A/B benchmarking only)
+extern "C" int ttdg_debug_set_lap_variant(int v) { g_lap_variant = v; return 0; }
+
+__global__ __launch_bounds__(64) void lap_batched_kernel(const float* __restrict__ s, int R, int C, float* __restrict__ x, int variant) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lap_smem[];
   const float* m = s + (size_t)blockIdx.x * R * C;
   float* o = x + (size_t)blockIdx.x * R * C;
@@ -11,7 +14,7 @@ __global__ __launch_bounds__(64) void lap_batched_kernel(const float* __restrict
   const bool tr = C < R;  // tall matrices are solved transposed (scipy does the same)
   const int nr = tr ? C : R, nc = tr ? R : C;
   if (nc <= 64) {   // register-resident solver
-    const int j = lap_wave_solve_reg(nr, nc, m, tr ? 1 : C, tr ? C : 1);
+    const int j = variant ? lap_wave_solve_reg<1>(nr, nc, m, tr ? 1 : C, tr ? C : 1) : lap_wave_solve_reg<0>(nr, nc, m, tr ? 1 : C, tr ? C : 1);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     if (lane < nr) { if (tr) o[(size_t)j * C + lane] = 1.f; else o[(size_t)lane * C + j] = 1.f; }
     return;
@@ -32,6 +35,6 @@ extern "C" int ttdg_lap_batched(const float* s, int b, int r, int c, float* x, t
   if (b == 0) return 0;
   const size_t bytes = lap_scratch_bytes(lo, hi);
   TTDG_ALLOW_LDS((lap_batched_kernel), bytes);
-  hipLaunchKernelGGL(lap_batched_kernel, dim3(b), dim3(64), bytes, (hipStream_t)stream, s, r, c, x);
+  hipLaunchKernelGGL(lap_batched_kernel, dim3(b), dim3(64), bytes, (hipStream_t)stream, s, r, c, x, g_lap_variant);
   return ttdg_launch_status("lap_batched");
 }

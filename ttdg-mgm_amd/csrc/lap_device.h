@@ -210,6 +210,9 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 }
 
 // returns this lane's assigned column (valid for lanes < nr)
+// kMinImpl: 0 = compiler-lowered fp64 DPP min (default: measured 6 % faster on MI355X, tools/bench_lap.py),
+//           1 = hand-scheduled inline-asm stages (kept for A/B runs)
+template <int kMinImpl = 0>
 __device__ __forceinline__ int lap_wave_solve_reg(int nr, int nc, const float* val, int si, int sj) {
   const int lane = threadIdx.x & 63;
   double u = 0.0, v = 0.0, spc = INFINITY;
@@ -228,7 +231,8 @@ __device__ __forceinline__ int lap_wave_solve_reg(int nr, int nc, const float* v
         const double r = minVal + (-(double)val[i * si + lane * sj]) - ui - v;
         if (r < spc) { path = i; spc = r; }
       }
-      const double gmin = wave_min_f64_fast(active ? spc : INFINITY, nc > 32);
+      const double gmin = (kMinImpl == 1) ? wave_min_f64_fast(active ? spc : INFINITY, nc > 32)
+                                           : wave_min_f64_dpp(active ? spc : INFINITY);
       const bool is_min = active && spc == gmin;
       const unsigned long long minmask = __ballot(is_min);
       int jsel;
