@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=64)
     ap.add_argument("--free-running", action="store_true", help="use the detector's own boxes instead of teacher forcing")
     ap.add_argument("--bf16-backbone", action="store_true", help="cfg-5 style: bf16 autocast for the backbone only")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (validation on a 1-GPU box)")
+    ap.add_argument("--share-device", action="store_true", help="validation only: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -63,7 +65,7 @@ def build(cfg_id, n_images, args, device, rank, world):
     batches = list(loader)
     from ttdg_mgm_amd.modeling import calibrate_frozen_bn
     calibrate_frozen_bn(model, batches[0])
-    return cfg, model, opt, batches, name
+    return cfg, model, opt, batches, name, loader.dataset_dicts
 
 
 def gpu_run(args, rank, world, device):
@@ -72,9 +74,9 @@ def gpu_run(args, rank, world, device):
     from ttdg_mgm_amd import ops
     K, W, B = args.steps, args.warmup, args.batch
     # every rank owns (K + W) batches: the sampler shards a (world * (K+W) * B)-image stream contiguously
-    cfg, model, opt, batches, name = build(2, world * (K + W) * B, args, device, rank, world)
+    cfg, model, opt, batches, name, local_dicts = build(2, world * (K + W) * B, args, device, rank, world)
     assert len(batches) >= K + W, (len(batches), K, W)
-    dice = DiceEvaluator(name, cfg.TEST.DICE_THRES)
+    dice = DiceEvaluator(name, cfg.TEST.DICE_THRES, dataset_dicts=local_dicts)
 
     def adapt(bs):
         for b in bs:
@@ -110,7 +112,7 @@ def gpu_run(args, rank, world, device):
     ops.KERNEL_TIMERS = None
     el, tta = t1 - t0, t_mid - t0
     if world > 1:
-        t = torch.tensor([el, tta], device=device, dtype=torch.float64)
+        t = torch.tensor([el, tta], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el, tta = float(t[0]), float(t[1])
     return dict(elapsed=el, tta=tta, dice=res, stamps=stamps)
@@ -171,8 +173,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl")       # RCCL; used for the barrier and the max-over-ranks timing only
+        dist.init_process_group(args.dist_backend)   # RCCL; used for the barrier and the max-over-ranks timing only
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    if args.share_device:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     import __graft_entry__

@@ -80,7 +80,7 @@ def time_steps(n_steps, batch, size, teacher_forced=True):
         for b in batches:
             tta_step(model, b, bufs, cfg)
         model.eval()
-        dice = DiceEvaluator(name, cfg.TEST.DICE_THRES)
+        dice = DiceEvaluator(name, cfg.TEST.DICE_THRES, dataset_dicts=[it["dataset_dict"] for b in batches for it in b])
         with torch.no_grad():
             for b in batches:
                 dice.process(b, model(b))

@@ -13,11 +13,16 @@ def register_synthetic(name, num_images, size=512, cfg_id=2, kind="fundus", num_
     _REGISTRY[name] = dict(n=num_images, size=size, cfg_id=cfg_id, kind=kind, num_cls=num_cls)
 
 
-def dataset_dicts(name):
-    """List of dicts: image (3,H,W) uint8, height, width, image_id, annotations [{bbox xyxy, category_id, mask bool}]."""
+def dataset_size(name):
+    return _REGISTRY[name]["n"]
+
+
+def dataset_dicts(name, start=0, stop=None):
+    """List of dicts: image (3,H,W) uint8, height, width, image_id, annotations [{bbox xyxy, category_id, mask bool}].
+    ``start``/``stop`` generate only that index range (a rank's shard): images are synthesised on demand."""
     spec = _REGISTRY[name]
     out = []
-    for i in range(spec["n"]):
+    for i in range(start, spec["n"] if stop is None else min(stop, spec["n"])):
         seed = 1000 * spec["cfg_id"] + i                       # SURVEY.md §8d
         gen = synth.fundus_image if spec["kind"] == "fundus" else synth.polyp_image
         img, boxes, classes, masks = gen(seed, spec["size"]) if spec["kind"] == "fundus" else gen(seed, spec["size"], spec["num_cls"])
@@ -43,10 +48,11 @@ def map_for_test(d, min_size=800, max_size=1333):
 class TestLoader:
     """Iterable over lists of mapped dicts; rank r sees the contiguous shard detectron2's InferenceSampler gives it."""
 
-    def __init__(self, dicts, batch, rank=0, world=1, device=None, min_size=800, max_size=1333):
-        n = len(dicts)
-        shard = (n - 1) // world + 1 if n else 0
-        self.items = [map_for_test(d, min_size, max_size) for d in dicts[shard * rank:min(shard * (rank + 1), n)]]
+    def __init__(self, name, batch, rank=0, world=1, device=None, min_size=800, max_size=1333):
+        n = dataset_size(name)
+        shard = (n - 1) // world + 1 if n else 0           # detectron2 InferenceSampler [3P]: contiguous, unpadded
+        self.dataset_dicts = dataset_dicts(name, shard * rank, min(shard * (rank + 1), n))
+        self.items = [map_for_test(d, min_size, max_size) for d in self.dataset_dicts]
         if device is not None:                                   # keep inputs resident in HBM (bench)
             for it in self.items:
                 it["image"] = it["image"].to(device)
@@ -61,5 +67,5 @@ class TestLoader:
 
 
 def build_detection_test_loader(cfg, dataset_name, rank=0, world=1, device=None):
-    return TestLoader(dataset_dicts(dataset_name), cfg.TEST.BATCH, rank, world, device,
+    return TestLoader(dataset_name, cfg.TEST.BATCH, rank, world, device,
                       cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)

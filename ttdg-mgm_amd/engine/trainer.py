@@ -81,7 +81,8 @@ class BaselineTrainer:
                 timers.setdefault("tta_s", 0.0)
                 timers["tta_s"] += time.perf_counter() - t0
             t1 = time.perf_counter()
-            dice = evaluators[idx] if evaluators is not None else DiceEvaluator(dataset_name, cfg.TEST.DICE_THRES)
+            dice = evaluators[idx] if evaluators is not None else DiceEvaluator(
+                dataset_name, cfg.TEST.DICE_THRES, dataset_dicts=data_loader.dataset_dicts)   # ground truth of the local shard
             results_i, _ = inference_on_dataset(model, data_loader, dice, cfg)
             if timers is not None:
                 torch.cuda.synchronize()
