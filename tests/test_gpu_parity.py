@@ -589,3 +589,47 @@ def test_gagm_cycle_shortcut_on_feature_derived_inputs(dev):
         assert tr["info"].cpu().tolist()[:8] == i2.cpu().tolist()[:8]
         hits += int(i2.cpu().tolist()[5] == 200)
     assert hits >= 1      # at least one case actually exercised a capped Hungarian stage
+
+
+# ------------------------------------------------------------------------------------------- cfg-3 scale (8 x 256 nodes)
+def test_cfg3_scale_front_end_and_large_solver(dev):
+    """BASELINE cfg-3 operator shapes: 8 graphs x 256 nodes.  Wds / A / U0 / V0 against the oracle on a 3-graph
+    slice the CPU finishes in seconds, then the full 8 x 256 forward+backward through the large-graph solver with
+    size-independent properties (doubly-stochastic blocks, symmetric mirror, valid partial permutations, finite grads)."""
+    from oracle import gmodule as og
+    from ttdg_mgm_amd.GModule import MGM3_unsup
+    params = synth.mgm3_params(3003)
+    U = synth.universe(3004)
+    m = MGM3_unsup(2, 32).to(dev).eval()
+    m.load_state_dict(params, strict=True)
+    nodes, labels = synth.node_sets(3000, (256, 256, 256), scale=0.1)
+    otr = {}
+    og.mgm3_unsup_forward(params, nodes, labels, U, trace=otr)
+    tr = {}
+    with torch.no_grad():
+        m([x.to(dev) for x in nodes], [l.to(dev) for l in labels], U.to(dev), trace=tr)
+    assert maxerr(tr["Wds"], otr["Wds"]) <= TOL
+    assert maxerr(tr["V0"], otr["V0"]) <= TOL * max(1.0, float(otr["V0"].abs().max()))
+    assert maxerr(tr["apack"], _pack(otr["A"], (256, 256, 256))) <= 1e-5
+    # full cfg-3 size, forward + backward
+    sizes = (256,) * 8
+    nodes, labels = synth.node_sets(3001, sizes, scale=0.1)
+    dn = [x.to(dev).requires_grad_() for x in nodes]
+    tr = {}
+    loss = m(dn, [l.to(dev) for l in labels], U.to(dev), trace=tr)
+    loss.backward()
+    W = tr["Wds"]
+    assert float(W.min()) >= 0 and float(W.max()) <= 1 + 1e-6
+    assert maxerr(W, W.t()) <= 1e-6 or True        # diagonal blocks are not symmetric; off-diagonal mirrors are checked next
+    for a in range(8):
+        for b in range(a):
+            blk = W[a * 256:(a + 1) * 256, b * 256:(b + 1) * 256]
+            assert torch.equal(blk, W[b * 256:(b + 1) * 256, a * 256:(a + 1) * 256].t())
+            assert maxerr(blk.sum(0), torch.ones(256)) <= 1e-3        # 20 sweeps end on a column normalisation
+    Ub = tr["Ub"].cpu()
+    assert set(np.unique(Ub.numpy())).issubset({0.0, 1.0})
+    for g in range(8):
+        blk = Ub[g * 256:(g + 1) * 256]
+        assert float(blk.sum()) == 32 and float(blk.sum(0).max()) <= 1 and float(blk.sum(1).max()) <= 1
+    assert torch.isfinite(loss) and all(torch.isfinite(x.grad).all() for x in dn)
+    assert all(torch.isfinite(p.grad).all() for k, p in m.named_parameters() if k.startswith("node_affinity"))

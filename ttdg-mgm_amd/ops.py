@@ -148,10 +148,84 @@ def gagm_one_step(apack, W, Ucur, gr, sizes, tau=None, quad_weight=0.5, sk_iter=
     return U, V0
 
 
+GAGM_MAX_NODES = 128      # per-graph limit of the persistent single-workgroup solver
+
+
+def gagm_solve_large(apack, W, U0, sizes, cfg):
+    """Solver for graphs beyond the persistent kernel's 128-node limit (BASELINE cfg-3: 8 x 256 nodes; the node
+    sampler itself never produces more than 95).  Same schedule as reference multi_graph_matching.py:300-389, one
+    iteration = a handful of launches of the SAME device operators (MFMA GEMMs for B = A U, S = U^T B,
+    V = (2q B S + W U)/G; batched Sinkhorn / batched LAP projectors) and one host read of the two convergence norms,
+    like the reference.  Returns (U, info, V0)."""
+    dev = W.device
+    G, M = len(sizes), sum(sizes)
+    off = [0]
+    for n in sizes:
+        off.append(off[-1] + n)
+    aoff = [0]
+    for n in sizes:
+        aoff.append(aoff[-1] + n * n)
+    U = U0.detach().clone().contiguous()
+    lastU = torch.zeros_like(U)
+    tau, hung, stage, total = float(cfg.tau0), bool(cfg.start_hungarian), 0, 0
+    iters, V0 = [], None
+    qw2, invG = 2.0 * float(cfg.quad_weight), 1.0 / G
+    B = torch.empty(M, UNIV, device=dev)
+    S = torch.empty(UNIV, UNIV, device=dev)
+    V = torch.empty(M, UNIV, device=dev)
+    equal = all(n == sizes[0] for n in sizes)
+    while True:
+        i = 0
+        for i in range(int(cfg.max_iter)):
+            lastU2, lastU = lastU, U
+            for g, n in enumerate(sizes):                                    # B_g = A_g U_g
+                gemm(apack, n, 1, U, 1, UNIV, B, UNIV, 1, n, UNIV, n, a_off=aoff[g], b_off=off[g] * UNIV, c_off=off[g] * UNIV)
+            gemm(U, 1, UNIV, B, 1, UNIV, S, UNIV, 1, UNIV, UNIV, M)          # S = U^T B
+            gemm(B, UNIV, 1, S, 1, UNIV, V, UNIV, 1, M, UNIV, UNIV, alpha=qw2 * invG)          # V = 2q/G * B S
+            gemm(W, M, 1, U, 1, UNIV, V, UNIV, 1, M, UNIV, M, alpha=invG, beta=1.0)            #   + (W U)/G
+            if V0 is None:
+                V0 = V.clone()
+            if hung:
+                U = torch.cat([lap_batched(V[off[g]:off[g + 1]].unsqueeze(0))[0] for g in range(G)], 0)
+            elif equal:
+                n = sizes[0]
+                v3 = V.view(G, n, UNIV)
+                U = (sinkhorn_batched(v3, None, None, True, tau, cfg.sk_iter) if n <= UNIV else
+                     sinkhorn_batched(v3.transpose(1, 2), None, None, True, tau, cfg.sk_iter).transpose(1, 2)).reshape(M, UNIV)
+            else:
+                nmax = max(sizes)
+                pad = torch.zeros(G, nmax, UNIV, device=dev)
+                for g, n in enumerate(sizes):
+                    pad[g, :n] = V[off[g]:off[g + 1]]
+                Up = sinkhorn_batched(pad, torch.tensor(sizes), None, True, tau, cfg.sk_iter)
+                U = torch.cat([Up[g, :n] for g, n in enumerate(sizes)], 0)
+            U = U.contiguous()
+            if G == 2:
+                U[:sizes[0]] = torch.eye(sizes[0], UNIV, device=dev)
+            total += 1
+            d = torch.stack((torch.norm(U - lastU), torch.norm(U - lastU2))).tolist()        # the reference's two syncs
+            if d[0] < float(cfg.tol) or d[1] == 0:
+                break
+        iters.append(i + 1)
+        stage += 1
+        if hung or (cfg.max_stages > 0 and stage >= cfg.max_stages):
+            break
+        if tau > float(cfg.min_tau):
+            tau *= float(cfg.gamma)
+        else:
+            hung = True
+    info = torch.zeros(16, dtype=torch.int32)
+    info[:len(iters)] = torch.tensor(iters, dtype=torch.int32)
+    info[6], info[7] = total, stage
+    return U, info.to(dev), V0
+
+
 def gagm_solve(apack, W, U0, gr, sizes, cfg=None):
     """Returns (U (M,32) 0/1, info int32[16] on device, V0 (M,32) first-iteration V)."""
     M = sum(sizes)
     cfg = cfg or gagm_cfg()
+    if max(sizes) > GAGM_MAX_NODES:
+        return gagm_solve_large(apack, W, U0, list(sizes), cfg)
     nbytes = _lib.load().ttdg_gagm_workspace_bytes(M)
     ws = torch.empty(nbytes // 4, device=W.device, dtype=torch.float32)
     U = torch.empty(M, UNIV, device=W.device, dtype=torch.float32)
