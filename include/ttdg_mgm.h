@@ -67,9 +67,11 @@ int ttdg_affinity_pairwise_fwd(const float* P, const float* Q, const float* w2, 
                                int ksplit, float* part, ttdg_stream_t stream);
 /* bwd: given dM (M x M, read only where g(i) > g(j)):
  *      dP[i,k] = w2[k] * sum_j dM[i,j] [P[i,k]+Q[j,k] > 0],  dQ[j,k] likewise over i,
- *      dw2[k]  = sum_i P[i,k] S[i,k] + sum_j Q[j,k] R[j,k]  (S,R = the unscaled sums), db2 = sum dM. */
+ *      dw2[k]  = sum_i P[i,k] S[i,k] + sum_j Q[j,k] R[j,k]  (S,R = the unscaled sums), db2 = sum dM.
+ *      ws: ttdg_affinity_bwd_workspace_bytes(M,H) bytes (partial planes of the range-split reduction). */
+size_t ttdg_affinity_bwd_workspace_bytes(int M, int H);
 int ttdg_affinity_pairwise_bwd(const float* P, const float* Q, const float* w2, const float* dM, int H,
-                               ttdg_graphs_t gr, float* dP, float* dQ, float* dw2, float* db2,
+                               ttdg_graphs_t gr, float* dP, float* dQ, float* dw2, float* db2, void* ws,
                                ttdg_stream_t stream);
 
 /* ---- A5 log-space Sinkhorn, pair stage (utils/sinkhorn.py:85-87 -> pygmtools [3P];

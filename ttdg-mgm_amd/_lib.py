@@ -52,7 +52,8 @@ SIGNATURES = {
     "ttdg_gemm_f32": (C.c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _F, _F, _S]),
     "ttdg_colsum_f32": (C.c_int, [_P, _L, _P, _I, _I, _S]),
     "ttdg_affinity_pairwise_fwd": (C.c_int, [_P, _P, _P, _I, Graphs, _I, _P, _S]),
-    "ttdg_affinity_pairwise_bwd": (C.c_int, [_P, _P, _P, _P, _I, Graphs, _P, _P, _P, _P, _S]),
+    "ttdg_affinity_bwd_workspace_bytes": (C.c_size_t, [_I, _I]),
+    "ttdg_affinity_pairwise_bwd": (C.c_int, [_P, _P, _P, _P, _I, Graphs, _P, _P, _P, _P, _P, _S]),
     "ttdg_sinkhorn_pairs_fwd": (C.c_int, [_P, _I, _P, Graphs, _F, _I, _P, _P, _S]),
     "ttdg_sinkhorn_pairs_bwd": (C.c_int, [_P, _I, _P, _P, _P, Graphs, _F, _I, _P, _S]),
     "ttdg_sinkhorn_batched_fwd": (C.c_int, [_P, _L, _L, _L, _I, _I, _I, _P, _P, _I, _F, _I, _P, _S]),

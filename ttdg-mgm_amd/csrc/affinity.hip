@@ -114,8 +114,9 @@ extern "C" int ttdg_affinity_pairwise_fwd(const float* P, const float* Q, const 
 template <bool kRowsAreSrc>
 __global__ __launch_bounds__(256) void affinity_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Y,
                                                            const float* __restrict__ dM, int H, ttdg_graphs_t gr,
-                                                           float* __restrict__ O) {
+                                                           float* __restrict__ Opart) {
   const int M = gr.off[gr.G];
+  float* O = Opart + (size_t)blockIdx.z * M * H;       // partial plane of this slice of the reduced range
   const int r0 = blockIdx.y * TILE, k0 = blockIdx.x * TILE;
   __shared__ __attribute__((aligned(16))) float Dt[BC][LDR];
   __shared__ __attribute__((aligned(16))) float Ys[BC][LDR];
@@ -138,6 +139,13 @@ __global__ __launch_bounds__(256) void affinity_bwd_kernel(const float* __restri
     const int rl = min(r0 + TILE, M) - 1;
     if (kRowsAreSrc) { cbeg = 0; cend = gr.off[graph_of(gr, rl)]; }
     else { cbeg = gr.off[graph_of(gr, r0) + 1]; cend = M; }
+    // split the reduced range over gridDim.z in multiples of the slab size: more workgroups per CU (latency hiding)
+    // and an even load although the wanted blocks are block-triangular
+    const int nslab = (cend - cbeg + BC - 1) / BC;
+    const int per = (nslab + gridDim.z - 1) / gridDim.z;
+    const int b0 = cbeg + blockIdx.z * per * BC;
+    cend = min(cend, b0 + per * BC);
+    cbeg = b0;
   }
 
   float x[4][4], acc[4][4];
@@ -217,61 +225,95 @@ __global__ __launch_bounds__(256) void affinity_bwd_kernel(const float* __restri
   }
 }
 
-// finish: dw2[k] = sum_i P S + sum_j Q R (unscaled sums), then scale S,R by w2 in place -> dP,dQ.
-// One wavefront per 64 k-columns slice x 4 row groups; deterministic tree over rows.
+// finish, stage 1: S = sum of the partial planes; dP = w2 * S, dQ = w2 * R; per 64-row chunk the partial column sums
+// of P*S + Q*R (-> dw2) and of dM over the wanted blocks (-> db2).  Grid (H/64, ceil(M/64)).
 __global__ __launch_bounds__(256) void affinity_bwd_finish_kernel(const float* __restrict__ P, const float* __restrict__ Q,
-                                                                  const float* __restrict__ w2, int H, int M,
-                                                                  float* __restrict__ S, float* __restrict__ R,
-                                                                  float* __restrict__ dw2) {
+                                                                  const float* __restrict__ w2, const float* __restrict__ dM,
+                                                                  int H, ttdg_graphs_t gr, int nsplit,
+                                                                  const float* __restrict__ Spart, const float* __restrict__ Rpart,
+                                                                  float* __restrict__ dP, float* __restrict__ dQ,
+                                                                  float* __restrict__ dw2part, float* __restrict__ db2part) {
   __shared__ float red[4][64];
+  const int M = gr.off[gr.G];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + lane;
+  const int m0 = blockIdx.y * 64, m1 = min(M, m0 + 64);
   const float w = w2[k];
+  const size_t plane = (size_t)M * H;
   float s = 0.f;
-  for (int m = wave; m < M; m += 4) {
+  for (int m = m0 + wave; m < m1; m += 4) {
     const size_t o = (size_t)m * H + k;
-    const float sv = S[o], rv = R[o];
+    float sv = 0.f, rv = 0.f;
+    for (int z = 0; z < nsplit; ++z) { sv += Spart[z * plane + o]; rv += Rpart[z * plane + o]; }
     s += P[o] * sv + Q[o] * rv;
-    S[o] = sv * w;
-    R[o] = rv * w;
+    dP[o] = sv * w;
+    dQ[o] = rv * w;
   }
   red[wave][lane] = s;
   __syncthreads();
-  if (wave == 0) dw2[k] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (wave == 0) dw2part[(size_t)blockIdx.y * H + k] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (blockIdx.x == 0) {   // db2 partial of this row chunk: sum of dM[i, j < off[graph(i)]]
+    __syncthreads();
+    float t = 0.f;
+    for (int m = m0 + wave; m < m1; m += 4) {
+      const int lim = gr.off[graph_of(gr, m)];
+      for (int j = lane; j < lim; j += 64) t += dM[(size_t)m * M + j];
+    }
+    t = wave_sum(t);
+    if (lane == 0) red[wave][0] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) db2part[blockIdx.y] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+  }
 }
 
-// db2 = sum of dM over the blocks with graph(i) > graph(j); one workgroup, fixed summation order.
-__global__ __launch_bounds__(1024) void affinity_db2_kernel(const float* __restrict__ dM, ttdg_graphs_t gr,
-                                                            float* __restrict__ db2) {
-  const int M = gr.off[gr.G];
-  __shared__ float red[16];
-  float s = 0.f;
-  for (int i = gr.off[1] + (threadIdx.x >> 6); i < M; i += 16) {
-    const int lim = gr.off[graph_of(gr, i)];
-    for (int j = threadIdx.x & 63; j < lim; j += 64) s += dM[(size_t)i * M + j];
+// finish, stage 2: fixed-order sums over the row chunks
+__global__ __launch_bounds__(64) void affinity_bwd_reduce_kernel(const float* __restrict__ dw2part, const float* __restrict__ db2part,
+                                                                 int H, int nchunk, float* __restrict__ dw2, float* __restrict__ db2) {
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (k < H) {
+    float s = 0.f;
+    for (int c = 0; c < nchunk; ++c) s += dw2part[(size_t)c * H + k];
+    dw2[k] = s;
   }
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     float t = 0.f;
-    for (int w = 0; w < 16; ++w) t += red[w];
+    for (int c = 0; c < nchunk; ++c) t += db2part[c];
     *db2 = t;
   }
 }
 
+static int affinity_bwd_nsplit(int M, int H) {
+  const int base = (H / TILE) * ((M + TILE - 1) / TILE);
+  int ns = (2048 + base - 1) / base;                 // aim at ~8 workgroups per CU
+  const int maxs = (M + BC - 1) / BC;                // at least one slab per slice
+  if (ns > maxs) ns = maxs;
+  if (ns > 16) ns = 16;
+  return ns < 1 ? 1 : ns;
+}
+
+extern "C" size_t ttdg_affinity_bwd_workspace_bytes(int M, int H) {
+  const int ns = affinity_bwd_nsplit(M, H), nchunk = (M + 63) / 64;
+  return ((size_t)2 * ns * M * H + (size_t)nchunk * H + nchunk + 16) * sizeof(float);
+}
+
 extern "C" int ttdg_affinity_pairwise_bwd(const float* P, const float* Q, const float* w2, const float* dM, int H,
-                                          ttdg_graphs_t gr, float* dP, float* dQ, float* dw2, float* db2,
+                                          ttdg_graphs_t gr, float* dP, float* dQ, float* dw2, float* db2, void* ws,
                                           ttdg_stream_t stream) {
-  TTDG_REQUIRE(P && Q && w2 && dM && dP && dQ && dw2 && db2, "affinity_bwd: null pointer");
+  TTDG_REQUIRE(P && Q && w2 && dM && dP && dQ && dw2 && db2 && ws, "affinity_bwd: null pointer");
   if (int e = ttdg_validate_graphs(gr)) return e;
   TTDG_REQUIRE(H % TILE == 0, "affinity_bwd: H must be a multiple of 64");
   const int M = gr.off[gr.G];
+  const int ns = affinity_bwd_nsplit(M, H), nchunk = (M + 63) / 64;
+  float* Spart = (float*)ws;
+  float* Rpart = Spart + (size_t)ns * M * H;
+  float* dw2part = Rpart + (size_t)ns * M * H;
+  float* db2part = dw2part + (size_t)nchunk * H;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(H / TILE, (M + TILE - 1) / TILE);
-  hipLaunchKernelGGL((affinity_bwd_kernel<true>), grid, dim3(256), 0, st, P, Q, dM, H, gr, dP);
-  hipLaunchKernelGGL((affinity_bwd_kernel<false>), grid, dim3(256), 0, st, Q, P, dM, H, gr, dQ);
-  hipLaunchKernelGGL(affinity_bwd_finish_kernel, dim3(H / 64), dim3(256), 0, st, P, Q, w2, H, M, dP, dQ, dw2);
-  hipLaunchKernelGGL(affinity_db2_kernel, dim3(1), dim3(1024), 0, st, dM, gr, db2);
+  dim3 grid(H / TILE, (M + TILE - 1) / TILE, ns);
+  hipLaunchKernelGGL((affinity_bwd_kernel<true>), grid, dim3(256), 0, st, P, Q, dM, H, gr, Spart);
+  hipLaunchKernelGGL((affinity_bwd_kernel<false>), grid, dim3(256), 0, st, Q, P, dM, H, gr, Rpart);
+  hipLaunchKernelGGL(affinity_bwd_finish_kernel, dim3(H / 64, nchunk), dim3(256), 0, st, P, Q, w2, dM, H, gr, ns, Spart, Rpart,
+                     dP, dQ, dw2part, db2part);
+  hipLaunchKernelGGL(affinity_bwd_reduce_kernel, dim3((H + 63) / 64), dim3(64), 0, st, dw2part, db2part, H, nchunk, dw2, db2);
   return ttdg_launch_status("affinity_bwd");
 }

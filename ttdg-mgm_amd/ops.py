@@ -71,7 +71,7 @@ def pick_ksplit(M, H=HID):
     nt = (M + 63) // 64
     tiles = nt * (nt + 1) // 2
     ks = 1
-    while ks < 16 and tiles * ks < 256 and H % (ks * 2 * 32) == 0:
+    while ks < 16 and tiles * ks < 1024 and H % (ks * 2 * 32) == 0:      # ~4 workgroups per CU
         ks *= 2
     return ks
 
@@ -87,8 +87,9 @@ def affinity_pairwise_bwd(P, Q, w2, dM, gr):
     dP, dQ = torch.empty_like(P), torch.empty_like(Q)
     dw2 = torch.empty(P.shape[1], device=P.device, dtype=torch.float32)
     db2 = torch.empty(1, device=P.device, dtype=torch.float32)
+    ws = torch.empty(_lib.load().ttdg_affinity_bwd_workspace_bytes(P.shape[0], P.shape[1]) // 4 + 1, device=P.device, dtype=torch.float32)
     call("ttdg_affinity_pairwise_bwd", ptr(P), ptr(Q), ptr(w2), ptr(dM), P.shape[1], gr, ptr(dP), ptr(dQ), ptr(dw2),
-         ptr(db2), stream())
+         ptr(db2), ptr(ws), stream())
     return dP, dQ, dw2, db2
 
 
