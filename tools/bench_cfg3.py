@@ -31,7 +31,7 @@ out = {}
 pairs_ge = G * (G + 1) // 2
 pairs_gt = G * (G - 1) // 2
 # affinity forward: 4 FLOP per (i,j,k) (4 h n_i n_j), 3 VALU lane-ops
-ks = ops.pick_ksplit(M)
+ks = ops.pick_ksplit(M, H, n)
 t, part = timed(lambda: ops.affinity_pairwise_fwd(P, Q, w2, gr, ks))
 fl = 4.0 * H * pairs_ge * n * n
 out["affinity_fwd"] = dict(ms=t * 1e3, tflops=fl / t / 1e12, frac_fp32_peak=fl / t / 157.3e12,

@@ -66,8 +66,11 @@ class LinearFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------- pieces
-def pick_ksplit(M, H=HID):
-    """Split K so that the pairwise kernel launches >= ~256 workgroups (one per CU) on small batches."""
+def pick_ksplit(M, H=HID, nmax=0):
+    """Split K so that the pairwise kernel launches ~4 workgroups per CU on small batches.  When a graph is too large
+    for the LDS-resident pair Sinkhorn (> 190 nodes) the partial planes would be re-summed on every sweep: keep 1."""
+    if nmax > 190:
+        return 1
     nt = (M + 63) // 64
     tiles = nt * (nt + 1) // 2
     ks = 1
@@ -285,7 +288,7 @@ class MatchingLossFn(torch.autograd.Function):
         P = linear_raw(Xs, W1, None, 0, HID)
         Q = linear_raw(Xt, W1, b1, DIM, HID)
         w2f = w2.reshape(-1)
-        ks = opts.get("ksplit") or pick_ksplit(M)
+        ks = opts.get("ksplit") or pick_ksplit(M, HID, max(sizes))
         part = affinity_pairwise_fwd(P, Q, w2f, gr, ks)
         tau, iters = opts.get("pair_tau", 0.05), opts.get("pair_iters", 20)
         Wds, pot = sinkhorn_pairs_fwd(part, b2, gr, sizes, tau, iters)
