@@ -128,6 +128,13 @@ class MGM3_unsup(nn.Module):
         sizes = [len(l) for l in labels]
         if sizes != [int(x.shape[0]) for x in nodes]:
             raise ValueError("nodes and labels disagree on the graph sizes")
+        if 0 in sizes:
+            # a detection too small to contain any FPN point yields an empty graph; the reference's loops are
+            # undefined there (0-row Sinkhorn / LAP).  Documented deviation: such graphs take no part in the matching.
+            keep = [g for g, n in enumerate(sizes) if n > 0]
+            nodes, labels, sizes = [nodes[g] for g in keep], [labels[g] for g in keep], [sizes[g] for g in keep]
+            if len(sizes) < 2:
+                return None
         if trace is None and self.keep_trace:
             trace = {}
         X = torch.cat(list(nodes), dim=0).float().contiguous()

@@ -558,3 +558,49 @@ extern "C" int ttdg_gagm_solve(const float* Apack, const float* W, const float* 
 #undef GA_LAUNCH
   return ttdg_launch_status("gagm");
 }
+
+
+// ---- micro-benchmark hook: `reps` back-to-back projections of G graphs of n nodes, one wavefront per graph, from an
+// LDS-resident V exactly as inside gagm_kernel (tools/bench_gagm_parts.py).  mode 0 = Sinkhorn, 1 = LAP.
+__global__ __launch_bounds__(512) void debug_project_kernel(const float* __restrict__ Vg, int n, int G, float scale, int iters,
+                                                            int reps, int mode, float* __restrict__ Ug, long long* __restrict__ ticks) {
+  extern __shared__ __attribute__((aligned(16))) float dbg_smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* V = dbg_smem;                       // G*n*32
+  float* U = V + G * n * NU;
+  float* wex = U + G * n * NU;               // per wave 40 + 64
+  for (int e = threadIdx.x; e < G * n * NU; e += blockDim.x) V[e] = Vg[e];
+  __syncthreads();
+  const long long t0 = (long long)__builtin_readcyclecounter();
+  if (wave < G) {
+    const float* Vb = V + wave * n * NU;
+    float* Ub = U + wave * n * NU;
+    float* fbuf = wex + wave * 104;
+    for (int r = 0; r < reps; ++r) {
+      if (mode == 0) sk_wave_project<1>(Vb, n, scale, iters, Ub, fbuf, fbuf + 40);
+      else {
+        const bool tr = n > NU;
+        const int nr = tr ? NU : n, nc = tr ? n : NU;
+        for (int e = lane; e < n * NU; e += 64) Ub[e] = 0.f;
+        const int b = lap_wave_solve_reg(nr, nc, Vb, tr ? 1 : NU, tr ? NU : 1);
+        wave_sync();
+        if (lane < nr) { if (tr) Ub[b * NU + lane] = 1.f; else Ub[lane * NU + b] = 1.f; }
+      }
+      wave_sync();
+    }
+  }
+  __syncthreads();
+  const long long t1 = (long long)__builtin_readcyclecounter();
+  if (threadIdx.x == 0) ticks[0] = t1 - t0;
+  for (int e = threadIdx.x; e < G * n * NU; e += blockDim.x) Ug[e] = U[e];
+}
+
+extern "C" int ttdg_debug_project(const float* V, int n, int G, float tau, int iters, int reps, int mode, float* U,
+                                  long long* ticks, ttdg_stream_t stream) {
+  TTDG_REQUIRE(V && U && ticks && n >= 1 && n <= 64 && G >= 1 && G <= 8, "debug_project: bad arguments");
+  const size_t bytes = ((size_t)2 * G * n * NU + 8 * 104) * sizeof(float);
+  TTDG_ALLOW_LDS(debug_project_kernel, bytes);
+  hipLaunchKernelGGL(debug_project_kernel, dim3(1), dim3(512), bytes, (hipStream_t)stream, V, n, G, TTDG_LOG2E / tau, iters, reps,
+                     mode, U, ticks);
+  return ttdg_launch_status("debug_project");
+}

@@ -19,7 +19,9 @@ class FusedSGD(torch.optim.Optimizer):
         if momentum <= 0:
             raise ValueError("FusedSGD implements SGD with momentum (the TTA configuration)")
         super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
-        self._pinned = None
+        self._pinned = [None, None]       # two staging buffers: a buffer is rewritten only after its H2D copy completed
+        self._copied = [None, None]
+        self._flip = 0
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -58,9 +60,13 @@ class FusedSGD(torch.optim.Optimizer):
         nc = len(chunks_t)
         tbytes = C.sizeof(_lib.SgdTensor) * nt
         total = tbytes + 4 * nc + 8 * nc + 64
-        if self._pinned is None or self._pinned.numel() < total:
-            self._pinned = torch.empty(total * 2, dtype=torch.uint8).pin_memory()
-        host = self._pinned
+        slot = self._flip
+        self._flip ^= 1
+        if self._copied[slot] is not None:
+            self._copied[slot].synchronize()
+        if self._pinned[slot] is None or self._pinned[slot].numel() < total:
+            self._pinned[slot] = torch.empty(total * 2, dtype=torch.uint8).pin_memory()
+        host = self._pinned[slot]
         table = (_lib.SgdTensor * nt).from_address(host.data_ptr())
         for ti, (p, g, b, wd, first) in enumerate(todo):
             table[ti].p, table[ti].g, table[ti].buf = ptr(p), ptr(g), ptr(b)
@@ -70,6 +76,9 @@ class FusedSGD(torch.optim.Optimizer):
         (C.c_int64 * nc).from_address(host.data_ptr() + o_off)[:] = chunks_o
         (C.c_int32 * nc).from_address(host.data_ptr() + t_off)[:] = chunks_t
         devbuf = host[:t_off + 4 * nc].to(dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._copied[slot] = ev
         base = devbuf.data_ptr()
         call("ttdg_sgd_multi_tensor", base, base + t_off, base + o_off, nc, CHUNK, float(lr), float(mom), stream())
         self._keepalive = (devbuf, [t[1] for t in todo])
