@@ -134,6 +134,89 @@ __device__ __forceinline__ void sk_wave_project(const float* Vb, int n, float sc
   }
 }
 
+// ---- narrow projection: n <= 32 nodes (the common case: the sampler yields ~20-35 nodes per image) -------------------
+// 32 x 32 problem after dummy rows; every lane owns 16 entries in BOTH layouts (row = lane & 31, half = lane >> 5), the
+// dummy row lives in the free row slot n (its column-layout copy carries +log2(multiplicity)), so both sweeps are the
+// same 16-element loop with no special cases.  A single wavefront issues ~1 instruction per 4-5 cycles, so the loop is
+// written for instruction count: packed fp32 subtracts/adds, and NO max pass - after any sweep y = L - f - g <= 0, so
+// the previous potential is a valid stabiliser (exp2 arguments <= 0, sums in (0, 32]); the exact two-pass form is used
+// for the first sweep and whenever a sum underflows (< 2^-60).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float sk_line_exact(const f32x2 (&t)[8], bool used) {
+  float m = NEG_BIG;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) m = fmaxf(m, fmaxf(t[k].x, t[k].y));
+  m = fmaxf(m, other_half(m));
+  const float ms = used ? m : 0.f;
+  f32x2 acc = {0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { const f32x2 a = t[k] - ms; acc += (f32x2){fast_exp2(a.x), fast_exp2(a.y)}; }
+  float s = acc.x + acc.y;
+  s += other_half(s);
+  return used ? ms + fast_log2(s) : 0.f;
+}
+
+__device__ __forceinline__ void sk_wave_project_narrow(const float* Vb, int n, float scale, int iters, float* Ub, float* fbuf,
+                                                       float* gbuf) {
+  const int lane = threadIdx.x & 63, lo = lane & 31, hi = lane >> 5;
+  const int mult = NU - n;
+  const float D = -100.0f * TTDG_LOG2E;
+  const int nrow = n + (mult > 0 ? 1 : 0);
+  const bool row_used = lo < nrow;
+  f32x2 Lr[8], Lc[8];
+  const float dcol = (mult > 0) ? D + fast_log2((float)mult) : NEG_BIG;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int q = hi * 16 + k;                                  // row layout: row lo, column q
+    const float vr = (lo < n) ? Vb[lo * NU + q] * scale : ((lo == n && mult > 0) ? D : NEG_BIG);
+    const int p = hi * 16 + k;                                  // column layout: column lo, row p
+    const float vc = (p < n) ? Vb[p * NU + lo] * scale : (p == n ? dcol : NEG_BIG);
+    if (k & 1) { Lr[k >> 1].y = vr; Lc[k >> 1].y = vc; } else { Lr[k >> 1].x = vr; Lc[k >> 1].x = vc; }
+  }
+  if (lane < 32) { fbuf[lane] = 0.f; gbuf[lane] = 0.f; }
+  float fown = 0.f, gown = 0.f;
+  wave_sync();
+  for (int it = 0; it < iters; ++it) {
+    const bool rows = (it & 1) == 0;
+    const float* pot = (rows ? gbuf : fbuf) + hi * 16;          // the OTHER side's potentials for my 16 entries
+    f32x2 t[8];
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      const float4 p4 = *reinterpret_cast<const float4*>(pot + 2 * k);
+      t[k] = (rows ? Lr[k] : Lc[k]) - (f32x2){p4.x, p4.y};
+      t[k + 1] = (rows ? Lr[k + 1] : Lc[k + 1]) - (f32x2){p4.z, p4.w};
+    }
+    const bool used = rows ? row_used : true;
+    const float own = rows ? fown : gown;
+    float fresh;
+    bool exact = (it == 0);
+    if (!exact) {
+      f32x2 acc = {0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const f32x2 a = t[k] - own; acc += (f32x2){fast_exp2(a.x), fast_exp2(a.y)}; }
+      float sm = acc.x + acc.y;
+      sm += other_half(sm);
+      fresh = used ? own + fast_log2(sm) : 0.f;
+      exact = __ballot(used && !(sm >= 8.6736174e-19f && sm <= 1.0e6f)) != 0ull;      // 2^-60: underflow guard
+    }
+    if (exact) fresh = sk_line_exact(t, used);
+    if (rows) { fown = fresh; if (hi == 0) fbuf[lo] = fresh; }
+    else      { gown = fresh; if (hi == 0) gbuf[lo] = fresh; }
+    wave_sync();
+  }
+  // U[p][lo] = exp(L - f_p - g_lo) from the column layout (conflict-free stores); the dummy slot is not stored
+  {
+    const float* fp = fbuf + hi * 16;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int p = hi * 16 + k;
+      const float l = (k & 1) ? Lc[k >> 1].y : Lc[k >> 1].x;
+      if (p < n) Ub[p * NU + lo] = fast_exp2(l - fp[k] - gown);
+    }
+  }
+}
+
 template <int GA_WAVES>
 __device__ __forceinline__ float block_sum2(float a, float b, float* red, float& outb) {
   a = wave_sum_f32_dpp(a);
@@ -366,7 +449,8 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
           float* fbuf = wex + wave * wex_stride;
           float* gbuf = fbuf + 40;
           const float scale = TTDG_LOG2E / tau;
-          if (CWMAX == 1 || n <= 64) sk_wave_project<1>(Vb, n, scale, cfg.sk_iter, Ub, fbuf, gbuf);
+          if (n <= NU) sk_wave_project_narrow(Vb, n, scale, cfg.sk_iter, Ub, fbuf, gbuf);
+          else if (CWMAX == 1 || n <= 64) sk_wave_project<1>(Vb, n, scale, cfg.sk_iter, Ub, fbuf, gbuf);
           else sk_wave_project<CWMAX>(Vb, n, scale, cfg.sk_iter, Ub, fbuf, gbuf);
         } else {
           const bool tr = n > NU;
@@ -577,7 +661,7 @@ __global__ __launch_bounds__(512) void debug_project_kernel(const float* __restr
     float* Ub = U + wave * n * NU;
     float* fbuf = wex + wave * 104;
     for (int r = 0; r < reps; ++r) {
-      if (mode == 0) sk_wave_project<1>(Vb, n, scale, iters, Ub, fbuf, fbuf + 40);
+      if (mode == 0) { if (n <= NU) sk_wave_project_narrow(Vb, n, scale, iters, Ub, fbuf, fbuf + 40); else sk_wave_project<1>(Vb, n, scale, iters, Ub, fbuf, fbuf + 40); }
       else {
         const bool tr = n > NU;
         const int nr = tr ? NU : n, nc = tr ? n : NU;
