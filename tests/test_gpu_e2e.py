@@ -78,9 +78,11 @@ def test_tta_step_updates_exactly_the_reference_parameter_set(setup):
     assert all(k.startswith(("backbone.bottom_up.res3", "backbone.bottom_up.res4", "backbone.bottom_up.res5", "backbone.fpn_",
                              "multi_matching_unsup.node_affinity.")) for k in changed), sorted(changed)[:5]
     assert any(k.startswith("backbone.bottom_up.res3") for k in changed) and any(k.startswith("backbone.fpn_lateral") for k in changed)
-    assert {k for k in changed if k.startswith("multi_matching_unsup")} == {
-        "multi_matching_unsup.node_affinity." + s for s in ("fc_M.0.weight", "fc_M.0.bias", "fc_M.2.weight", "fc_M.2.bias",
-                                                             "project_sr.weight", "project_tg.weight")}
+    # fc_M.2.bias (b2) is optional: Sinkhorn is invariant to a constant shift of the affinities, so d loss / d b2 is
+    # rounding noise around 0 (starting from b2 = 0 the update may be exactly nothing)
+    moved = {k for k in changed if k.startswith("multi_matching_unsup")} - {"multi_matching_unsup.node_affinity.fc_M.2.bias"}
+    assert moved == {"multi_matching_unsup.node_affinity." + s for s in ("fc_M.0.weight", "fc_M.0.bias", "fc_M.2.weight",
+                                                                        "project_sr.weight", "project_tg.weight")}
     assert torch.isfinite(torch.stack([v.detach().abs().max() for v in gpu.parameters()])).all()
 
 
