@@ -200,6 +200,13 @@ def main():
             "tta_only_images_per_s": images / run["tta"], "dice": run["dice"],
         }
         out["roofline"] = roofline_from_stamps(run, K)
+        sgd = [(a.elapsed_time(b) * 1e-3, nb) for nm, a, b, nb, _ in run["stamps"] if nm == "sgd"]
+        if sgd:   # second hand-written kernel with a meaningful hardware bound: the fused SGD step streams 20 B/parameter
+            t, nb = sum(x[0] for x in sgd), sum(x[1] for x in sgd)
+            out["roofline_other_kernels"] = [{"kernel": "sgd_multi_tensor_kernel", "bound": "hbm", "achieved": nb / t / 1e9,
+                                              "peak": 8000.0, "unit": "GB/s", "frac": nb / t / 8e12, "traffic": None,
+                                              "launches": len(sgd), "avg_launch_ms": t / len(sgd) * 1e3,
+                                              "bytes_per_launch": nb / len(sgd)}]
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args)

@@ -80,6 +80,15 @@ class FusedSGD(torch.optim.Optimizer):
         ev.record()
         self._copied[slot] = ev
         base = devbuf.data_ptr()
+        from . import ops
+        timers = ops.KERNEL_TIMERS
+        if timers is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         call("ttdg_sgd_multi_tensor", base, base + t_off, base + o_off, nc, CHUNK, float(lr), float(mom), stream())
+        if timers is not None:
+            e1.record()
+            nbytes = sum(p.numel() * 4 * (4 if first else 5) for p, _, _, _, first in todo)   # p r/w, g r, buf (r)/w
+            timers.append(("sgd", e0, e1, nbytes, None))
         self._keepalive = (devbuf, [t[1] for t in todo])
         return None
