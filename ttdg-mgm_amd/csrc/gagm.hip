@@ -24,9 +24,10 @@
 // V block: Vb[node*32 + univ], n nodes.  Oriented problem: r = min(n,32) rows, c = max(n,32) columns,
 // (c - r) dummy rows.  CW = ceil(c / 64) columns per lane.
 template <int CW>
-__device__ __forceinline__ void sk_wave_project(const float* Vb, int n, float scale, int iters, float* Ub, float* fbuf, float* gbuf) {
+__device__ __forceinline__ void sk_wave_project(const float* Vb, int n, float scale, int iters, float* Ub, float* fbuf, float* gbuf,
+                                                bool square_tr = false) {
   const int lane = threadIdx.x & 63;
-  const bool tr = n > NU;            // rows = universe, cols = nodes
+  const bool tr = n > NU || square_tr;   // rows = universe, cols = nodes (square_tr: a 32-node block kept transposed, see gagm_kernel)
   const int r = tr ? NU : n, c = tr ? n : NU, mult = c - r;
   const float D = -100.0f * TTDG_LOG2E;
   // column layout: lane owns columns q = lane + 64*w; Lc[w][p]
@@ -310,8 +311,12 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
   const int MU = M * NU;
   const int Mp = (M + 31) & ~31;
   const int SB = NU * (Mp + 1);              // one state buffer: M x 32 row-major, or 32 x (Mp+1) for B^T
-  int asz = 0;
-  for (int g = 0; g < G; ++g) { const int n = gr.off[g + 1] - gr.off[g]; asz += n * n; }
+  int asz = 0, nmax = 0, nmin = 1 << 30;
+  for (int g = 0; g < G; ++g) { const int n = gr.off[g + 1] - gr.off[g]; asz += n * n; nmax = max(nmax, n); nmin = min(nmin, n); }
+  // Sinkhorn orientation of a 32-node block: in a batch of unequal sizes whose largest
+  // graph exceeds the universe the whole padded batch is transposed and only blocks with n_g < 32 are transposed back,
+  // so an exactly-32-node block keeps rows = universe; with equal sizes (or no graph above 32) rows = nodes
+  const bool sq_tr = (nmax > NU) && (nmin != nmax);
   // workspace (global): [V0 snapshot MU][first projected U, MU][W^T: M x Mp][state 4*SB when !kLds]
   float* V0snap = ws;
   float* U1snap = ws + MU;
@@ -449,8 +454,8 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
           float* fbuf = wex + wave * wex_stride;
           float* gbuf = fbuf + 40;
           const float scale = TTDG_LOG2E / tau;
-          if (n <= NU) sk_wave_project_narrow(Vb, n, scale, cfg.sk_iter, Ub, fbuf, gbuf);
-          else if (CWMAX == 1 || n <= 64) sk_wave_project<1>(Vb, n, scale, cfg.sk_iter, Ub, fbuf, gbuf);
+          if (n < NU || (n == NU && !sq_tr)) sk_wave_project_narrow(Vb, n, scale, cfg.sk_iter, Ub, fbuf, gbuf);
+          else if (CWMAX == 1 || n <= 64) sk_wave_project<1>(Vb, n, scale, cfg.sk_iter, Ub, fbuf, gbuf, n == NU);
           else sk_wave_project<CWMAX>(Vb, n, scale, cfg.sk_iter, Ub, fbuf, gbuf);
         } else {
           const bool tr = n > NU;
@@ -592,10 +597,15 @@ static size_t ga_fixed_lds_bytes(int cmaxp, int GA_WAVES, int cwmax, int M) {
 
 static inline int ga_mp(int M) { return (M + 31) & ~31; }
 
+// gagm_large.hip
+size_t ttdg_gagm_large_ws_bound(int M);
+int ttdg_gagm_large_solve(const float* Apack, const float* W, const float* U0, ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg,
+                          float* U, int32_t* info, void* ws, hipStream_t st);
+
 extern "C" size_t ttdg_gagm_workspace_bytes(int M) {
-  const int Mp = ga_mp(M);
-  (void)Mp;
-  return ga_ws_hist_off(M) * sizeof(float) + (size_t)GA_HIST * M + 64;
+  const size_t small = ga_ws_hist_off(M) * sizeof(float) + (size_t)GA_HIST * M + 64;
+  const size_t large = ttdg_gagm_large_ws_bound(M);
+  return small > large ? small : large;
 }
 
 extern "C" int ttdg_gagm_solve(const float* Apack, const float* W, const float* U0, ttdg_graphs_t gr,
@@ -610,7 +620,8 @@ extern "C" int ttdg_gagm_solve(const float* Apack, const float* W, const float* 
     cmax = n > cmax ? n : cmax;
     asz += n * n;
   }
-  TTDG_LIMIT(cmax <= 128, "gagm: graphs with more than 128 nodes need the multi-workgroup solver (not built yet)");
+  if (cmax > 128)   // beyond one CU's LDS: the multi-workgroup solver (gagm_large.hip), same schedule and outputs
+    return ttdg_gagm_large_solve(Apack, W, U0, gr, cfg, U, info, ws, (hipStream_t)stream);
   TTDG_LIMIT(gr.off[gr.G] <= 4096, "gagm: more than 4096 nodes in total");
   const int cmaxp = (cmax + 63) & ~63;
   const int M = gr.off[gr.G], Mp = ga_mp(M);

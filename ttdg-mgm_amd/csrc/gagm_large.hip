@@ -1,0 +1,387 @@
+// A6 — GA-MGM solver for graphs beyond the single-workgroup kernel's 128-node limit
+// (reference multi_graph_matching.py:300-389; BASELINE cfg-3: 8 graphs x 256 nodes, M = 2048).
+//
+// At this size the per-iteration operands no longer fit one CU: W is M x M (16 MB at cfg-3, MALL/L2 resident across
+// iterations) and W U alone is 0.27 GFLOP.  One iteration = TWO launches, and the host is not in the loop:
+//
+//   gagm_large_mul_kernel      grid (row tiles of 32 nodes) x (ks K-slices + 1), 256 threads, fp32 MFMA 32x32x2:
+//        slices 0..ks-1 : partial (W U)[tile] over their K range      -> WUp[z]           (deterministic planes, no atomics)
+//        slice  ks      : B[tile] = A_g[tile,:] U_g, then the tile's share of S = U^T B   -> B, Sp[tile]
+//   gagm_large_project_kernel  one workgroup per graph, 1024 threads:
+//        S = sum of the tile shares; V_g = (2q B_g S + sum_z WUp[z]) / G; projector (whole-workgroup log-Sinkhorn from
+//        sinkhorn_device.h, or the scipy-exact one-wavefront LAP of lap_device.h on an LDS copy of V_g);
+//        ||U' - U||^2 and ||U' - U''||^2 of the graph.
+//
+// The stage machine (tau annealing, Sinkhorn -> Hungarian switch, per-stage iteration counters, both exits of :361) is
+// evaluated ON THE DEVICE at the start of every mul launch from the norms the previous projection left behind: every
+// workgroup derives the same control word, workgroup (0,0) stores it for the projection launch (two slots, ping-pong).
+// Once `done` is set the remaining queued launches return immediately, so the host enqueues iterations in growing
+// chunks and reads ONE flag per chunk (the reference reads two norms per iteration).  U / lastU / lastU2 are a ring of
+// three buffers indexed by the device-side iteration counter.
+#include "lap_device.h"
+#include "sinkhorn_device.h"
+
+#define NU 32
+#define GL_TILE 32
+#define GL_MAXKS 8
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GlCtl {   // control state at the START of an iteration; 16 words
+  int32_t done, stage, hung, it, total;
+  float tau;
+  int32_t iters[6];
+  int32_t pad[4];
+};
+
+struct GlWs {
+  float* V0;     // first-iteration V        (M x 32)  -- same offsets as the single-workgroup kernel's workspace
+  float* U1;     // first projected U        (M x 32)
+  float* ring;   // U, lastU, lastU2         (3 x M x 32)
+  float* B;      // A U                      (M x 32)
+  float* V;      // current V                (M x 32)
+  float* WUp;    // K-slice planes of W U    (ks x M x 32)
+  float* Sp;     // per-tile shares of S     (ntiles x 32 x 32)
+  float* dn;     // per-graph squared norms  (2 x 64)
+  GlCtl* ctl;    // two slots
+  int32_t* res;  // control word after the last enqueued iteration (host-visible copy source), 16 words
+  int M, ntiles, ks, Kc;
+};
+
+static inline int gl_ntiles(const ttdg_graphs_t& gr) {
+  int t = 0;
+  for (int g = 0; g < gr.G; ++g) t += (gr.off[g + 1] - gr.off[g] + GL_TILE - 1) / GL_TILE;
+  return t;
+}
+
+static inline size_t gl_ws_floats(int M, int ntiles, int ks) {
+  return (size_t)M * NU * (size_t)(7 + ks) + (size_t)ntiles * NU * NU + 128 + 32 + 16;
+}
+
+// upper bound over every partition of M nodes into <= 64 graphs (ttdg_gagm_workspace_bytes takes only M)
+size_t ttdg_gagm_large_ws_bound(int M) { return gl_ws_floats(M, M / GL_TILE + TTDG_MAX_GRAPHS, GL_MAXKS) * sizeof(float); }
+
+static GlWs gl_carve(float* ws, const ttdg_graphs_t& gr) {
+  GlWs w;
+  const int M = gr.off[gr.G];
+  const size_t MU = (size_t)M * NU;
+  w.M = M;
+  w.ntiles = gl_ntiles(gr);
+  int ks = 512 / w.ntiles;
+  ks = ks < 1 ? 1 : (ks > GL_MAXKS ? GL_MAXKS : ks);
+  int Kc = ((M + ks - 1) / ks + 127) & ~127;       // every wavefront of a slice gets whole 32-wide chunks
+  ks = (M + Kc - 1) / Kc;
+  w.ks = ks; w.Kc = Kc;
+  w.V0 = ws; w.U1 = ws + MU; w.ring = ws + 2 * MU; w.B = ws + 5 * MU; w.V = ws + 6 * MU; w.WUp = ws + 7 * MU;
+  w.Sp = w.WUp + (size_t)ks * MU;
+  w.dn = w.Sp + (size_t)w.ntiles * NU * NU;
+  w.ctl = (GlCtl*)(w.dn + 128);
+  w.res = (int32_t*)(w.dn + 128 + 32);
+  return w;
+}
+
+// control word after an iteration whose squared norms are in dn (:361-383)
+__device__ __forceinline__ GlCtl gl_advance(GlCtl c, const float* dn, int G, const ttdg_gagm_cfg_t& cfg) {
+  if (c.done) return c;
+  float s1 = 0.f, s2 = 0.f;
+  for (int g = 0; g < G; ++g) { s1 += dn[2 * g]; s2 += dn[2 * g + 1]; }
+  ++c.it; ++c.total;
+  if (sqrtf(s1) < cfg.tol || s2 == 0.f || c.it >= cfg.max_iter) {
+    if (c.stage < 6) c.iters[c.stage] = c.it;
+    ++c.stage; c.it = 0;
+    if (c.hung) c.done = 1;                                                // :374-376
+    else if (cfg.max_stages > 0 && c.stage >= cfg.max_stages) c.done = 1;
+    else if (c.tau > cfg.min_tau) c.tau *= cfg.gamma;                      // :377-379
+    else c.hung = 1;                                                       // :382-383
+  }
+  return c;
+}
+
+__global__ __launch_bounds__(256) void gagm_large_init_kernel(const float* __restrict__ U0, ttdg_gagm_cfg_t cfg, GlWs w) {
+  const size_t MU = (size_t)w.M * NU;
+  for (size_t e = blockIdx.x * 256 + threadIdx.x; e < MU; e += (size_t)gridDim.x * 256) {
+    w.ring[e] = U0[e];
+    w.ring[MU + e] = 0.f;
+    w.ring[2 * MU + e] = 0.f;          // lastU = zeros (:305)
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 128) w.dn[threadIdx.x] = 0.f;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    GlCtl c;
+    c.done = 0; c.stage = 0; c.hung = cfg.start_hungarian != 0; c.it = 0; c.total = 0; c.tau = cfg.tau0;
+    for (int k = 0; k < 6; ++k) c.iters[k] = 0;
+    for (int k = 0; k < 4; ++k) c.pad[k] = 0;
+    w.ctl[0] = c;
+    w.ctl[1] = c;
+  }
+}
+
+__device__ __forceinline__ void gl_load_chunk(const float* __restrict__ Asrc, int lda, int nrows, const float* __restrict__ Ub,
+                                              int k0, int kend, int li, int kh, float (&ra)[16], float (&rb)[16]) {
+  const int k = k0 + li;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {        // 32 x 32 tile of A, coalesced 128-byte rows
+    const int row = kh + 2 * j;
+    ra[j] = (row < nrows && k < kend) ? Asrc[(size_t)row * lda + k] : 0.f;
+  }
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {        // MFMA B operand: U[k][col], two k per step
+    const int kk = k0 + 2 * s + kh;
+    rb[s] = (kk < kend) ? Ub[(size_t)kk * NU + li] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void gagm_large_mul_kernel(const float* __restrict__ Apack, const float* __restrict__ W,
+                                                             ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg, GlWs w, int t) {
+  __shared__ GlCtl s_ctl;
+  __shared__ __attribute__((aligned(16))) float s_a[4 * GL_TILE * 33];   // per-wavefront A tiles, then the 4 accumulator planes
+  __shared__ float s_bt[GL_TILE * 33], s_ut[GL_TILE * 33];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, G = gr.G, M = w.M;
+  const size_t MU = (size_t)M * NU;
+  if (tid == 0) {
+    GlCtl c = w.ctl[t & 1];
+    if (t > 0) c = gl_advance(c, w.dn, G, cfg);
+    s_ctl = c;
+    if (blockIdx.x == 0 && blockIdx.y == 0) w.ctl[(t + 1) & 1] = c;
+  }
+  __syncthreads();
+  if (s_ctl.done) return;
+  const float* U = w.ring + (size_t)(s_ctl.total % 3) * MU;
+
+  int tile = blockIdx.x, g = 0;
+  size_t aoff = 0;
+  for (;; ++g) {
+    const int n = gr.off[g + 1] - gr.off[g], nt = (n + GL_TILE - 1) / GL_TILE;
+    if (tile < nt) break;
+    tile -= nt;
+    aoff += (size_t)n * n;
+  }
+  const int o = gr.off[g], n = gr.off[g + 1] - o;
+  const int row0 = o + tile * GL_TILE, nrows = min(GL_TILE, o + n - row0);
+  const int z = blockIdx.y;
+  const bool wpart = z < w.ks;
+  const float* Asrc; const float* Ub;
+  int lda, kbeg, kend;
+  if (wpart) { Asrc = W + (size_t)row0 * M; lda = M; kbeg = z * w.Kc; kend = min(M, kbeg + w.Kc); Ub = U; }
+  else       { Asrc = Apack + aoff + (size_t)tile * GL_TILE * n; lda = n; kbeg = 0; kend = n; Ub = U + (size_t)o * NU; }
+
+  float* sa = s_a + wave * (GL_TILE * 33);
+  const int li = lane & 31, kh = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float ra[16], rb[16], cb[16];
+  int k0 = kbeg + wave * 32;
+  if (k0 < kend) gl_load_chunk(Asrc, lda, nrows, Ub, k0, kend, li, kh, ra, rb);
+  for (; k0 < kend; k0 += 128) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sa[(kh + 2 * j) * 33 + li] = ra[j];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) cb[s] = rb[s];
+    wave_sync();
+    if (k0 + 128 < kend) gl_load_chunk(Asrc, lda, nrows, Ub, k0 + 128, kend, li, kh, ra, rb);   // in flight under the MFMAs
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[li * 33 + 2 * s + kh], cb[s], acc, 0, 0, 0);
+    wave_sync();
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s_a[wave * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * kh) * NU + li] = acc[r];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = tid + 256 * j, row = e >> 5, col = e & 31;
+    const float v = (s_a[e] + s_a[1024 + e]) + (s_a[2048 + e] + s_a[3072 + e]);
+    const bool ok = row < nrows;
+    if (wpart) {
+      if (ok) w.WUp[(size_t)z * MU + (size_t)(row0 + row) * NU + col] = v;
+    } else {
+      if (ok) w.B[(size_t)(row0 + row) * NU + col] = v;
+      s_bt[row * 33 + col] = ok ? v : 0.f;
+      s_ut[row * 33 + col] = ok ? U[(size_t)(row0 + row) * NU + col] : 0.f;
+    }
+  }
+  if (wpart) return;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {            // this tile's share of S = U^T B
+    const int e = tid + 256 * j, u = e >> 5, v = e & 31;
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < GL_TILE; ++r) s = fmaf(s_ut[r * 33 + u], s_bt[r * 33 + v], s);
+    w.Sp[(size_t)blockIdx.x * (NU * NU) + e] = s;
+  }
+}
+
+#define GL_PTHREADS 1024
+__global__ __launch_bounds__(GL_PTHREADS) void gagm_large_project_kernel(ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg, GlWs w, int t) {
+  extern __shared__ __attribute__((aligned(16))) float gl_smem[];
+  __shared__ __attribute__((aligned(16))) float s_S[NU * NU];
+  __shared__ __attribute__((aligned(16))) float s_brow[(GL_PTHREADS / 64) * 64];
+  __shared__ float s_red[2 * (GL_PTHREADS / 64)];
+  __shared__ GlCtl s_c;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, G = gr.G, M = w.M;
+  const size_t MU = (size_t)M * NU;
+  if (tid == 0) s_c = w.ctl[(t + 1) & 1];
+  __syncthreads();
+  if (s_c.done) return;
+  const int total = s_c.total;
+  const bool hung = s_c.hung != 0;
+  const float tau = s_c.tau;
+  const int g = blockIdx.x, o = gr.off[g], n = gr.off[g + 1] - o;
+  const float* Ucur = w.ring + (size_t)(total % 3) * MU + (size_t)o * NU;
+  float* Unew = w.ring + (size_t)((total + 1) % 3) * MU + (size_t)o * NU;
+  const float* Uprev = w.ring + (size_t)((total + 2) % 3) * MU + (size_t)o * NU;
+
+  for (int e = tid; e < NU * NU; e += GL_PTHREADS) {
+    float s = 0.f;
+    for (int tt = 0; tt < w.ntiles; ++tt) s += w.Sp[(size_t)tt * (NU * NU) + e];
+    s_S[e] = s;
+  }
+  __syncthreads();
+  // V_g = (2q B_g S + W U) / G: a wavefront takes two rows at a time, B rows broadcast from LDS, S column in registers
+  {
+    const int li = lane & 31, kh = lane >> 5;
+    float sc[NU];
+#pragma unroll
+    for (int k = 0; k < NU; ++k) sc[k] = s_S[k * NU + li];
+    const float qw2 = 2.f * cfg.quad_weight, invG = 1.f / (float)G;
+    float* br = s_brow + wave * 64;
+    for (int i0 = wave * 2; i0 < n; i0 += 2 * (GL_PTHREADS / 64)) {
+      const int i = i0 + kh;
+      const bool ok = i < n;
+      const size_t idx = (size_t)(o + i) * NU + li;
+      br[lane] = ok ? w.B[idx] : 0.f;
+      wave_sync();
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < NU; k += 4) {
+        const float4 b4 = *reinterpret_cast<const float4*>(br + kh * 32 + k);
+        a0 = fmaf(b4.x, sc[k], a0); a1 = fmaf(b4.y, sc[k + 1], a1);
+        a0 = fmaf(b4.z, sc[k + 2], a0); a1 = fmaf(b4.w, sc[k + 3], a1);
+      }
+      float wu = 0.f;
+      if (ok) for (int z = 0; z < w.ks; ++z) wu += w.WUp[(size_t)z * MU + idx];
+      const float v = (qw2 * (a0 + a1) + wu) * invG;
+      if (ok) {
+        w.V[idx] = v;
+        if (total == 0) w.V0[idx] = v;
+      }
+      wave_sync();
+    }
+  }
+  __syncthreads();
+  const float* Vg = w.V + (size_t)o * NU;
+
+  if (!hung) {
+    // Sinkhorn orientation (Appendix B steps 1-3) in a batch whose largest graph exceeds the universe (always true on this
+    // path): rows = universe unless n_g < 32; with equal sizes the caller transposes n > 32 itself -- the same rule
+    SkProb pb;
+    pb.src = Vg; pb.splane = 0; pb.nplanes = 1; pb.bias = 0.f; pb.scale = TTDG_LOG2E / tau;
+    const bool rows_nodes = n < NU;
+    if (rows_nodes) { pb.r = n; pb.c = NU; pb.sp = NU; pb.sq = 1; pb.op = NU; pb.oq = 1; }
+    else            { pb.r = NU; pb.c = n; pb.sp = 1; pb.sq = NU; pb.op = 1; pb.oq = NU; }
+    pb.out = Unew; pb.mir = nullptr; pb.mp = pb.mq = 0;
+    pb.mult = pb.c - pb.r;
+    pb.pot = nullptr; pb.potld = 0;
+    sk_forward<true>(pb, gl_smem, cfg.sk_iter);
+  } else {
+    const bool tr = n > NU;
+    const int nr = tr ? NU : n, nc = tr ? n : NU;
+    float* vl = gl_smem;                                   // V_g, row stride 33
+    for (int e = tid; e < n * NU; e += GL_PTHREADS) { vl[(e >> 5) * 33 + (e & 31)] = Vg[e]; Unew[e] = 0.f; }
+    __syncthreads();
+    if (wave == 0) {
+      if (nc <= 64) {
+        const int b = lap_wave_solve_reg<0>(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1);
+        wave_sync();
+        if (lane < nr) { if (tr) Unew[b * NU + lane] = 1.f; else Unew[lane * NU + b] = 1.f; }
+      } else {
+        LapScratch sc = lap_carve(vl + ((n * 33 + 3) & ~3), nr, nc);
+        lap_wave_solve(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1, sc);
+        wave_sync();
+        for (int a = lane; a < nr; a += 64) {
+          const int b = sc.col4row[a];
+          if (tr) Unew[b * NU + a] = 1.f; else Unew[a * NU + b] = 1.f;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (G == 2 && g == 0) {   // :358-359
+    for (int e = tid; e < n * NU; e += GL_PTHREADS) Unew[e] = ((e >> 5) == (e & 31)) ? 1.f : 0.f;
+    __syncthreads();
+  }
+  float d1 = 0.f, d2 = 0.f;
+  for (int e = tid; e < n * NU; e += GL_PTHREADS) {
+    const float un = Unew[e], a = un - Ucur[e], b = un - Uprev[e];
+    d1 = fmaf(a, a, d1);
+    d2 = fmaf(b, b, d2);
+    if (total == 0) w.U1[(size_t)o * NU + e] = un;
+  }
+  d1 = wave_sum(d1); d2 = wave_sum(d2);
+  if (lane == 0) { s_red[2 * wave] = d1; s_red[2 * wave + 1] = d2; }
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < GL_PTHREADS / 64; ++k) { a += s_red[2 * k]; b += s_red[2 * k + 1]; }
+    w.dn[2 * g] = a;
+    w.dn[2 * g + 1] = b;
+  }
+}
+
+// control word after `t` enqueued iterations -> w.res (what the host polls)
+__global__ void gagm_large_peek_kernel(ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg, GlWs w, int t) {
+  if (threadIdx.x != 0) return;
+  GlCtl c = w.ctl[t & 1];
+  if (t > 0) c = gl_advance(c, w.dn, gr.G, cfg);
+  const int32_t* p = (const int32_t*)&c;
+  for (int k = 0; k < 16; ++k) w.res[k] = p[k];
+}
+
+__global__ __launch_bounds__(256) void gagm_large_finish_kernel(GlWs w, float* __restrict__ Uout, int32_t* __restrict__ info) {
+  const GlCtl* c = (const GlCtl*)w.res;
+  const size_t MU = (size_t)w.M * NU;
+  const float* U = w.ring + (size_t)(c->total % 3) * MU;
+  for (size_t e = blockIdx.x * 256 + threadIdx.x; e < MU; e += (size_t)gridDim.x * 256) Uout[e] = U[e];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int k = 0; k < 6; ++k) info[k] = c->iters[k];
+    info[6] = c->total; info[7] = c->stage;
+    for (int k = 8; k < 16; ++k) info[k] = 0;
+  }
+}
+
+// entry point used by ttdg_gagm_solve (gagm.hip) when a graph has more than 128 nodes
+int ttdg_gagm_large_solve(const float* Apack, const float* W, const float* U0, ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg,
+                          float* U, int32_t* info, void* ws, hipStream_t st) {
+  int cmax = 0;
+  for (int g = 0; g < gr.G; ++g) cmax = gr.off[g + 1] - gr.off[g] > cmax ? gr.off[g + 1] - gr.off[g] : cmax;
+  TTDG_LIMIT(cmax <= 768, "gagm: graphs with more than 768 nodes are not supported");
+  TTDG_LIMIT(gr.off[gr.G] <= 16384, "gagm: more than 16384 nodes in total");
+  GlWs w = gl_carve((float*)ws, gr);
+  // dynamic LDS of the projection launch: Sinkhorn (f, g, oriented matrix) or LAP (V_g copy + scratch), whichever is larger
+  const int r = cmax < NU ? cmax : NU, c = cmax < NU ? NU : cmax;
+  const size_t sk = (size_t)(2 * c + 1 + (size_t)r * (c | 1) + 4) * sizeof(float);
+  const size_t lp = (size_t)((cmax * 33 + 3) & ~3) * sizeof(float) + lap_scratch_bytes(r, c) + 16;
+  const size_t bytes = sk > lp ? sk : lp;
+  TTDG_ALLOW_LDS(gagm_large_project_kernel, bytes);
+  const int M = gr.off[gr.G];
+  const int cblocks = (M * NU + 255) / 256 < 256 ? (M * NU + 255) / 256 : 256;
+  hipLaunchKernelGGL(gagm_large_init_kernel, dim3(cblocks), dim3(256), 0, st, U0, cfg, w);
+  int t = 0, chunk = 4;
+  const long long cap = 8LL * cfg.max_iter + 8;
+  int32_t h[16];
+  for (;;) {
+    for (int k = 0; k < chunk; ++k, ++t) {
+      hipLaunchKernelGGL(gagm_large_mul_kernel, dim3(w.ntiles, w.ks + 1), dim3(256), 0, st, Apack, W, gr, cfg, w, t);
+      hipLaunchKernelGGL(gagm_large_project_kernel, dim3(gr.G), dim3(GL_PTHREADS), bytes, st, gr, cfg, w, t);
+    }
+    hipLaunchKernelGGL(gagm_large_peek_kernel, dim3(1), dim3(64), 0, st, gr, cfg, w, t);
+    if (int e = ttdg_launch_status("gagm_large")) return e;
+    TTDG_HIP(hipMemcpyAsync(h, w.res, sizeof(h), hipMemcpyDeviceToHost, st));
+    TTDG_HIP(hipStreamSynchronize(st));     // the one convergence read per chunk (the reference reads two norms per iteration)
+    if (h[0]) break;
+    TTDG_REQUIRE(t < cap, "gagm: the stage machine did not terminate");
+    chunk = chunk < 32 ? chunk * 2 : 32;
+  }
+  hipLaunchKernelGGL(gagm_large_finish_kernel, dim3(cblocks), dim3(256), 0, st, w, U, info);
+  return ttdg_launch_status("gagm_large_finish");
+}

@@ -12,115 +12,8 @@
 //
 // One workgroup per matrix; a line (row or column) is reduced by a sub-group of 16/32/64 lanes with
 // xor-shuffles; the matrix lives in LDS when it fits (<= 36k floats), otherwise it is re-read from L2.
-#include "common.h"
-
-#define SK_MAXK 64
-#define SK_DUMMY (-100.0f * TTDG_LOG2E)
-
-struct SkProb {
-  // oriented problem: r <= c; element (p,q) of the input is sum_s src[s*splane + p*sp + q*sq] + bias
-  const float* src;
-  int64_t sp, sq, splane;
-  int nplanes;
-  float bias, scale;  // L2 = (x + bias) * scale, scale = log2(e)/tau
-  int r, c, mult;     // mult = number of dummy rows (0 when dummy_row is off)
-  float* out;         // out[p*op + q*oq] = exp(y)
-  int64_t op, oq;
-  float* mir;         // optional mirror (transposed copy), may be null
-  int64_t mp, mq;
-  float* pot;         // optional potentials log: pot[k*(cmax+1) + idx]
-  int potld;
-};
-
-__device__ __forceinline__ float sk_load(const SkProb& pb, int p, int q) {
-  float v = pb.bias;
-  const float* s = pb.src + p * pb.sp + q * pb.sq;
-  for (int k = 0; k < pb.nplanes; ++k) v += s[k * pb.splane];
-  return v * pb.scale;
-}
-
-__device__ __forceinline__ float sub_max(float v, int sg) {
-  for (int o = sg >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
-__device__ __forceinline__ float sub_sum(float v, int sg) {
-  for (int o = sg >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
-// LDS carve (dynamic): [f: cmax+1][g: cmax][mat: r*ldm  (kLds only)]
-template <bool kLds>
-__device__ void sk_forward(const SkProb& pb, float* smem, int iters) {
-  const int r = pb.r, c = pb.c, mult = pb.mult;
-  float* f = smem;           // r real rows + 1 dummy
-  float* g = smem + c + 1;   // c
-  float* mat = g + c;        // r x ldm
-  const int ldm = c | 1;     // odd stride: column walks are conflict-free
-  const int tid = threadIdx.x, nthr = blockDim.x;
-
-  for (int q = tid; q < c; q += nthr) g[q] = 0.f;
-  for (int p = tid; p <= r; p += nthr) f[p] = 0.f;
-  if (kLds)
-    for (int e = tid; e < r * c; e += nthr) {
-      const int p = e / c, q = e - p * c;
-      mat[p * ldm + q] = sk_load(pb, p, q);
-    }
-  __syncthreads();
-
-  const int sg = (c > 32) ? 64 : (c > 16 ? 32 : 16);      // lanes per line
-  const int sl = tid & (sg - 1), sgi = tid / sg, nsg = nthr / sg;
-  for (int it = 0; it < iters; ++it) {
-    if ((it & 1) == 0) {
-      // rows: f_p = lse_q(L_pq - g_q); the dummy row uses the constant fill
-      const int nlines = r + (mult > 0 ? 1 : 0);
-      for (int p = sgi; p < nlines; p += nsg) {
-        const bool dum = (p == r);
-        float m = -INFINITY;
-        for (int q = sl; q < c; q += sg) {
-          const float t = (dum ? SK_DUMMY : (kLds ? mat[p * ldm + q] : sk_load(pb, p, q))) - g[q];
-          m = fmaxf(m, t);
-        }
-        m = sub_max(m, sg);
-        float s = 0.f;
-        for (int q = sl; q < c; q += sg) {
-          const float t = (dum ? SK_DUMMY : (kLds ? mat[p * ldm + q] : sk_load(pb, p, q))) - g[q];
-          s += fast_exp2(t - m);
-        }
-        s = sub_sum(s, sg);
-        if (sl == 0) {
-          const float v = m + fast_log2(s);
-          f[p] = v;
-          if (pb.pot) pb.pot[it * pb.potld + p] = v;
-        }
-      }
-    } else {
-      // cols: g_q = lse over the r real rows and `mult` copies of the dummy row
-      const float td0 = SK_DUMMY - f[r];
-      for (int q = sgi; q < c; q += nsg) {
-        float m = (mult > 0) ? td0 : -INFINITY;
-        for (int p = sl; p < r; p += sg) m = fmaxf(m, (kLds ? mat[p * ldm + q] : sk_load(pb, p, q)) - f[p]);
-        m = sub_max(m, sg);
-        float s = 0.f;
-        for (int p = sl; p < r; p += sg) s += fast_exp2((kLds ? mat[p * ldm + q] : sk_load(pb, p, q)) - f[p] - m);
-        s = sub_sum(s, sg);
-        if (mult > 0) s += (float)mult * fast_exp2(td0 - m);
-        if (sl == 0) {
-          const float v = m + fast_log2(s);
-          g[q] = v;
-          if (pb.pot) pb.pot[it * pb.potld + q] = v;
-        }
-      }
-    }
-    __syncthreads();
-  }
-  for (int e = tid; e < r * c; e += nthr) {
-    const int p = e / c, q = e - p * c;
-    const float y = (kLds ? mat[p * ldm + q] : sk_load(pb, p, q)) - f[p] - g[q];
-    const float v = fast_exp2(y);
-    pb.out[p * pb.op + q * pb.oq] = v;
-    if (pb.mir) pb.mir[p * pb.mp + q * pb.mq] = v;
-  }
-}
+#include "sinkhorn_device.h"
+#include "lap_device.h"   // DPP wavefront reductions
 
 // ---- pair stage (multi_graph_matching.py:504-525) --------------------------------------------------
 __device__ __forceinline__ void pair_of(int idx, int G, int& a, int& b) {
@@ -162,6 +55,217 @@ __global__ void sinkhorn_pairs_fwd_kernel(const float* __restrict__ part, int ks
   sk_forward<kLds>(pb, smem, iters);
 }
 
+
+// ---- register-resident pair stage for 128 < c <= 256 (BASELINE cfg-3: 256-node graphs) ---------------------------------
+// A 256 x 256 fp32 matrix (256 KB) does not fit the 160 KB LDS, but it fits the register file of ONE workgroup:
+// 512 threads x 128 VGPRs.  Wavefront w owns rows [32w, 32w+32), lane l owns columns 4l..4l+3, so
+//   row sweep : 4 in-lane terms + one DPP wavefront reduction per row, no LDS, no barrier;
+//   col sweep : 32 in-lane terms per column, the 8 wavefront partials meet in LDS (one barrier), and every wavefront
+//               finishes all 256 columns redundantly (no second barrier, identical values everywhere).
+// After the first row+col pair y = L - f - g <= 0, so the previous potential is a valid stabiliser: sweeps >= 2 are
+// single-pass (no max); a line whose sum leaves [2^-80, 2^80] falls back to the exact two-pass form (rows: per row,
+// wavefront-uniform; columns: ballot over the wavefront, the same decision in every wavefront).
+#define SKR_THREADS 512
+#define SKR_WAVES 8
+#define SKR_C 256
+#define SKR_BIG 1.2e24f
+#define SKR_SMALL 8.3e-25f
+
+__device__ __forceinline__ float skr_sgpr(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ bool skr_sane(float s) { return s > SKR_SMALL && s < SKR_BIG; }
+
+// element (p, q) through a wavefront-uniform row pointer + a 32-bit lane offset (scalar base + vector offset addressing)
+__device__ __forceinline__ float skr_load(const SkProb& pb, const float* rowp, int qo) {
+  float v = pb.bias;
+  for (int k = 0; k < pb.nplanes; ++k) v += rowp[(size_t)k * pb.splane + qo];
+  return v * pb.scale;
+}
+
+__device__ __forceinline__ void sk_pair_problem(const float* part, int ksplit, const float* b2, const ttdg_graphs_t& gr, float tau,
+                                                int a, int b, SkProb& pb) {
+  const int M = gr.off[gr.G];
+  const int na = gr.off[a + 1] - gr.off[a], nb = gr.off[b + 1] - gr.off[b];
+  pb.src = part + (size_t)gr.off[a] * M + gr.off[b];
+  pb.splane = (int64_t)M * M;
+  pb.nplanes = ksplit;
+  pb.bias = b2 ? *b2 : 0.f;
+  pb.scale = TTDG_LOG2E / tau;
+  if (nb >= na) { pb.r = na; pb.c = nb; pb.sp = M; pb.sq = 1; }
+  else          { pb.r = nb; pb.c = na; pb.sp = 1; pb.sq = M; }
+  pb.mult = pb.c - pb.r;
+}
+
+__global__ __launch_bounds__(SKR_THREADS) void sinkhorn_pairs_fwd_reg_kernel(const float* __restrict__ part, int ksplit,
+                                                                             const float* __restrict__ b2, ttdg_graphs_t gr, float tau,
+                                                                             int iters, float* __restrict__ Wds,
+                                                                             float* __restrict__ pot, int cmax) {
+  __shared__ __attribute__((aligned(16))) float s_part[2][SKR_WAVES * SKR_C];
+  int a, b;
+  pair_of(blockIdx.x, gr.G, a, b);
+  const int M = gr.off[gr.G];
+  SkProb pb;
+  sk_pair_problem(part, ksplit, b2, gr, tau, a, b, pb);
+  float* wab = Wds + (size_t)gr.off[a] * M + gr.off[b];
+  float* wba = Wds + (size_t)gr.off[b] * M + gr.off[a];
+  const bool flip = pb.sq != 1;
+  pb.out = wab; pb.op = flip ? 1 : M; pb.oq = flip ? M : 1;
+  pb.mir = (flip || a != b) ? wba : nullptr; pb.mp = flip ? M : 1; pb.mq = flip ? 1 : M;
+  const int potld = cmax + 1;
+  float* pt = pot ? pot + (size_t)blockIdx.x * iters * potld : nullptr;
+  const int r = pb.r, c = pb.c, mult = pb.mult;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave: provably uniform -> scalar row pointers
+  const int p0 = wave * 32, q0 = lane * 4;
+
+  // branch-free load: clamped (always valid) addresses, every plane's 128 loads in flight together
+  const int sq = (int)pb.sq;
+  unsigned qo[4];   // 32-bit BYTE offsets: scalar row base + vector offset addressing (blocks span < 4 GB)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) qo[j] = (unsigned)(min(q0 + j, c - 1) * sq) * 4u;
+  float L[32][4];   // single plane only (the host routes K-split inputs to the LDS kernel): no loop for LICM to hoist 128 addresses out of
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {   // 128 unconditional loads in flight (clamped addresses); the empty asm keeps them from being sunk into branches
+    const char* rowp = reinterpret_cast<const char*>(pb.src + (int64_t)min(p0 + i, r - 1) * pb.sp);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) L[i][j] = *reinterpret_cast<const float*>(rowp + qo[j]);
+  }
+#pragma unroll
+  for (int i = 0; i < 32; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(L[i][j]));
+#pragma unroll
+  for (int i = 0; i < 32; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) L[i][j] = (p0 + i < r && q0 + j < c) ? (L[i][j] + pb.bias) * pb.scale : -INFINITY;
+  float f[32], g[4] = {0.f, 0.f, 0.f, 0.f}, fd = 0.f;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) f[i] = 0.f;
+  int buf = 0;
+
+  for (int it = 0; it < iters; ++it) {
+    if ((it & 1) == 0) {
+      // ---- rows: f_p = lse_q(L_pq - g_q) ----
+      float flog = 0.f;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        if (p0 + i < r) {
+          const float t0 = L[i][0] - g[0], t1 = L[i][1] - g[1], t2 = L[i][2] - g[2], t3 = L[i][3] - g[3];
+          float sh = f[i], s = 0.f;
+          bool exact = it < 2;
+          if (!exact) {
+            s = wave_sum_f32_dpp((fast_exp2(t0 - sh) + fast_exp2(t1 - sh)) + (fast_exp2(t2 - sh) + fast_exp2(t3 - sh)));
+            exact = !skr_sane(s);
+          }
+          if (exact) {
+            sh = wave_max_f32_dpp(fmaxf(fmaxf(t0, t1), fmaxf(t2, t3)));
+            s = wave_sum_f32_dpp((fast_exp2(t0 - sh) + fast_exp2(t1 - sh)) + (fast_exp2(t2 - sh) + fast_exp2(t3 - sh)));
+          }
+          f[i] = skr_sgpr(sh + fast_log2(s));
+        }
+        flog = (lane == i) ? f[i] : flog;
+      }
+      if (mult > 0) {   // the dummy row, always in the exact form (4 terms per lane)
+        float dm = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (q0 + j < c) dm = fmaxf(dm, -g[j]);
+        dm = wave_max_f32_dpp(dm);
+        float ds = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (q0 + j < c) ds += fast_exp2(-g[j] - dm);
+        ds = wave_sum_f32_dpp(ds);
+        fd = skr_sgpr(SK_DUMMY + dm + fast_log2(ds));
+      }
+      if (pt) {
+        if (lane < 32 && p0 + lane < r) pt[it * potld + p0 + lane] = flog;
+        if (mult > 0 && tid == 0) pt[it * potld + r] = fd;
+      }
+    } else {
+      // ---- cols: g_q = lse over the r real rows and `mult` copies of the dummy row ----
+      const float td0 = (mult > 0) ? SK_DUMMY - fd : -INFINITY;
+      bool exact = it < 2;
+      float gn[4];
+      for (;;) {
+        float sh[4];
+        if (exact) {
+          float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+          for (int i = 0; i < 32; ++i)
+            if (p0 + i < r) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) mx[j] = fmaxf(mx[j], L[i][j] - f[i]);
+            }
+          *reinterpret_cast<float4*>(&s_part[buf][wave * SKR_C + q0]) = make_float4(mx[0], mx[1], mx[2], mx[3]);
+          __syncthreads();
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sh[j] = td0;
+#pragma unroll
+          for (int w = 0; w < SKR_WAVES; ++w) {
+            const float4 v = *reinterpret_cast<const float4*>(&s_part[buf][w * SKR_C + q0]);
+            sh[0] = fmaxf(sh[0], v.x); sh[1] = fmaxf(sh[1], v.y); sh[2] = fmaxf(sh[2], v.z); sh[3] = fmaxf(sh[3], v.w);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) if (q0 + j >= c) sh[j] = 0.f;
+          buf ^= 1;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) sh[j] = g[j];
+        }
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+          if (p0 + i < r) {
+            const float fi = f[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += fast_exp2(L[i][j] - fi - sh[j]);
+          }
+        *reinterpret_cast<float4*>(&s_part[buf][wave * SKR_C + q0]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        __syncthreads();
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < SKR_WAVES; ++w) {
+          const float4 v = *reinterpret_cast<const float4*>(&s_part[buf][w * SKR_C + q0]);
+          s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        }
+        buf ^= 1;
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (mult > 0) s[j] += (float)mult * fast_exp2(td0 - sh[j]);
+          const bool live = q0 + j < c;
+          gn[j] = live ? sh[j] + fast_log2(s[j]) : 0.f;
+          bad |= live && !skr_sane(s[j]);
+        }
+        if (exact || __ballot(bad) == 0ull) break;
+        exact = true;     // the same ballot in every wavefront: all of them redo the sweep in the two-pass form
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) g[j] = gn[j];
+      if (pt && wave == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (q0 + j < c) pt[it * potld + q0 + j] = g[j];
+      }
+    }
+  }
+  unsigned oo[4], mo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { oo[j] = (unsigned)((q0 + j) * (int)pb.oq) * 4u; mo[j] = (unsigned)((q0 + j) * (int)pb.mq) * 4u; }
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int p = p0 + i;
+    if (p < r) {
+      char* orow = reinterpret_cast<char*>(pb.out + (int64_t)p * pb.op);
+      char* mrow = reinterpret_cast<char*>(pb.mir + (int64_t)p * pb.mp);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (q0 + j < c) {
+          const float v = fast_exp2(L[i][j] - f[i] - g[j]);
+          *reinterpret_cast<float*>(orow + oo[j]) = v;
+          if (pb.mir) *reinterpret_cast<float*>(mrow + mo[j]) = v;
+        }
+      }
+    }
+  }
+}
+
 static inline size_t sk_lds_bytes(int rmax, int cmax, bool mat, int nmat) {
   size_t n = (size_t)(cmax + 1) + cmax + 4;
   if (mat) n += (size_t)nmat * rmax * (cmax | 1);
@@ -186,6 +290,11 @@ extern "C" int ttdg_sinkhorn_pairs_fwd(const float* part, int ksplit, const floa
   const size_t bytes = sk_lds_bytes(cmax, cmax, lds, 1);
   const int threads = cmax <= 64 ? 256 : 1024;
   hipStream_t st = (hipStream_t)stream;
+  if (cmax > 128 && cmax <= SKR_C && ksplit == 1) {
+    hipLaunchKernelGGL(sinkhorn_pairs_fwd_reg_kernel, dim3(npairs), dim3(SKR_THREADS), 0, st, part, ksplit, b2, gr, tau, iters,
+                       Wds, pot, cmax);
+    return ttdg_launch_status("sinkhorn_pairs_fwd_reg");
+  }
   if (lds) {
     TTDG_ALLOW_LDS((sinkhorn_pairs_fwd_kernel<true>), bytes);
     hipLaunchKernelGGL((sinkhorn_pairs_fwd_kernel<true>), dim3(npairs), dim3(threads), bytes, st, part, ksplit, b2, gr, tau,
@@ -301,6 +410,150 @@ __global__ void sinkhorn_pairs_bwd_kernel(const float* __restrict__ part, int ks
   }
 }
 
+
+// register-resident backward for 128 < c <= 256: dY lives in registers (32 x 4 per lane, same ownership as the forward
+// kernel), L is streamed from L2 every sweep in groups of 4 rows (the next group's 16 loads are in flight under the
+// current group's exps), potentials come from the forward log; row sums are DPP wavefront reductions, column sums meet
+// in LDS with one barrier per column sweep (double-buffered, every wavefront finishes all columns).
+#define SKR_GROUP 4
+__device__ __forceinline__ void skr_load_group(const SkProb& pb, int p0, int grp, int r, const unsigned (&qo)[4], float (&dst)[SKR_GROUP][4]) {
+#pragma unroll
+  for (int a = 0; a < SKR_GROUP; ++a) {
+    const char* rowp = reinterpret_cast<const char*>(pb.src + (int64_t)min(p0 + grp * SKR_GROUP + a, r - 1) * pb.sp);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dst[a][j] = *reinterpret_cast<const float*>(rowp + qo[j]);
+  }
+}
+
+__global__ __launch_bounds__(SKR_THREADS) void sinkhorn_pairs_bwd_reg_kernel(const float* __restrict__ part, int ksplit,
+                                                                             const float* __restrict__ b2, const float* __restrict__ pot,
+                                                                             const float* __restrict__ dWds, ttdg_graphs_t gr, float tau,
+                                                                             int iters, float* __restrict__ dM, int cmax) {
+  __shared__ __attribute__((aligned(16))) float s_part[2][SKR_WAVES * SKR_C];
+  int a = 1, idx = blockIdx.x;
+  while (idx >= a) { idx -= a; ++a; }
+  const int b = idx;
+  const int pair_fwd = a * (a + 1) / 2 + b;
+  const int M = gr.off[gr.G];
+  SkProb pb;
+  sk_pair_problem(part, ksplit, b2, gr, tau, a, b, pb);
+  const bool flip = pb.sq != 1;
+  const float* dout = dWds + (size_t)gr.off[b] * M + gr.off[a];
+  float* dm = dM + (size_t)gr.off[a] * M + gr.off[b];
+  const int64_t dop = flip ? M : 1, dmp = flip ? 1 : M;
+  const int doq = flip ? 1 : M, dmq = flip ? M : 1;
+  const int r = pb.r, c = pb.c, mult = pb.mult, potld = cmax + 1;
+  const float* pt = pot + (size_t)pair_fwd * iters * potld;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave: provably uniform -> scalar row pointers
+  const int p0 = wave * 32, q0 = lane * 4;
+  const float bias = pb.bias, scale = pb.scale;
+  unsigned qo[4], qd[4], qm[4];   // 32-bit byte offsets of the lane's columns in L / dOut / dM
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = min(q0 + j, c - 1);
+    qo[j] = (unsigned)(q * (int)pb.sq) * 4u; qd[j] = (unsigned)(q * doq) * 4u; qm[j] = (unsigned)(q * dmq) * 4u;
+  }
+
+  float f[32], g[4], fd, dY[32][4], dd[4] = {0.f, 0.f, 0.f, 0.f};
+  // potentials of sweep index kf (rows) / kg (cols); a negative index means "still zero"
+#define SKR_LOAD_POT(kf, kg)                                                                             \
+  {                                                                                                      \
+    const float fv = ((kf) >= 0 && lane < 32 && p0 + lane < r) ? pt[(kf) * potld + p0 + lane] : 0.f;     \
+    _Pragma("unroll") for (int i = 0; i < 32; ++i) f[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fv), i)); \
+    fd = ((kf) >= 0 && mult > 0) ? pt[(kf) * potld + r] : 0.f;                                           \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) g[j] = ((kg) >= 0 && q0 + j < c) ? pt[(kg) * potld + q0 + j] : 0.f; \
+  }
+  {
+    const int klast_row = (iters - 1) & ~1, klast_col = ((iters - 1) & 1) ? iters - 1 : iters - 2;
+    SKR_LOAD_POT(klast_row, (klast_col >= 1 ? klast_col : -1))
+  }
+  float Lb[2][SKR_GROUP][4];
+  // dY = dOut * out on the real rows
+  skr_load_group(pb, p0, 0, r, qo, Lb[0]);
+#pragma unroll
+  for (int grp = 0; grp < 32 / SKR_GROUP; ++grp) {
+    if (grp + 1 < 32 / SKR_GROUP) skr_load_group(pb, p0, grp + 1, r, qo, Lb[(grp + 1) & 1]);
+#pragma unroll
+    for (int a2 = 0; a2 < SKR_GROUP; ++a2) {
+      const int i = grp * SKR_GROUP + a2, p = p0 + i;
+      const char* drow = reinterpret_cast<const char*>(dout + (int64_t)min(p, r - 1) * dop);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float o = fast_exp2((Lb[grp & 1][a2][j] + bias) * scale - f[i] - g[j]);
+        dY[i][j] = (p < r && q0 + j < c) ? *reinterpret_cast<const float*>(drow + qd[j]) * o : 0.f;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  int buf = 0;
+  for (int k = iters - 1; k >= 0; --k) {
+    if ((k & 1) == 0) { SKR_LOAD_POT(k, (k >= 1 ? k - 1 : -1)) } else { SKR_LOAD_POT(k - 1, k) }
+    float de[4];   // exp(y) of the dummy row in the lane's columns
+#pragma unroll
+    for (int j = 0; j < 4; ++j) de[j] = (mult > 0 && q0 + j < c) ? fast_exp2(SK_DUMMY - fd - g[j]) : 0.f;
+    float ls[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool rows = (k & 1) == 0;
+    if (!rows) {
+      float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 32; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cs[j] += dY[i][j];
+      *reinterpret_cast<float4*>(&s_part[buf][wave * SKR_C + q0]) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+      __syncthreads();
+#pragma unroll
+      for (int w = 0; w < SKR_WAVES; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(&s_part[buf][w * SKR_C + q0]);
+        ls[0] += v.x; ls[1] += v.y; ls[2] += v.z; ls[3] += v.w;
+      }
+      buf ^= 1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ls[j] += (float)mult * dd[j];
+    }
+    skr_load_group(pb, p0, 0, r, qo, Lb[0]);
+#pragma unroll
+    for (int grp = 0; grp < 32 / SKR_GROUP; ++grp) {
+      if (grp + 1 < 32 / SKR_GROUP) skr_load_group(pb, p0, grp + 1, r, qo, Lb[(grp + 1) & 1]);
+#pragma unroll
+      for (int a2 = 0; a2 < SKR_GROUP; ++a2) {
+        const int i = grp * SKR_GROUP + a2;
+        if (p0 + i < r) {
+          float lrow = 0.f;
+          if (rows) lrow = wave_sum_f32_dpp((dY[i][0] + dY[i][1]) + (dY[i][2] + dY[i][3]));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float e = fast_exp2((Lb[grp & 1][a2][j] + bias) * scale - f[i] - g[j]);
+            if (q0 + j < c) dY[i][j] -= e * (rows ? lrow : ls[j]);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (rows) {
+      if (mult > 0) {
+        const float lsd = wave_sum_f32_dpp((dd[0] + dd[1]) + (dd[2] + dd[3]));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dd[j] -= de[j] * lsd;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dd[j] -= de[j] * ls[j];
+    }
+  }
+#undef SKR_LOAD_POT
+  const float inv_tau = 1.f / tau;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const int p = p0 + i;
+    if (p < r) {
+      char* mrow = reinterpret_cast<char*>(dm + (int64_t)p * dmp);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (q0 + j < c) *reinterpret_cast<float*>(mrow + qm[j]) = dY[i][j] * inv_tau;
+    }
+  }
+}
+
 extern "C" int ttdg_sinkhorn_pairs_bwd(const float* part, int ksplit, const float* b2, const float* pot,
                                        const float* dWds, ttdg_graphs_t gr, float tau, int iters, float* dM,
                                        ttdg_stream_t stream) {
@@ -316,6 +569,11 @@ extern "C" int ttdg_sinkhorn_pairs_bwd(const float* part, int ksplit, const floa
   const size_t bytes = lds ? need : base;
   const int threads = cmax <= 64 ? 256 : 1024;
   hipStream_t st = (hipStream_t)stream;
+  if (cmax > 128 && cmax <= SKR_C && ksplit == 1) {
+    hipLaunchKernelGGL(sinkhorn_pairs_bwd_reg_kernel, dim3(npairs), dim3(SKR_THREADS), 0, st, part, ksplit, b2, pot, dWds, gr, tau,
+                       iters, dM, cmax);
+    return ttdg_launch_status("sinkhorn_pairs_bwd_reg");
+  }
   if (lds) {
     TTDG_ALLOW_LDS((sinkhorn_pairs_bwd_kernel<true>), bytes);
     hipLaunchKernelGGL((sinkhorn_pairs_bwd_kernel<true>), dim3(npairs), dim3(threads), bytes, st, part, ksplit, b2, pot, dWds,

@@ -1,0 +1,114 @@
+// Device-side log-Sinkhorn on dual potentials, shared by the pair stage / stand-alone operator (sinkhorn.hip) and
+// the large-graph GA-MGM solver (gagm_large.hip).  Formulation and citations: see the header of sinkhorn.hip.
+#pragma once
+#include "common.h"
+
+
+#define SK_MAXK 64
+#define SK_DUMMY (-100.0f * TTDG_LOG2E)
+
+struct SkProb {
+  // oriented problem: r <= c; element (p,q) of the input is sum_s src[s*splane + p*sp + q*sq] + bias
+  const float* src;
+  int64_t sp, sq, splane;
+  int nplanes;
+  float bias, scale;  // L2 = (x + bias) * scale, scale = log2(e)/tau
+  int r, c, mult;     // mult = number of dummy rows (0 when dummy_row is off)
+  float* out;         // out[p*op + q*oq] = exp(y)
+  int64_t op, oq;
+  float* mir;         // optional mirror (transposed copy), may be null
+  int64_t mp, mq;
+  float* pot;         // optional potentials log: pot[k*(cmax+1) + idx]
+  int potld;
+};
+
+__device__ __forceinline__ float sk_load(const SkProb& pb, int p, int q) {
+  float v = pb.bias;
+  const float* s = pb.src + p * pb.sp + q * pb.sq;
+  for (int k = 0; k < pb.nplanes; ++k) v += s[k * pb.splane];
+  return v * pb.scale;
+}
+
+__device__ __forceinline__ float sub_max(float v, int sg) {
+  for (int o = sg >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float sub_sum(float v, int sg) {
+  for (int o = sg >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// LDS carve (dynamic): [f: cmax+1][g: cmax][mat: r*ldm  (kLds only)]
+template <bool kLds>
+__device__ void sk_forward(const SkProb& pb, float* smem, int iters) {
+  const int r = pb.r, c = pb.c, mult = pb.mult;
+  float* f = smem;           // r real rows + 1 dummy
+  float* g = smem + c + 1;   // c
+  float* mat = g + c;        // r x ldm
+  const int ldm = c | 1;     // odd stride: column walks are conflict-free
+  const int tid = threadIdx.x, nthr = blockDim.x;
+
+  for (int q = tid; q < c; q += nthr) g[q] = 0.f;
+  for (int p = tid; p <= r; p += nthr) f[p] = 0.f;
+  if (kLds)
+    for (int e = tid; e < r * c; e += nthr) {
+      const int p = e / c, q = e - p * c;
+      mat[p * ldm + q] = sk_load(pb, p, q);
+    }
+  __syncthreads();
+
+  const int sg = (c > 32) ? 64 : (c > 16 ? 32 : 16);      // lanes per line
+  const int sl = tid & (sg - 1), sgi = tid / sg, nsg = nthr / sg;
+  for (int it = 0; it < iters; ++it) {
+    if ((it & 1) == 0) {
+      // rows: f_p = lse_q(L_pq - g_q); the dummy row uses the constant fill
+      const int nlines = r + (mult > 0 ? 1 : 0);
+      for (int p = sgi; p < nlines; p += nsg) {
+        const bool dum = (p == r);
+        float m = -INFINITY;
+        for (int q = sl; q < c; q += sg) {
+          const float t = (dum ? SK_DUMMY : (kLds ? mat[p * ldm + q] : sk_load(pb, p, q))) - g[q];
+          m = fmaxf(m, t);
+        }
+        m = sub_max(m, sg);
+        float s = 0.f;
+        for (int q = sl; q < c; q += sg) {
+          const float t = (dum ? SK_DUMMY : (kLds ? mat[p * ldm + q] : sk_load(pb, p, q))) - g[q];
+          s += fast_exp2(t - m);
+        }
+        s = sub_sum(s, sg);
+        if (sl == 0) {
+          const float v = m + fast_log2(s);
+          f[p] = v;
+          if (pb.pot) pb.pot[it * pb.potld + p] = v;
+        }
+      }
+    } else {
+      // cols: g_q = lse over the r real rows and `mult` copies of the dummy row
+      const float td0 = SK_DUMMY - f[r];
+      for (int q = sgi; q < c; q += nsg) {
+        float m = (mult > 0) ? td0 : -INFINITY;
+        for (int p = sl; p < r; p += sg) m = fmaxf(m, (kLds ? mat[p * ldm + q] : sk_load(pb, p, q)) - f[p]);
+        m = sub_max(m, sg);
+        float s = 0.f;
+        for (int p = sl; p < r; p += sg) s += fast_exp2((kLds ? mat[p * ldm + q] : sk_load(pb, p, q)) - f[p] - m);
+        s = sub_sum(s, sg);
+        if (mult > 0) s += (float)mult * fast_exp2(td0 - m);
+        if (sl == 0) {
+          const float v = m + fast_log2(s);
+          g[q] = v;
+          if (pb.pot) pb.pot[it * pb.potld + q] = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < r * c; e += nthr) {
+    const int p = e / c, q = e - p * c;
+    const float y = (kLds ? mat[p * ldm + q] : sk_load(pb, p, q)) - f[p] - g[q];
+    const float v = fast_exp2(y);
+    pb.out[p * pb.op + q * pb.oq] = v;
+    if (pb.mir) pb.mir[p * pb.mp + q * pb.mq] = v;
+  }
+}
+

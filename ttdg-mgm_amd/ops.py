@@ -67,9 +67,9 @@ class LinearFn(torch.autograd.Function):
 
 # ------------------------------------------------------------------------------------------- pieces
 def pick_ksplit(M, H=HID, nmax=0):
-    """Split K so that the pairwise kernel launches ~4 workgroups per CU on small batches.  When a graph is too large
-    for the LDS-resident pair Sinkhorn (> 190 nodes) the partial planes would be re-summed on every sweep: keep 1."""
-    if nmax > 190:
+    """Split K so that the pairwise kernel launches ~4 workgroups per CU on small batches.  Above 128 nodes per graph
+    the pair Sinkhorn holds the matrix in registers and reads a single plane: keep 1 (the tile count is large anyway)."""
+    if nmax > 128:
         return 1
     nt = (M + 63) // 64
     tiles = nt * (nt + 1) // 2
@@ -152,15 +152,15 @@ def gagm_one_step(apack, W, Ucur, gr, sizes, tau=None, quad_weight=0.5, sk_iter=
     return U, V0
 
 
-GAGM_MAX_NODES = 128      # per-graph limit of the persistent single-workgroup solver
+GAGM_MAX_NODES = 128      # per-graph limit of the single-workgroup kernel; larger graphs take csrc/gagm_large.hip
 
 
-def gagm_solve_large(apack, W, U0, sizes, cfg):
-    """Solver for graphs beyond the persistent kernel's 128-node limit (BASELINE cfg-3: 8 x 256 nodes; the node
-    sampler itself never produces more than 95).  Same schedule as reference multi_graph_matching.py:300-389, one
-    iteration = a handful of launches of the SAME device operators (MFMA GEMMs for B = A U, S = U^T B,
-    V = (2q B S + W U)/G; batched Sinkhorn / batched LAP projectors) and one host read of the two convergence norms,
-    like the reference.  Returns (U, info, V0)."""
+def gagm_solve_hostloop(apack, W, U0, sizes, cfg, states=None):
+    """Host-driven statement of the solver (reference multi_graph_matching.py:300-389) on the stand-alone device
+    operators: one iteration = a handful of launches (MFMA GEMMs for B = A U, S = U^T B, V = (2q B S + W U)/G; batched
+    Sinkhorn / LAP projectors) and one host read of the two convergence norms, like the reference.  NOT on the product
+    path: it is the independent cross-check of the native multi-workgroup solver in the GPU tests.
+    Returns (U, info, V0)."""
     dev = W.device
     G, M = len(sizes), sum(sizes)
     off = [0]
@@ -207,6 +207,8 @@ def gagm_solve_large(apack, W, U0, sizes, cfg):
             if G == 2:
                 U[:sizes[0]] = torch.eye(sizes[0], UNIV, device=dev)
             total += 1
+            if states is not None:
+                states.append((hung, tau, lastU, U, V.clone()))
             d = torch.stack((torch.norm(U - lastU), torch.norm(U - lastU2))).tolist()        # the reference's two syncs
             if d[0] < float(cfg.tol) or d[1] == 0:
                 break
@@ -228,8 +230,6 @@ def gagm_solve(apack, W, U0, gr, sizes, cfg=None):
     """Returns (U (M,32) 0/1, info int32[16] on device, V0 (M,32) first-iteration V)."""
     M = sum(sizes)
     cfg = cfg or gagm_cfg()
-    if max(sizes) > GAGM_MAX_NODES:
-        return gagm_solve_large(apack, W, U0, list(sizes), cfg)
     nbytes = _lib.load().ttdg_gagm_workspace_bytes(M)
     ws = torch.empty(nbytes // 4, device=W.device, dtype=torch.float32)
     U = torch.empty(M, UNIV, device=W.device, dtype=torch.float32)
