@@ -18,19 +18,28 @@
 // Once `done` is set the remaining queued launches return immediately, so the host enqueues iterations in growing
 // chunks and reads ONE flag per chunk (the reference reads two norms per iteration).  U / lastU / lastU2 are a ring of
 // three buffers indexed by the device-side iteration counter.
+//
+// Hungarian stage: the exact cycle shortcut of the single-workgroup kernel (gagm.hip) -- the stage map is a deterministic
+// map on a finite set and the reference only exits on periods 1 and 2, so a longer cycle burns all 200 iterations.  Every
+// projection leaves a one-byte-per-node code of its state and a per-graph 64-bit hash; the control step looks the hash up
+// in the stage's history, verifies the candidate byte for byte, and on a period p >= 3 jumps to the state iteration
+// max_iter-1 would land on (bit-identical to running them all).
 #include "lap_device.h"
 #include "sinkhorn_device.h"
 
 #define NU 32
 #define GL_TILE 32
 #define GL_MAXKS 8
+#define GL_HIST 256   /* states remembered per Hungarian stage (>= the reference's 200-iteration cap) */
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct GlCtl {   // control state at the START of an iteration; 16 words
   int32_t done, stage, hung, it, total;
   float tau;
   int32_t iters[6];
-  int32_t pad[4];
+  int32_t jump;          // 1 + history index of the final state when the cycle shortcut fired, else 0
+  int32_t cyc_p, cyc_i;  // period and detection iteration (info[14], info[15])
+  int32_t pad;
 };
 
 struct GlWs {
@@ -44,6 +53,9 @@ struct GlWs {
   float* dn;     // per-graph squared norms  (2 x 64)
   GlCtl* ctl;    // two slots
   int32_t* res;  // control word after the last enqueued iteration (host-visible copy source), 16 words
+  unsigned long long* hg;      // per-graph state hashes of the latest projection (64)
+  unsigned long long* hhash;   // whole-state hash per Hungarian-stage iteration (GL_HIST)
+  unsigned char* hist;         // state codes, GL_HIST x M bytes
   int M, ntiles, ks, Kc;
 };
 
@@ -54,7 +66,7 @@ static inline int gl_ntiles(const ttdg_graphs_t& gr) {
 }
 
 static inline size_t gl_ws_floats(int M, int ntiles, int ks) {
-  return (size_t)M * NU * (size_t)(7 + ks) + (size_t)ntiles * NU * NU + 128 + 32 + 16;
+  return (size_t)M * NU * (size_t)(7 + ks) + (size_t)ntiles * NU * NU + 128 + 32 + 16 + 2 * (64 + GL_HIST) + (size_t)GL_HIST * ((M + 3) / 4) + 8;
 }
 
 // upper bound over every partition of M nodes into <= 64 graphs (ttdg_gagm_workspace_bytes takes only M)
@@ -76,24 +88,68 @@ static GlWs gl_carve(float* ws, const ttdg_graphs_t& gr) {
   w.dn = w.Sp + (size_t)w.ntiles * NU * NU;
   w.ctl = (GlCtl*)(w.dn + 128);
   w.res = (int32_t*)(w.dn + 128 + 32);
+  w.hg = (unsigned long long*)(w.dn + 128 + 32 + 16);      // 8-byte aligned: every block above is a multiple of 2 floats
+  w.hhash = w.hg + 64;
+  w.hist = (unsigned char*)(w.hhash + GL_HIST);
   return w;
 }
 
-// control word after an iteration whose squared norms are in dn (:361-383)
-__device__ __forceinline__ GlCtl gl_advance(GlCtl c, const float* dn, int G, const ttdg_gagm_cfg_t& cfg) {
-  if (c.done) return c;
-  float s1 = 0.f, s2 = 0.f;
-  for (int g = 0; g < G; ++g) { s1 += dn[2 * g]; s2 += dn[2 * g + 1]; }
-  ++c.it; ++c.total;
-  if (sqrtf(s1) < cfg.tol || s2 == 0.f || c.it >= cfg.max_iter) {
-    if (c.stage < 6) c.iters[c.stage] = c.it;
-    ++c.stage; c.it = 0;
-    if (c.hung) c.done = 1;                                                // :374-376
-    else if (cfg.max_stages > 0 && c.stage >= cfg.max_stages) c.done = 1;
-    else if (c.tau > cfg.min_tau) c.tau *= cfg.gamma;                      // :377-379
-    else c.hung = 1;                                                       // :382-383
+// Control word at the start of iteration t: the stored word of iteration t-1 advanced by the norms (and, in the Hungarian
+// stage, the state hash) its projection left behind (:361-383).  Called by every thread of a workgroup; every workgroup
+// of a launch derives the same word; `store` (one workgroup per launch) persists it for the projection launch.
+__device__ __forceinline__ GlCtl gl_control(const GlWs& w, int G, const ttdg_gagm_cfg_t& cfg, int t, bool store) {
+  __shared__ GlCtl s_ctl;
+  __shared__ int s_prev, s_i, s_ok;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    GlCtl c = w.ctl[t & 1];
+    s_prev = -1; s_ok = 1; s_i = 0;
+    if (t > 0 && !c.done) {
+      float s1 = 0.f, s2 = 0.f;
+      for (int g = 0; g < G; ++g) { s1 += w.dn[2 * g]; s2 += w.dn[2 * g + 1]; }
+      const int i = c.it;          // index of the iteration just finished inside its stage
+      ++c.it; ++c.total;
+      const bool conv = sqrtf(s1) < cfg.tol || s2 == 0.f;
+      if (conv || c.it >= cfg.max_iter) {
+        if (c.stage < 6) c.iters[c.stage] = c.it;
+        ++c.stage; c.it = 0;
+        if (c.hung) c.done = 1;                                                // :374-376
+        else if (cfg.max_stages > 0 && c.stage >= cfg.max_stages) c.done = 1;
+        else if (c.tau > cfg.min_tau) c.tau *= cfg.gamma;                      // :377-379
+        else c.hung = 1;                                                       // :382-383
+      } else if (c.hung && !cfg.no_cycle_skip && i < GL_HIST) {
+        unsigned long long h = 0ull;
+        for (int g = 0; g < G; ++g) h ^= w.hg[g];
+        if (store) w.hhash[i] = h;
+        for (int k = i - 1; k >= 0; --k)
+          if (w.hhash[k] == h) { s_prev = k; s_i = i; break; }                  // most recent earlier state with this hash
+      }
+    }
+    s_ctl = c;
   }
-  return c;
+  __syncthreads();
+  if (s_prev >= 0) {   // exact check of the candidate (a hash collision must not jump), all threads
+    const unsigned char* ha = w.hist + (size_t)s_prev * w.M;
+    const unsigned char* hb = w.hist + (size_t)s_i * w.M;
+    for (int e = tid; e < w.M; e += blockDim.x) if (ha[e] != hb[e]) s_ok = 0;
+    __syncthreads();
+    if (tid == 0 && s_ok) {
+      const int i = s_i, p = i - s_prev;
+      if (p >= 3) {                                  // periods 1 and 2 are the reference's own exits
+        GlCtl c = s_ctl;
+        const int R = cfg.max_iter - 1 - i;          // iterations the reference would still run
+        c.jump = 1 + (i - p + (R % p));              // the state iteration max_iter-1 lands on
+        c.cyc_p = p; c.cyc_i = i;
+        c.total += R;
+        if (c.stage < 6) c.iters[c.stage] = cfg.max_iter;
+        ++c.stage; c.it = 0; c.done = 1;
+        s_ctl = c;
+      }
+    }
+    __syncthreads();
+  }
+  if (store && tid == 0) w.ctl[(t + 1) & 1] = s_ctl;
+  return s_ctl;
 }
 
 __global__ __launch_bounds__(256) void gagm_large_init_kernel(const float* __restrict__ U0, ttdg_gagm_cfg_t cfg, GlWs w) {
@@ -108,7 +164,7 @@ __global__ __launch_bounds__(256) void gagm_large_init_kernel(const float* __res
     GlCtl c;
     c.done = 0; c.stage = 0; c.hung = cfg.start_hungarian != 0; c.it = 0; c.total = 0; c.tau = cfg.tau0;
     for (int k = 0; k < 6; ++k) c.iters[k] = 0;
-    for (int k = 0; k < 4; ++k) c.pad[k] = 0;
+    c.jump = 0; c.cyc_p = 0; c.cyc_i = 0; c.pad = 0;
     w.ctl[0] = c;
     w.ctl[1] = c;
   }
@@ -131,20 +187,13 @@ __device__ __forceinline__ void gl_load_chunk(const float* __restrict__ Asrc, in
 
 __global__ __launch_bounds__(256) void gagm_large_mul_kernel(const float* __restrict__ Apack, const float* __restrict__ W,
                                                              ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg, GlWs w, int t) {
-  __shared__ GlCtl s_ctl;
   __shared__ __attribute__((aligned(16))) float s_a[4 * GL_TILE * 33];   // per-wavefront A tiles, then the 4 accumulator planes
   __shared__ float s_bt[GL_TILE * 33], s_ut[GL_TILE * 33];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, G = gr.G, M = w.M;
   const size_t MU = (size_t)M * NU;
-  if (tid == 0) {
-    GlCtl c = w.ctl[t & 1];
-    if (t > 0) c = gl_advance(c, w.dn, G, cfg);
-    s_ctl = c;
-    if (blockIdx.x == 0 && blockIdx.y == 0) w.ctl[(t + 1) & 1] = c;
-  }
-  __syncthreads();
-  if (s_ctl.done) return;
-  const float* U = w.ring + (size_t)(s_ctl.total % 3) * MU;
+  const GlCtl ctl = gl_control(w, G, cfg, t, blockIdx.x == 0 && blockIdx.y == 0);
+  if (ctl.done) return;
+  const float* U = w.ring + (size_t)(ctl.total % 3) * MU;
 
   int tile = blockIdx.x, g = 0;
   size_t aoff = 0;
@@ -326,26 +375,58 @@ __global__ __launch_bounds__(GL_PTHREADS) void gagm_large_project_kernel(ttdg_gr
     w.dn[2 * g] = a;
     w.dn[2 * g + 1] = b;
   }
+  if (hung && !cfg.no_cycle_skip && s_c.it < GL_HIST) {   // state code + hash for the cycle shortcut (gl_control)
+    __shared__ unsigned long long s_h[GL_PTHREADS / 64];
+    unsigned long long hx = 0ull;
+    for (int r = tid; r < n; r += GL_PTHREADS) {
+      int code = 255;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) if (Unew[r * NU + u] != 0.f) code = u;
+      w.hist[(size_t)s_c.it * M + o + r] = (unsigned char)code;
+      unsigned long long z = (unsigned long long)((o + r) * 256 + code) + 0x9E3779B97F4A7C15ull;     // splitmix64
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      hx ^= z ^ (z >> 31);
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) {
+      const unsigned lo = __shfl_xor((unsigned)hx, sft, 64), hi = __shfl_xor((unsigned)(hx >> 32), sft, 64);
+      hx ^= ((unsigned long long)hi << 32) | lo;
+    }
+    if (lane == 0) s_h[wave] = hx;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long h = 0ull;
+      for (int k = 0; k < GL_PTHREADS / 64; ++k) h ^= s_h[k];
+      w.hg[g] = h;
+    }
+  }
 }
 
 // control word after `t` enqueued iterations -> w.res (what the host polls)
-__global__ void gagm_large_peek_kernel(ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg, GlWs w, int t) {
-  if (threadIdx.x != 0) return;
-  GlCtl c = w.ctl[t & 1];
-  if (t > 0) c = gl_advance(c, w.dn, gr.G, cfg);
-  const int32_t* p = (const int32_t*)&c;
-  for (int k = 0; k < 16; ++k) w.res[k] = p[k];
+__global__ __launch_bounds__(256) void gagm_large_peek_kernel(ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg, GlWs w, int t) {
+  const GlCtl c = gl_control(w, gr.G, cfg, t, false);
+  if (threadIdx.x == 0) {
+    const int32_t* p = (const int32_t*)&c;
+    for (int k = 0; k < 16; ++k) w.res[k] = p[k];
+  }
 }
 
 __global__ __launch_bounds__(256) void gagm_large_finish_kernel(GlWs w, float* __restrict__ Uout, int32_t* __restrict__ info) {
   const GlCtl* c = (const GlCtl*)w.res;
   const size_t MU = (size_t)w.M * NU;
-  const float* U = w.ring + (size_t)(c->total % 3) * MU;
-  for (size_t e = blockIdx.x * 256 + threadIdx.x; e < MU; e += (size_t)gridDim.x * 256) Uout[e] = U[e];
+  if (c->jump > 0) {   // cycle shortcut: the final state is a remembered one
+    const unsigned char* code = w.hist + (size_t)(c->jump - 1) * w.M;
+    for (size_t e = blockIdx.x * 256 + threadIdx.x; e < MU; e += (size_t)gridDim.x * 256) Uout[e] = (code[e >> 5] == (e & 31)) ? 1.f : 0.f;
+  } else {
+    const float* U = w.ring + (size_t)(c->total % 3) * MU;
+    for (size_t e = blockIdx.x * 256 + threadIdx.x; e < MU; e += (size_t)gridDim.x * 256) Uout[e] = U[e];
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     for (int k = 0; k < 6; ++k) info[k] = c->iters[k];
     info[6] = c->total; info[7] = c->stage;
-    for (int k = 8; k < 16; ++k) info[k] = 0;
+    for (int k = 8; k < 14; ++k) info[k] = 0;
+    info[14] = c->cyc_p; info[15] = c->cyc_i;
   }
 }
 
@@ -374,7 +455,7 @@ int ttdg_gagm_large_solve(const float* Apack, const float* W, const float* U0, t
       hipLaunchKernelGGL(gagm_large_mul_kernel, dim3(w.ntiles, w.ks + 1), dim3(256), 0, st, Apack, W, gr, cfg, w, t);
       hipLaunchKernelGGL(gagm_large_project_kernel, dim3(gr.G), dim3(GL_PTHREADS), bytes, st, gr, cfg, w, t);
     }
-    hipLaunchKernelGGL(gagm_large_peek_kernel, dim3(1), dim3(64), 0, st, gr, cfg, w, t);
+    hipLaunchKernelGGL(gagm_large_peek_kernel, dim3(1), dim3(256), 0, st, gr, cfg, w, t);
     if (int e = ttdg_launch_status("gagm_large")) return e;
     TTDG_HIP(hipMemcpyAsync(h, w.res, sizeof(h), hipMemcpyDeviceToHost, st));
     TTDG_HIP(hipStreamSynchronize(st));     // the one convergence read per chunk (the reference reads two norms per iteration)
