@@ -54,6 +54,14 @@ int ttdg_gemm_f32(const float* A, int64_t sam, int64_t sak, const float* B, int6
                   float* C, int64_t scm, int64_t scn, const float* bias, int M, int N, int K,
                   float alpha, float beta, ttdg_stream_t stream);
 
+/* Same product with K split over `kslices` workgroup planes (weight-gradient shapes: few output tiles, K = sum n_g up to
+ * thousands -- the backward of utils/affinity.py:46-47,55).  Deterministic: every slice writes its own M x N plane of
+ * `ws` (ttdg_gemm_splitk_workspace_bytes), a second kernel adds the planes in a fixed order, then bias and beta * C. */
+size_t ttdg_gemm_splitk_workspace_bytes(int M, int N, int kslices);
+int ttdg_gemm_f32_splitk(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbn, int64_t sbk,
+                         float* C, int64_t scm, int64_t scn, const float* bias, int M, int N, int K,
+                         float alpha, float beta, int kslices, void* ws, ttdg_stream_t stream);
+
 /* column sums: out[n] = sum_m X[m*ld + n]  (bias gradients) */
 int ttdg_colsum_f32(const float* X, int64_t ld, float* out, int M, int N, ttdg_stream_t stream);
 
@@ -138,7 +146,9 @@ int ttdg_debug_project(const float* V, int n, int G, float tau, int iters, int r
  * loss = mean over pairs a<b of mean over elements of focal-BCE(clamp(Wds[a,b]), U_a U_b^T).
  * dWds (M x M) is fully written (zero outside the a<b blocks) with d loss / d Wds.
  * flag[0] is set to 1 if any Wds entry of an a<b block is outside [0,1] (losses.py:437-439).
- * pair_ws: G(G-1)/2 floats of scratch (per-pair means, summed in fixed order). */
+ * pair_ws: ttdg_perm_loss_workspace_bytes(gr) of scratch (one partial sum per 64 x 64 tile of every pair block,
+ * added in a fixed order). */
+size_t ttdg_perm_loss_workspace_bytes(ttdg_graphs_t gr);
 int ttdg_perm_loss_fwd_bwd(const float* Wds, const float* U, ttdg_graphs_t gr, float alpha, float eps,
                            float* loss, float* dWds, int32_t* flag, float* pair_ws, ttdg_stream_t stream);
 

@@ -50,6 +50,8 @@ SIGNATURES = {
     "ttdg_version": (C.c_int, []),
     "ttdg_last_error": (C.c_char_p, []),
     "ttdg_gemm_f32": (C.c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _F, _F, _S]),
+    "ttdg_gemm_splitk_workspace_bytes": (C.c_size_t, [_I, _I, _I]),
+    "ttdg_gemm_f32_splitk": (C.c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _F, _F, _I, _P, _S]),
     "ttdg_colsum_f32": (C.c_int, [_P, _L, _P, _I, _I, _S]),
     "ttdg_affinity_pairwise_fwd": (C.c_int, [_P, _P, _P, _I, Graphs, _I, _P, _S]),
     "ttdg_affinity_bwd_workspace_bytes": (C.c_size_t, [_I, _I]),
@@ -63,6 +65,7 @@ SIGNATURES = {
     "ttdg_lap_batched": (C.c_int, [_P, _I, _I, _I, _P, _S]),
     "ttdg_debug_set_lap_variant": (C.c_int, [_I]),
     "ttdg_debug_project": (C.c_int, [_P, _I, _I, _F, _I, _I, _I, _P, _P, _S]),
+    "ttdg_perm_loss_workspace_bytes": (C.c_size_t, [Graphs]),
     "ttdg_perm_loss_fwd_bwd": (C.c_int, [_P, _P, Graphs, _F, _F, _P, _P, _P, _P, _S]),
     "ttdg_node_labels": (C.c_int, [_P, _P, _P, _I, _I, Levels, _P, _S]),
     "ttdg_node_select": (C.c_int, [_P, _I, Levels, _I, _I, _P, _P, _P, _S]),

@@ -261,6 +261,114 @@ __global__ __launch_bounds__(256) void gagm_large_mul_kernel(const float* __rest
 }
 
 #define GL_PTHREADS 1024
+#define GL_PWAVES (GL_PTHREADS / 64)
+
+// ---- Sinkhorn projector of one graph block with n >= 32 nodes: rows = universe (32), columns = nodes -----------------
+// One column per thread, held in registers (32 values): the column sweep is lane-local and exact (in-lane max); the row
+// sweep reduces 33 lines (32 universe rows + the dummy row of multiplicity n - 32) over the workgroup: DPP wavefront
+// reductions, one LDS hop across the 16 wavefronts.  Rows use the previous potential as the stabiliser (after any
+// column sweep y = L - f - g <= 0), the exact row maximum on the first sweep and whenever a row sum leaves
+// [2^-80, 2^80].  Same map as sk_forward (sinkhorn_device.h) on the oriented problem r = 32, c = n, mult = n - 32.
+template <bool kMax>
+__device__ __forceinline__ void gl_reduce33(const float (&val)[33], float* s_part, int wave, int lane) {
+  float mine = 0.f;
+#pragma unroll
+  for (int p = 0; p < 33; ++p) {
+    const float red = kMax ? wave_max_f32_dpp(val[p]) : wave_sum_f32_dpp(val[p]);
+    mine = (lane == p) ? red : mine;
+  }
+  if (lane < 33) s_part[wave * 33 + lane] = mine;
+}
+
+__device__ __forceinline__ void gl_project_cols(const float* __restrict__ Vg, int n, float scale, int iters, float* __restrict__ Unew,
+                                                float* smem) {
+  float* s_f = smem;                    // 33 potentials (index 32 = dummy row) + pad
+  float* s_stab = smem + 36;            // 33 stabilisers of the sweep in flight
+  float* s_part = smem + 72;            // GL_PWAVES x 33 partials
+  int* s_flag = (int*)(s_part + GL_PWAVES * 33);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const bool live = tid < n;            // n <= 768 < GL_PTHREADS: one column per thread
+  const int mult = n - NU;
+  float L[NU];
+  {
+    const float4* row = reinterpret_cast<const float4*>(Vg + (size_t)(live ? tid : 0) * NU);
+#pragma unroll
+    for (int k = 0; k < NU / 4; ++k) {
+      const float4 v = row[k];
+      L[4 * k] = v.x * scale; L[4 * k + 1] = v.y * scale; L[4 * k + 2] = v.z * scale; L[4 * k + 3] = v.w * scale;
+    }
+  }
+  float g = 0.f;
+  if (tid < 36) s_f[tid] = 0.f;
+  __syncthreads();
+  for (int it = 0; it < iters; ++it) {
+    if ((it & 1) == 0) {
+      float val[33];
+      bool exact = (it == 0);
+      for (;;) {
+        if (exact) {   // stabiliser = exact line maximum
+#pragma unroll
+          for (int p = 0; p < NU; ++p) val[p] = live ? L[p] - g : -INFINITY;
+          val[32] = (live && mult > 0) ? SK_DUMMY - g : -INFINITY;
+          gl_reduce33<true>(val, s_part, wave, lane);
+          __syncthreads();
+          if (tid < 33) {
+            float m = -INFINITY;
+            for (int k = 0; k < GL_PWAVES; ++k) m = fmaxf(m, s_part[k * 33 + tid]);
+            s_stab[tid] = (m == -INFINITY) ? 0.f : m;
+          }
+          __syncthreads();
+        } else if (tid < 33) {
+          s_stab[tid] = s_f[tid];
+        }
+        if (!exact) __syncthreads();
+#pragma unroll
+        for (int p = 0; p < NU; ++p) val[p] = live ? fast_exp2(L[p] - g - s_stab[p]) : 0.f;
+        val[32] = (live && mult > 0) ? fast_exp2(SK_DUMMY - g - s_stab[32]) : 0.f;
+        if (tid == 0) *s_flag = 0;
+        gl_reduce33<false>(val, s_part, wave, lane);
+        __syncthreads();
+        if (tid < 33) {
+          float sum = 0.f;
+          for (int k = 0; k < GL_PWAVES; ++k) sum += s_part[k * 33 + tid];
+          const bool used = tid < NU || mult > 0;
+          if (used && !(sum > 8.3e-25f && sum < 1.2e24f)) *s_flag = 1;
+          s_part[tid] = used ? s_stab[tid] + fast_log2(sum) : 0.f;    // candidate, committed below (wave 0 only touches row 0 of s_part)
+        }
+        __syncthreads();
+        const bool redo = !exact && *s_flag != 0;
+        if (!redo && tid < 33) s_f[tid] = s_part[tid];
+        __syncthreads();
+        if (!redo) break;
+        exact = true;
+      }
+    } else {
+      float f[33];
+#pragma unroll
+      for (int p = 0; p < 33; ++p) f[p] = s_f[p];
+      const float td0 = (mult > 0) ? SK_DUMMY - f[32] : -INFINITY;
+      float m0 = td0, m1 = -INFINITY;
+#pragma unroll
+      for (int p = 0; p < NU; p += 2) { m0 = fmaxf(m0, L[p] - f[p]); m1 = fmaxf(m1, L[p + 1] - f[p + 1]); }
+      const float m = fmaxf(m0, m1);
+      float s0 = (mult > 0) ? (float)mult * fast_exp2(td0 - m) : 0.f, s1 = 0.f;
+#pragma unroll
+      for (int p = 0; p < NU; p += 2) { s0 += fast_exp2(L[p] - f[p] - m); s1 += fast_exp2(L[p + 1] - f[p + 1] - m); }
+      g = m + fast_log2(s0 + s1);
+    }
+  }
+  if (live) {
+    float4* out = reinterpret_cast<float4*>(Unew + (size_t)tid * NU);
+#pragma unroll
+    for (int k = 0; k < NU / 4; ++k) {
+      float4 v;
+      v.x = fast_exp2(L[4 * k] - s_f[4 * k] - g); v.y = fast_exp2(L[4 * k + 1] - s_f[4 * k + 1] - g);
+      v.z = fast_exp2(L[4 * k + 2] - s_f[4 * k + 2] - g); v.w = fast_exp2(L[4 * k + 3] - s_f[4 * k + 3] - g);
+      out[k] = v;
+    }
+  }
+}
+
 __global__ __launch_bounds__(GL_PTHREADS) void gagm_large_project_kernel(ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg, GlWs w, int t) {
   extern __shared__ __attribute__((aligned(16))) float gl_smem[];
   __shared__ __attribute__((aligned(16))) float s_S[NU * NU];
@@ -326,12 +434,15 @@ __global__ __launch_bounds__(GL_PTHREADS) void gagm_large_project_kernel(ttdg_gr
     SkProb pb;
     pb.src = Vg; pb.splane = 0; pb.nplanes = 1; pb.bias = 0.f; pb.scale = TTDG_LOG2E / tau;
     const bool rows_nodes = n < NU;
-    if (rows_nodes) { pb.r = n; pb.c = NU; pb.sp = NU; pb.sq = 1; pb.op = NU; pb.oq = 1; }
-    else            { pb.r = NU; pb.c = n; pb.sp = 1; pb.sq = NU; pb.op = 1; pb.oq = NU; }
-    pb.out = Unew; pb.mir = nullptr; pb.mp = pb.mq = 0;
-    pb.mult = pb.c - pb.r;
-    pb.pot = nullptr; pb.potld = 0;
-    sk_forward<true>(pb, gl_smem, cfg.sk_iter);
+    if (rows_nodes) {
+      pb.r = n; pb.c = NU; pb.sp = NU; pb.sq = 1; pb.op = NU; pb.oq = 1;
+      pb.out = Unew; pb.mir = nullptr; pb.mp = pb.mq = 0;
+      pb.mult = pb.c - pb.r;
+      pb.pot = nullptr; pb.potld = 0;
+      sk_forward<true>(pb, gl_smem, cfg.sk_iter);
+    } else {
+      gl_project_cols(Vg, n, pb.scale, cfg.sk_iter, Unew, gl_smem);
+    }
   } else {
     const bool tr = n > NU;
     const int nr = tr ? NU : n, nc = tr ? n : NU;

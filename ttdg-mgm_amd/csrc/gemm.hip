@@ -46,7 +46,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        const float* __restrict__ B, int64_t sbn, int64_t sbk,
                                                        float* __restrict__ C, int64_t scm, int64_t scn,
                                                        const float* __restrict__ bias, int M, int N, int K, float alpha,
-                                                       float beta) {
+                                                       float beta, int Kc, float* __restrict__ part) {
+  // split-K (part != nullptr): blockIdx.z owns k in [z*Kc, (z+1)*Kc) and writes alpha * partial into its own M x N plane
+  // (deterministic; gemm_splitk_reduce_kernel adds the planes, the bias and beta * C)
   __shared__ float As[2][BK][LDS_LD];
   __shared__ float Bs[2][BK][LDS_LD];
   const int tid = threadIdx.x;
@@ -58,15 +60,17 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 
-  const int nk = (K + BK - 1) / BK;
-  stage<a_kc>(As[0], A, sam, sak, m0, 0, M, K, tid);
-  stage<b_kc>(Bs[0], B, sbn, sbk, n0, 0, N, K, tid);
+  const int kbeg = part ? blockIdx.z * Kc : 0;
+  const int kend = part ? min(K, kbeg + Kc) : K;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  stage<a_kc>(As[0], A, sam, sak, m0, kbeg, M, kend, tid);
+  stage<b_kc>(Bs[0], B, sbn, sbk, n0, kbeg, N, kend, tid);
   __syncthreads();
   for (int t = 0; t < nk; ++t) {
     const int cur = t & 1;
     if (t + 1 < nk) {  // prefetch the next slab into the other buffer while this one feeds the MFMAs
-      stage<a_kc>(As[cur ^ 1], A, sam, sak, m0, (t + 1) * BK, M, K, tid);
-      stage<b_kc>(Bs[cur ^ 1], B, sbn, sbk, n0, (t + 1) * BK, N, K, tid);
+      stage<a_kc>(As[cur ^ 1], A, sam, sak, m0, kbeg + (t + 1) * BK, M, kend, tid);
+      stage<b_kc>(Bs[cur ^ 1], B, sbn, sbk, n0, kbeg + (t + 1) * BK, N, kend, tid);
     }
     const int kh = lane >> 5, mi = lane & 31;
 #pragma unroll
@@ -86,6 +90,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     for (int r = 0; r < 16; ++r) {
       const int m = m0 + wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (m < M) {
+        if (part) { part[((size_t)blockIdx.z * M + m) * N + n] = alpha * acc[r]; continue; }
         float* c = C + m * scm + n * scn;
         float v = alpha * acc[r] + bv;
         if (beta != 0.f) v += beta * (*c);
@@ -105,13 +110,57 @@ extern "C" int ttdg_gemm_f32(const float* A, int64_t sam, int64_t sak, const flo
   hipStream_t st = (hipStream_t)stream;
   const bool akc = (sak == 1), bkc = (sbk == 1);
 #define LAUNCH(a, b) \
-  hipLaunchKernelGGL((gemm_f32_kernel<a, b>), grid, dim3(256), 0, st, A, sam, sak, B, sbn, sbk, C, scm, scn, bias, M, N, K, alpha, beta)
+  hipLaunchKernelGGL((gemm_f32_kernel<a, b>), grid, dim3(256), 0, st, A, sam, sak, B, sbn, sbk, C, scm, scn, bias, M, N, K, alpha, beta, 0, (float*)nullptr)
   if (akc && bkc) LAUNCH(true, true);
   else if (akc) LAUNCH(true, false);
   else if (bkc) LAUNCH(false, true);
   else LAUNCH(false, false);
 #undef LAUNCH
   return ttdg_launch_status("gemm_f32");
+}
+
+// ---- split-K variant for weight-gradient shapes (few output tiles, long K: dW = dY^T X with K = sum n_g) ------------
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int kslices, float* __restrict__ C,
+                                                                 int64_t scm, int64_t scn, const float* __restrict__ bias, int M,
+                                                                 int N, float beta) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (size_t)M * N) return;
+  const int m = (int)(e / N), n = (int)(e - (size_t)m * N);
+  float v = 0.f;
+  for (int z = 0; z < kslices; ++z) v += part[(size_t)z * M * N + e];    // fixed order: deterministic
+  if (bias) v += bias[n];
+  float* c = C + m * scm + n * scn;
+  if (beta != 0.f) v += beta * (*c);
+  *c = v;
+}
+
+extern "C" size_t ttdg_gemm_splitk_workspace_bytes(int M, int N, int kslices) {
+  return (size_t)(kslices > 0 ? kslices : 0) * M * N * sizeof(float);
+}
+
+extern "C" int ttdg_gemm_f32_splitk(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbn, int64_t sbk,
+                                    float* C, int64_t scm, int64_t scn, const float* bias, int M, int N, int K, float alpha,
+                                    float beta, int kslices, void* ws, ttdg_stream_t stream) {
+  TTDG_REQUIRE(A && B && C && ws, "gemm_splitk: null operand");
+  TTDG_REQUIRE(M >= 0 && N >= 0 && K >= 0 && kslices >= 1 && kslices <= 64, "gemm_splitk: bad size");
+  if (M == 0 || N == 0) return 0;
+  const int Kc = (((K + kslices - 1) / kslices) + BK - 1) / BK * BK;
+  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, kslices);
+  hipStream_t st = (hipStream_t)stream;
+  const bool akc = (sak == 1), bkc = (sbk == 1);
+  float* part = (float*)ws;
+#define LAUNCH(a, b) \
+  hipLaunchKernelGGL((gemm_f32_kernel<a, b>), grid, dim3(256), 0, st, A, sam, sak, B, sbn, sbk, C, scm, scn, bias, M, N, K, alpha, beta, Kc, part)
+  if (akc && bkc) LAUNCH(true, true);
+  else if (akc) LAUNCH(true, false);
+  else if (bkc) LAUNCH(false, true);
+  else LAUNCH(false, false);
+#undef LAUNCH
+  if (int e = ttdg_launch_status("gemm_f32_splitk")) return e;
+  const size_t total = (size_t)M * N;
+  hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, kslices, C, scm, scn, bias,
+                     M, N, beta);
+  return ttdg_launch_status("gemm_splitk_reduce");
 }
 
 // ---- column sums (bias gradients): out[n] = sum_m X[m, n] ------------------------------------------

@@ -6,36 +6,72 @@
 //   p = clamp(s, eps, 1-eps);  l = -alpha (1-p)^2 t log p - (1-alpha) p^2 (1-t) log(1-p)
 //   loss = (1/#pairs) * sum_pairs mean_elements(l)
 // The Hungarian solve the reference also runs on every s (:626) feeds only the unused 'perm_mat_list'
-// and is skipped.  One workgroup per pair, fixed-order tree reduction (deterministic); a one-thread
-// epilogue adds the per-pair means.  dWds gets d loss / d Wds on the a<b blocks (clamp gradient is 1
-// on [eps, 1-eps], 0 outside, as torch.clamp).
+// and is skipped.  One workgroup per 64 x 64 tile of a pair block (the two 64 x 32 slabs of U staged in LDS, the
+// thread's U_b row in registers, coalesced Wds / dWds rows), fixed-order reductions (deterministic): per-tile partial
+// sums, then a one-workgroup epilogue adds tiles per pair and the per-pair means.  dWds gets d loss / d Wds on the
+// a<b blocks (clamp gradient is 1 on [eps, 1-eps], 0 outside, as torch.clamp).
 #include "common.h"
+
+#define PL_TILE 64
+
+static inline int pl_tiles(int n) { return (n + PL_TILE - 1) / PL_TILE; }
+
+__device__ __forceinline__ int pl_tiles_d(int n) { return (n + PL_TILE - 1) / PL_TILE; }
+
+// workgroup index -> (pair, tile): pairs (a<b) ordered (0,1),(0,2),(1,2),(0,3)..., tiles row-major inside a pair
+__device__ __forceinline__ void pl_locate(const ttdg_graphs_t& gr, int wg, int& a, int& b, int& ti, int& tj, int& pair) {
+  pair = 0;
+  for (b = 1; b < gr.G; ++b)
+    for (a = 0; a < b; ++a, ++pair) {
+      const int nt = pl_tiles_d(gr.off[a + 1] - gr.off[a]) * pl_tiles_d(gr.off[b + 1] - gr.off[b]);
+      if (wg < nt) {
+        const int tb = pl_tiles_d(gr.off[b + 1] - gr.off[b]);
+        ti = wg / tb; tj = wg - ti * tb;
+        return;
+      }
+      wg -= nt;
+    }
+}
 
 __global__ __launch_bounds__(256) void perm_loss_pair_kernel(const float* __restrict__ Wds, const float* __restrict__ U,
                                                              ttdg_graphs_t gr, float alpha, float eps,
-                                                             float* __restrict__ pair_loss, float* __restrict__ dWds,
+                                                             float* __restrict__ tile_loss, float* __restrict__ dWds,
                                                              int32_t* __restrict__ flag) {
-  int b = 1, idx = blockIdx.x;  // pairs (a<b) ordered (0,1),(0,2),(1,2),(0,3)...
-  while (idx >= b) { idx -= b; ++b; }
-  const int a = idx;
+  __shared__ __attribute__((aligned(16))) float ua[PL_TILE * TTDG_UNIV];   // rows of graph a: broadcast reads
+  __shared__ float ub[PL_TILE * (TTDG_UNIV + 1)];                          // rows of graph b: one row per lane, odd stride
+  __shared__ float red[4];
+  int a, b, ti, tj, pair;
+  pl_locate(gr, blockIdx.x, a, b, ti, tj, pair);
   const int M = gr.off[gr.G];
   const int na = gr.off[a + 1] - gr.off[a], nb = gr.off[b + 1] - gr.off[b];
   const int npairs = gr.G * (gr.G - 1) / 2;
   const float gscale = 1.f / ((float)npairs * (float)na * (float)nb);
-  __shared__ float red[4];
+  const int i0 = ti * PL_TILE, j0 = tj * PL_TILE;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < PL_TILE * TTDG_UNIV; e += 256) {
+    const int r = e >> 5, u = e & 31;
+    ua[e] = (i0 + r < na) ? U[(size_t)(gr.off[a] + i0 + r) * TTDG_UNIV + u] : 0.f;
+    ub[r * (TTDG_UNIV + 1) + u] = (j0 + r < nb) ? U[(size_t)(gr.off[b] + j0 + r) * TTDG_UNIV + u] : 0.f;
+  }
+  __syncthreads();
+  const int tx = tid & 63, ty = tid >> 6;
+  float uj[TTDG_UNIV];
+#pragma unroll
+  for (int u = 0; u < TTDG_UNIV; ++u) uj[u] = ub[tx * (TTDG_UNIV + 1) + u];
   float acc = 0.f;
   bool bad = false;
-  for (int e = threadIdx.x; e < na * nb; e += 256) {
-    const int i = e / nb, j = e - i * nb;
-    const float* ui = U + (size_t)(gr.off[a] + i) * TTDG_UNIV;
-    const float* uj = U + (size_t)(gr.off[b] + j) * TTDG_UNIV;
-    float t = 0.f;
+  const int j = j0 + tx;
+  for (int rr = 0; rr < PL_TILE / 4; ++rr) {
+    const int il = ty * (PL_TILE / 4) + rr, i = i0 + il;
+    if (i >= na || j >= nb) continue;
+    float t0 = 0.f, t1 = 0.f;
 #pragma unroll
     for (int u = 0; u < TTDG_UNIV; u += 4) {
-      const float4 x = *reinterpret_cast<const float4*>(ui + u);
-      const float4 y = *reinterpret_cast<const float4*>(uj + u);
-      t += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+      const float4 x = *reinterpret_cast<const float4*>(ua + il * TTDG_UNIV + u);
+      t0 = fmaf(x.x, uj[u], t0); t1 = fmaf(x.y, uj[u + 1], t1);
+      t0 = fmaf(x.z, uj[u + 2], t0); t1 = fmaf(x.w, uj[u + 3], t1);
     }
+    const float t = t0 + t1;
     const size_t o = (size_t)(gr.off[a] + i) * M + gr.off[b] + j;
     const float s = Wds[o];
     bad |= !(s >= 0.f && s <= 1.f) || !(t >= 0.f && t <= 1.f);
@@ -48,16 +84,38 @@ __global__ __launch_bounds__(256) void perm_loss_pair_kernel(const float* __rest
     dWds[o] = d * gscale;
   }
   acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  if (__any(bad) && (tid & 63) == 0) atomicOr(flag, 1);
   __syncthreads();
-  if (threadIdx.x == 0) pair_loss[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) / ((float)na * (float)nb);
+  if (tid == 0) tile_loss[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ void perm_loss_finish_kernel(const float* __restrict__ pair_loss, int npairs, float* __restrict__ loss) {
+// loss = (1/#pairs) * sum_pairs (sum of the pair's tiles, in tile order) / (na nb)
+__global__ void perm_loss_finish_kernel(const float* __restrict__ tile_loss, ttdg_graphs_t gr, float* __restrict__ loss) {
   float s = 0.f;
-  for (int p = 0; p < npairs; ++p) s += pair_loss[p];
+  int wg = 0, npairs = 0;
+  for (int b = 1; b < gr.G; ++b)
+    for (int a = 0; a < b; ++a, ++npairs) {
+      const int na = gr.off[a + 1] - gr.off[a], nb = gr.off[b + 1] - gr.off[b];
+      const int nt = pl_tiles_d(na) * pl_tiles_d(nb);
+      float ps = 0.f;
+      for (int k = 0; k < nt; ++k) ps += tile_loss[wg + k];
+      wg += nt;
+      s += ps / ((float)na * (float)nb);
+    }
   *loss = s / (float)npairs;
+}
+
+static int pl_total_tiles(const ttdg_graphs_t& gr) {
+  int t = 0;
+  for (int b = 1; b < gr.G; ++b)
+    for (int a = 0; a < b; ++a) t += pl_tiles(gr.off[a + 1] - gr.off[a]) * pl_tiles(gr.off[b + 1] - gr.off[b]);
+  return t;
+}
+
+extern "C" size_t ttdg_perm_loss_workspace_bytes(ttdg_graphs_t gr) {
+  if (gr.G < 2 || gr.G > TTDG_MAX_GRAPHS) return 0;
+  return (size_t)pl_total_tiles(gr) * sizeof(float);
 }
 
 extern "C" int ttdg_perm_loss_fwd_bwd(const float* Wds, const float* U, ttdg_graphs_t gr, float alpha, float eps,
@@ -66,11 +124,10 @@ extern "C" int ttdg_perm_loss_fwd_bwd(const float* Wds, const float* U, ttdg_gra
   if (int e = ttdg_validate_graphs(gr)) return e;
   TTDG_REQUIRE(gr.G >= 2, "perm_loss: needs at least two graphs");
   const int M = gr.off[gr.G];
-  const int npairs = gr.G * (gr.G - 1) / 2;
   hipStream_t st = (hipStream_t)stream;
   TTDG_HIP(hipMemsetAsync(dWds, 0, (size_t)M * M * sizeof(float), st));
   TTDG_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), st));
-  hipLaunchKernelGGL(perm_loss_pair_kernel, dim3(npairs), dim3(256), 0, st, Wds, U, gr, alpha, eps, pair_ws, dWds, flag);
-  hipLaunchKernelGGL(perm_loss_finish_kernel, dim3(1), dim3(1), 0, st, pair_ws, npairs, loss);
+  hipLaunchKernelGGL(perm_loss_pair_kernel, dim3(pl_total_tiles(gr)), dim3(256), 0, st, Wds, U, gr, alpha, eps, pair_ws, dWds, flag);
+  hipLaunchKernelGGL(perm_loss_finish_kernel, dim3(1), dim3(1), 0, st, pair_ws, gr, loss);
   return ttdg_launch_status("perm_loss");
 }

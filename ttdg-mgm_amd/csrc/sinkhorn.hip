@@ -13,7 +13,6 @@
 // One workgroup per matrix; a line (row or column) is reduced by a sub-group of 16/32/64 lanes with
 // xor-shuffles; the matrix lives in LDS when it fits (<= 36k floats), otherwise it is re-read from L2.
 #include "sinkhorn_device.h"
-#include "lap_device.h"   // DPP wavefront reductions
 
 // ---- pair stage (multi_graph_matching.py:504-525) --------------------------------------------------
 __device__ __forceinline__ void pair_of(int idx, int G, int& a, int& b) {
@@ -361,9 +360,9 @@ __global__ void sinkhorn_pairs_bwd_kernel(const float* __restrict__ part, int ks
   }
   __syncthreads();
 
-  const int sg = (c > 32) ? 64 : (c > 16 ? 32 : 16);
-  const int sl = tid & (sg - 1), sgi = tid / sg, nsg = nthr / sg;
   for (int k = iters - 1; k >= 0; --k) {
+    const int sg = sk_group((k & 1) ? r : c);
+    const int sl = tid & (sg - 1), sgi = tid / sg, nsg = nthr / sg;
     // potentials as of just after sweep k
     if ((k & 1) == 0) { for (int p = tid; p <= r; p += nthr) if (p < r || mult > 0) f[p] = pt[k * potld + p]; }
     else              { for (int q = tid; q < c; q += nthr) g[q] = pt[k * potld + q]; }

@@ -2,6 +2,7 @@
 // the large-graph GA-MGM solver (gagm_large.hip).  Formulation and citations: see the header of sinkhorn.hip.
 #pragma once
 #include "common.h"
+#include "lap_device.h"   // DPP row operations
 
 
 #define SK_MAXK 64
@@ -29,14 +30,36 @@ __device__ __forceinline__ float sk_load(const SkProb& pb, int p, int q) {
   return v * pb.scale;
 }
 
-__device__ __forceinline__ float sub_max(float v, int sg) {
-  for (int o = sg >> 1; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+// Reductions over aligned sub-groups of sg = 16 / 32 / 64 lanes on DPP row operations (no ds_bpermute round trips):
+// four in-row stages leave every lane of a 16-lane row with the row total; row_bcast15 / row_bcast31 extend it to the
+// last lane of a 32 / 64 group, from where it is broadcast with v_readlane.  Result in every lane of the sub-group.
+// Lanes of other sub-groups may be masked off (ragged line counts): every source lane is in the reader's own sub-group.
+__device__ __forceinline__ float sub_bcast(float v, int sg) {
+  if (sg == 64) return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+  if (sg == 32) {
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    return (threadIdx.x & 32) ? b : a;
+  }
   return v;
+}
+__device__ __forceinline__ float sub_max(float v, int sg) {
+#define OP(C, R) v = fmaxf(v, __int_as_float(dpp_mov<C, R>(__float_as_int(v))));
+  OP(0xB1, 0xf) OP(0x4E, 0xf) OP(0x141, 0xf) OP(0x140, 0xf)
+  if (sg >= 32) { OP(0x142, 0xa) }
+  if (sg == 64) { OP(0x143, 0xc) }
+#undef OP
+  return sub_bcast(v, sg);
 }
 __device__ __forceinline__ float sub_sum(float v, int sg) {
-  for (int o = sg >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+#define OP(C, R) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), C, R, 0xf, false));
+  OP(0xB1, 0xf) OP(0x4E, 0xf) OP(0x141, 0xf) OP(0x140, 0xf)
+  if (sg >= 32) { OP(0x142, 0xa) }
+  if (sg == 64) { OP(0x143, 0xc) }
+#undef OP
+  return sub_bcast(v, sg);
 }
+__device__ __forceinline__ int sk_group(int len) { return len > 32 ? 64 : (len > 16 ? 32 : 16); }
 
 // LDS carve (dynamic): [f: cmax+1][g: cmax][mat: r*ldm  (kLds only)]
 template <bool kLds>
@@ -57,9 +80,9 @@ __device__ void sk_forward(const SkProb& pb, float* smem, int iters) {
     }
   __syncthreads();
 
-  const int sg = (c > 32) ? 64 : (c > 16 ? 32 : 16);      // lanes per line
-  const int sl = tid & (sg - 1), sgi = tid / sg, nsg = nthr / sg;
   for (int it = 0; it < iters; ++it) {
+    const int sg = sk_group((it & 1) ? r : c);             // lanes per line: rows hold c entries, columns r
+    const int sl = tid & (sg - 1), sgi = tid / sg, nsg = nthr / sg;
     if ((it & 1) == 0) {
       // rows: f_p = lse_q(L_pq - g_q); the dummy row uses the constant fill
       const int nlines = r + (mult > 0 ? 1 : 0);

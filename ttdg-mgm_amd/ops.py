@@ -19,7 +19,15 @@ KERNEL_TIMERS = None
 # ------------------------------------------------------------------------------------------- GEMM
 def gemm(A, sam, sak, B, sbn, sbk, Cout, scm, scn, M, N, K, bias=None, alpha=1.0, beta=0.0,
          a_off=0, b_off=0, c_off=0):
-    """C[m,n] = alpha * sum_k A(m,k) B(n,k) + bias[n] + beta*C[m,n] (element strides; offsets in elements)."""
+    """C[m,n] = alpha * sum_k A(m,k) B(n,k) + bias[n] + beta*C[m,n] (element strides; offsets in elements).
+    Few output tiles with a long K (weight gradients at cfg-3: 256x256 outputs, K = 2048) go through the split-K entry."""
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    if tiles <= 64 and K >= 1024:
+        ks = max(2, min(16, 256 // tiles, K // 128))
+        ws = torch.empty(ks * M * N, device=Cout.device, dtype=torch.float32)
+        call("ttdg_gemm_f32_splitk", ptr(A) + 4 * a_off, sam, sak, ptr(B) + 4 * b_off, sbn, sbk, ptr(Cout) + 4 * c_off, scm, scn,
+             ptr(bias), M, N, K, float(alpha), float(beta), ks, ptr(ws), stream())
+        return Cout
     call("ttdg_gemm_f32", ptr(A) + 4 * a_off, sam, sak, ptr(B) + 4 * b_off, sbn, sbk, ptr(Cout) + 4 * c_off, scm, scn,
          ptr(bias), M, N, K, float(alpha), float(beta), stream())
     return Cout
@@ -259,7 +267,7 @@ def perm_loss_fwd_bwd(Wds, U, gr, G, alpha=0.25, eps=1e-6):
     loss = torch.empty((), device=Wds.device, dtype=torch.float32)
     dWds = torch.empty(M, M, device=Wds.device, dtype=torch.float32)
     flag = torch.empty(1, device=Wds.device, dtype=torch.int32)
-    pws = torch.empty(G * (G - 1) // 2, device=Wds.device, dtype=torch.float32)
+    pws = torch.empty(max(1, _lib.load().ttdg_perm_loss_workspace_bytes(gr) // 4), device=Wds.device, dtype=torch.float32)
     call("ttdg_perm_loss_fwd_bwd", ptr(Wds), ptr(U), gr, float(alpha), float(eps), ptr(loss), ptr(dWds), ptr(flag),
          ptr(pws), stream())
     return loss, dWds, flag
