@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=64)
+    ap.add_argument("--eval-streams", type=int, default=2, help="concurrent eval batches (HIP streams) in the Dice pass; 1 = sequential")
     ap.add_argument("--free-running", action="store_true", help="use the detector's own boxes instead of teacher forcing")
     ap.add_argument("--bf16-backbone", action="store_true", help="cfg-5 style: bf16 autocast for the backbone only")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (validation on a 1-GPU box)")
@@ -83,11 +84,10 @@ def gpu_run(args, rank, world, device):
             BaselineTrainer.tta_step(model, opt, b)
 
     def evaluate(bs):
+        from ttdg_mgm_amd.engine.trainer import run_eval_batches
         model.eval()
         dice.reset()
-        with torch.no_grad():
-            for b in bs:
-                dice.process(b, model(b))
+        run_eval_batches(model, bs, dice, args.eval_streams)      # independent batches on concurrent HIP streams
         model.train()
         return dice.evaluate()
 

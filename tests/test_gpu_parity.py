@@ -220,7 +220,7 @@ def test_hungarian_ties_and_errors(dev, golden):
         hungarian(torch.zeros(3, device=dev))
 
 
-@pytest.mark.parametrize("shape", [(6, 6), (12, 32), (40, 32), (32, 95), (64, 64), (256, 32), (20, 33)])
+@pytest.mark.parametrize("shape", [(6, 6), (12, 32), (40, 32), (32, 95), (64, 64), (256, 32), (20, 33), (32, 129), (200, 32), (60, 250), (100, 128)])
 def test_lap_batched_vs_scipy_incl_ties(dev, shape):
     import scipy.optimize
     from ttdg_mgm_amd import ops

@@ -454,6 +454,10 @@ __global__ __launch_bounds__(GL_PTHREADS) void gagm_large_project_kernel(ttdg_gr
         const int b = lap_wave_solve_reg<0>(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1);
         wave_sync();
         if (lane < nr) { if (tr) Unew[b * NU + lane] = 1.f; else Unew[lane * NU + b] = 1.f; }
+      } else if (nc <= 256) {   // 2 or 4 columns per lane, still register-resident
+        const int b = nc <= 128 ? lap_wave_solve_regw<2>(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1) : lap_wave_solve_regw<4>(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1);
+        wave_sync();
+        if (lane < nr) { if (tr) Unew[b * NU + lane] = 1.f; else Unew[lane * NU + b] = 1.f; }
       } else {
         LapScratch sc = lap_carve(vl + ((n * 33 + 3) & ~3), nr, nc);
         lap_wave_solve(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1, sc);

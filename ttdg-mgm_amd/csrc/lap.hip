@@ -19,6 +19,12 @@ __global__ __launch_bounds__(64) void lap_batched_kernel(const float* __restrict
     if (lane < nr) { if (tr) o[(size_t)j * C + lane] = 1.f; else o[(size_t)lane * C + j] = 1.f; }
     return;
   }
+  if (nc <= 256 && nr <= 64) {   // wide register-resident solver: 2 or 4 columns per lane
+    const int j = nc <= 128 ? lap_wave_solve_regw<2>(nr, nc, m, tr ? 1 : C, tr ? C : 1) : lap_wave_solve_regw<4>(nr, nc, m, tr ? 1 : C, tr ? C : 1);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    if (lane < nr) { if (tr) o[(size_t)j * C + lane] = 1.f; else o[(size_t)lane * C + j] = 1.f; }
+    return;
+  }
   LapScratch sc = lap_carve(lap_smem, nr, nc);
   lap_wave_solve(nr, nc, m, tr ? 1 : C, tr ? C : 1, sc);
   wave_sync();

@@ -272,3 +272,104 @@ __device__ __forceinline__ int lap_wave_solve_reg(int nr, int nc, const float* v
   }
   return col4row;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Register-resident variant for 64 < nc <= 64*CW columns (graphs of up to 256 nodes against the 32-slot universe,
+// solved transposed: nr = 32 rows, nc = n columns).  Lane l owns the CW columns l, l+64, ...; everything else as in
+// lap_wave_solve_reg: same steps, same tie rules on scipy's `remaining` positions, same fp64 evaluation order.
+template <int CW>
+__device__ __forceinline__ int lap_wave_solve_regw(int nr, int nc, const float* val, int si, int sj) {
+  const int lane = threadIdx.x & 63;
+  double u = 0.0;
+  int col4row = -1;
+  double v[CW], spc[CW];
+  int row4col[CW], path[CW], pos[CW];
+  bool is_col[CW];
+#pragma unroll
+  for (int w = 0; w < CW; ++w) { v[w] = 0.0; spc[w] = INFINITY; row4col[w] = -1; path[w] = -1; pos[w] = 0; is_col[w] = lane + 64 * w < nc; }
+  for (int cur = 0; cur < nr; ++cur) {
+    double minVal = 0.0;
+    int nrem = nc, i = cur, sink = -1;
+    bool active[CW], SC[CW], SR = false;
+#pragma unroll
+    for (int w = 0; w < CW; ++w) { active[w] = is_col[w]; SC[w] = false; pos[w] = nc - 1 - (lane + 64 * w); spc[w] = INFINITY; }
+    while (sink == -1) {
+      if (lane == i) SR = true;
+      const double ui = readlane_f64(u, i);
+      double lmin = INFINITY;
+#pragma unroll
+      for (int w = 0; w < CW; ++w)
+        if (active[w]) {
+          const double r = minVal + (-(double)val[i * si + (lane + 64 * w) * sj]) - ui - v[w];
+          if (r < spc[w]) { path[w] = i; spc[w] = r; }
+          lmin = fmin(lmin, spc[w]);
+        }
+      const double gmin = wave_min_f64_dpp(lmin);
+      bool is_min[CW];
+      unsigned long long mm[CW];
+      int cnt = 0;
+#pragma unroll
+      for (int w = 0; w < CW; ++w) { is_min[w] = active[w] && spc[w] == gmin; mm[w] = __ballot(is_min[w]); cnt += __builtin_popcountll(mm[w]); }
+      int wsel = 0, lsel = 0;
+      if (cnt == 1) {                                   // unique minimum: no tie rule needed (the common case)
+#pragma unroll
+        for (int w = 0; w < CW; ++w) if (mm[w]) { wsel = w; lsel = __builtin_ctzll(mm[w]); }
+      } else {
+        bool anyun = false;
+        int lmaxp = -1, lminp = 0x7fffffff;
+#pragma unroll
+        for (int w = 0; w < CW; ++w) {
+          const bool un = is_min[w] && row4col[w] == -1;
+          anyun |= __ballot(un) != 0ull;
+          if (un) lmaxp = max(lmaxp, pos[w]);
+          if (is_min[w]) lminp = min(lminp, pos[w]);
+        }
+        const int selpos = anyun ? wave_max_i32_dpp(lmaxp) : wave_min_i32_dpp(lminp);
+#pragma unroll
+        for (int w = 0; w < CW; ++w) {
+          const unsigned long long m = __ballot(active[w] && pos[w] == selpos);
+          if (m) { wsel = w; lsel = __builtin_ctzll(m); }
+        }
+      }
+      int selpos2 = 0, owner = -1;
+#pragma unroll
+      for (int w = 0; w < CW; ++w)
+        if (w == wsel) { selpos2 = __builtin_amdgcn_readlane(pos[w], lsel); owner = __builtin_amdgcn_readlane(row4col[w], lsel); }
+      minVal = gmin;
+#pragma unroll
+      for (int w = 0; w < CW; ++w) {
+        if (w == wsel && lane == lsel) { SC[w] = true; active[w] = false; }
+        else if (active[w] && pos[w] == nrem - 1) pos[w] = selpos2;
+      }
+      --nrem;
+      if (owner == -1) sink = lsel + 64 * wsel; else i = owner;
+    }
+    // dual updates (u of the rows on the alternating tree, v of the scanned columns)
+    const int c4r = (col4row >= 0) ? col4row : 0;
+    double spc_of_my_col = 0.0;
+#pragma unroll
+    for (int w = 0; w < CW; ++w) {
+      const double x = __shfl(spc[w], c4r & 63, 64);
+      if ((c4r >> 6) == w) spc_of_my_col = x;
+    }
+    if (lane == cur) u += minVal;
+    else if (SR) u += minVal - spc_of_my_col;
+#pragma unroll
+    for (int w = 0; w < CW; ++w) if (SC[w]) v[w] -= minVal - spc[w];
+    // augment
+    int j = sink;
+    for (;;) {
+      const int wj = j >> 6, lj = j & 63;
+      int r = 0;
+#pragma unroll
+      for (int w = 0; w < CW; ++w) if (w == wj) r = __builtin_amdgcn_readlane(path[w], lj);
+      const int t = __builtin_amdgcn_readlane(col4row, r);
+#pragma unroll
+      for (int w = 0; w < CW; ++w) if (w == wj && lane == lj) row4col[w] = r;
+      if (lane == r) col4row = j;
+      j = t;
+      if (r == cur) break;
+    }
+  }
+  return col4row;
+}
