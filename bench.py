@@ -87,7 +87,12 @@ def gpu_run(args, rank, world, device):
         from ttdg_mgm_amd.engine.trainer import run_eval_batches
         model.eval()
         dice.reset()
-        run_eval_batches(model, bs, dice, args.eval_streams)      # independent batches on concurrent HIP streams
+        if args.eval_streams == 0:        # A/B: the plain inline loop
+            with torch.no_grad():
+                for b in bs:
+                    dice.process(b, model(b))
+        else:
+            run_eval_batches(model, bs, dice, args.eval_streams)      # independent batches on concurrent HIP streams
         model.train()
         return dice.evaluate()
 

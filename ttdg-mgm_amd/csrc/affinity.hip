@@ -4,8 +4,12 @@
 // Linear(512,512)+ReLU+Linear(512,1).  Splitting the first Linear by input half gives the exact identity
 //     M_ij = sum_k w2[k] * relu(P[i,k] + Q[j,k]) + b2,   P = X' W1[:, :256]^T,  Q = Y' W1[:, 256:]^T + b1
 // (SURVEY.md §8a A4).  P and Q are two small GEMMs (gemm.hip, MFMA); what remains is this pairwise
-// reduction: 3 VALU lane-ops (add, max, fma) per (i, j, k), arithmetic intensity ~100 FLOP/B -> fp32
-// VALU bound, not HBM and not MFMA (relu sits between the two contractions).
+// reduction, arithmetic intensity ~100 FLOP/B -> fp32 VALU bound, not HBM and not MFMA (relu sits between the two
+// contractions).  The forward kernel writes relu(x) = (x + |x|) / 2: the linear half separates,
+//     M_ij = sum_k h_k |P_ik + Q_jk|  +  (sum_k h_k P_ik)  +  (sum_k h_k Q_jk) + b2,      h = w2 / 2,
+// so the (i,j,k) loop is one packed add (v_pk_add_f32, two k per instruction) and one fma with the |.| source
+// modifier: 1.5 VALU instructions per (i,j,k) instead of 3 (add, max, fma); the two row sums ride along with the
+// LDS staging (+2 % work).
 //
 // Forward:  workgroup = 64(i) x 64(j) outputs x one K slice, 256 threads, 4x4 register tile per thread
 //           (rows ty+16a, cols tx+16b so that the LDS row stride of 36 words is conflict-free for
@@ -19,6 +23,14 @@
 #define TILE 64
 #define BK 32
 #define LDK (BK + 4)  // 36-word row stride: 16 rows x 4 words hit 64 distinct banks
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// acc + w * |x| in ONE instruction.  Left to itself hipcc materialises |x| with v_and_b32 so that it can pair the
+// multiply-adds into v_pk_fma_f32 (packed operands have no abs modifier): 2 instructions per element instead of 1.5.
+__device__ __forceinline__ float fma_abs(float w, float x, float acc) {
+  asm("v_fma_f32 %0, %1, |%2|, %0" : "+v"(acc) : "v"(w), "v"(x));
+  return acc;
+}
 
 __device__ __forceinline__ bool tile_needed(const ttdg_graphs_t& gr, int i0, int j0, int M) {
   // the tile holds a wanted pair iff graph(last row) >= graph(first col)
@@ -35,6 +47,7 @@ __global__ __launch_bounds__(256) void affinity_fwd_kernel(const float* __restri
   __shared__ __attribute__((aligned(16))) float Ps[TILE][LDK];
   __shared__ __attribute__((aligned(16))) float Qs[TILE][LDK];
   __shared__ __attribute__((aligned(16))) float Ws[BK];
+  __shared__ float Arow[TILE], Brow[TILE];     // sum_k h_k P_ik / Q_jk over this K slice
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   const int kbeg = blockIdx.z * kslice;
 
@@ -43,9 +56,11 @@ __global__ __launch_bounds__(256) void affinity_fwd_kernel(const float* __restri
   for (int a = 0; a < 4; ++a)
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+  float pa[2] = {0.f, 0.f}, qa[2] = {0.f, 0.f};
 
   const int lrow = tid >> 3, lk = (tid & 7) * 4;  // staging map: 8 lanes x float4 cover one 32-wide row
   for (int k0 = kbeg; k0 < kbeg + kslice; k0 += BK) {
+    const float4 wv = *reinterpret_cast<const float4*>(w2 + k0 + lk);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int row = lrow + 32 * r;
@@ -54,29 +69,46 @@ __global__ __launch_bounds__(256) void affinity_fwd_kernel(const float* __restri
       if (j0 + row < M) qv = *reinterpret_cast<const float4*>(Q + (size_t)(j0 + row) * H + k0 + lk);
       *reinterpret_cast<float4*>(&Ps[row][lk]) = pv;
       *reinterpret_cast<float4*>(&Qs[row][lk]) = qv;
+      pa[r] = fmaf(wv.x, pv.x, fmaf(wv.y, pv.y, fmaf(wv.z, pv.z, fmaf(wv.w, pv.w, pa[r]))));
+      qa[r] = fmaf(wv.x, qv.x, fmaf(wv.y, qv.y, fmaf(wv.z, qv.z, fmaf(wv.w, qv.w, qa[r]))));
     }
-    if (tid < BK) Ws[tid] = w2[k0 + tid];
+    if (tid < BK) Ws[tid] = 0.5f * w2[k0 + tid];
     __syncthreads();
 #pragma unroll 2
     for (int kk = 0; kk < BK; kk += 4) {
-      float4 p[4], q[4];
+      f32x2 p[4][2], q[4][2];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) p[a] = *reinterpret_cast<const float4*>(&Ps[ty + 16 * a][kk]);
+      for (int a = 0; a < 4; ++a) {
+        const float4 v = *reinterpret_cast<const float4*>(&Ps[ty + 16 * a][kk]);
+        p[a][0] = (f32x2){v.x, v.y}; p[a][1] = (f32x2){v.z, v.w};
+      }
 #pragma unroll
-      for (int b = 0; b < 4; ++b) q[b] = *reinterpret_cast<const float4*>(&Qs[tx + 16 * b][kk]);
+      for (int b = 0; b < 4; ++b) {
+        const float4 v = *reinterpret_cast<const float4*>(&Qs[tx + 16 * b][kk]);
+        q[b][0] = (f32x2){v.x, v.y}; q[b][1] = (f32x2){v.z, v.w};
+      }
       const float4 w = *reinterpret_cast<const float4*>(&Ws[kk]);
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          acc[a][b] = fmaf(w.x, fmaxf(p[a].x + q[b].x, 0.f), acc[a][b]);
-          acc[a][b] = fmaf(w.y, fmaxf(p[a].y + q[b].y, 0.f), acc[a][b]);
-          acc[a][b] = fmaf(w.z, fmaxf(p[a].z + q[b].z, 0.f), acc[a][b]);
-          acc[a][b] = fmaf(w.w, fmaxf(p[a].w + q[b].w, 0.f), acc[a][b]);
+          const f32x2 x0 = p[a][0] + q[b][0], x1 = p[a][1] + q[b][1];      // v_pk_add_f32
+          acc[a][b] = fma_abs(w.x, x0.x, acc[a][b]);                       // |.| is a free VOP3 source modifier
+          acc[a][b] = fma_abs(w.y, x0.y, acc[a][b]);
+          acc[a][b] = fma_abs(w.z, x1.x, acc[a][b]);
+          acc[a][b] = fma_abs(w.w, x1.y, acc[a][b]);
         }
     }
     __syncthreads();
   }
+  // row sums of the linear half: the 8 lanes that staged a row hold its partial dot products
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) { pa[r] += __shfl_xor(pa[r], o, 64); qa[r] += __shfl_xor(qa[r], o, 64); }
+    if ((tid & 7) == 0) { Arow[lrow + 32 * r] = 0.5f * pa[r]; Brow[lrow + 32 * r] = 0.5f * qa[r]; }
+  }
+  __syncthreads();
   float* out = part + (size_t)blockIdx.z * M * M;
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
@@ -85,7 +117,7 @@ __global__ __launch_bounds__(256) void affinity_fwd_kernel(const float* __restri
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const int j = j0 + tx + 16 * b;
-      if (j < M) out[(size_t)i * M + j] = acc[a][b];
+      if (j < M) out[(size_t)i * M + j] = acc[a][b] + (Arow[ty + 16 * a] + Brow[tx + 16 * b]);
     }
   }
 }

@@ -288,6 +288,8 @@ __device__ __forceinline__ void gl_project_cols(const float* __restrict__ Vg, in
   int* s_flag = (int*)(s_part + GL_PWAVES * 33);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const bool live = tid < n;            // n <= 768 < GL_PTHREADS: one column per thread
+  const int nw = (n + 63) >> 6;         // wavefronts that own columns; the others only keep the barriers company
+  const bool wact = wave < nw;
   const int mult = n - NU;
   float L[NU];
   {
@@ -310,11 +312,11 @@ __device__ __forceinline__ void gl_project_cols(const float* __restrict__ Vg, in
 #pragma unroll
           for (int p = 0; p < NU; ++p) val[p] = live ? L[p] - g : -INFINITY;
           val[32] = (live && mult > 0) ? SK_DUMMY - g : -INFINITY;
-          gl_reduce33<true>(val, s_part, wave, lane);
+          if (wact) gl_reduce33<true>(val, s_part, wave, lane);
           __syncthreads();
           if (tid < 33) {
             float m = -INFINITY;
-            for (int k = 0; k < GL_PWAVES; ++k) m = fmaxf(m, s_part[k * 33 + tid]);
+            for (int k = 0; k < nw; ++k) m = fmaxf(m, s_part[k * 33 + tid]);
             s_stab[tid] = (m == -INFINITY) ? 0.f : m;
           }
           __syncthreads();
@@ -322,15 +324,17 @@ __device__ __forceinline__ void gl_project_cols(const float* __restrict__ Vg, in
           s_stab[tid] = s_f[tid];
         }
         if (!exact) __syncthreads();
-#pragma unroll
-        for (int p = 0; p < NU; ++p) val[p] = live ? fast_exp2(L[p] - g - s_stab[p]) : 0.f;
-        val[32] = (live && mult > 0) ? fast_exp2(SK_DUMMY - g - s_stab[32]) : 0.f;
         if (tid == 0) *s_flag = 0;
-        gl_reduce33<false>(val, s_part, wave, lane);
+        if (wact) {
+#pragma unroll
+          for (int p = 0; p < NU; ++p) val[p] = live ? fast_exp2(L[p] - g - s_stab[p]) : 0.f;
+          val[32] = (live && mult > 0) ? fast_exp2(SK_DUMMY - g - s_stab[32]) : 0.f;
+          gl_reduce33<false>(val, s_part, wave, lane);
+        }
         __syncthreads();
         if (tid < 33) {
           float sum = 0.f;
-          for (int k = 0; k < GL_PWAVES; ++k) sum += s_part[k * 33 + tid];
+          for (int k = 0; k < nw; ++k) sum += s_part[k * 33 + tid];
           const bool used = tid < NU || mult > 0;
           if (used && !(sum > 8.3e-25f && sum < 1.2e24f)) *s_flag = 1;
           s_part[tid] = used ? s_stab[tid] + fast_log2(sum) : 0.f;    // candidate, committed below (wave 0 only touches row 0 of s_part)
@@ -342,7 +346,7 @@ __device__ __forceinline__ void gl_project_cols(const float* __restrict__ Vg, in
         if (!redo) break;
         exact = true;
       }
-    } else {
+    } else if (wact) {
       float f[33];
 #pragma unroll
       for (int p = 0; p < 33; ++p) f[p] = s_f[p];
@@ -388,13 +392,23 @@ __global__ __launch_bounds__(GL_PTHREADS) void gagm_large_project_kernel(ttdg_gr
   float* Unew = w.ring + (size_t)((total + 1) % 3) * MU + (size_t)o * NU;
   const float* Uprev = w.ring + (size_t)((total + 2) % 3) * MU + (size_t)o * NU;
 
-  for (int e = tid; e < NU * NU; e += GL_PTHREADS) {
-    float s = 0.f;
-    for (int tt = 0; tt < w.ntiles; ++tt) s += w.Sp[(size_t)tt * (NU * NU) + e];
-    s_S[e] = s;
+  // S = sum of the tile shares: one element per thread, 16 independent loads in flight per round (the plain
+  // accumulate-as-you-go loop pays one L2 round trip per tile)
+  {
+    const int e = tid;      // GL_PTHREADS == NU * NU
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    for (int t0 = 0; t0 < w.ntiles; t0 += 16) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[k] += (t0 + k < w.ntiles) ? w.Sp[(size_t)(t0 + k) * (NU * NU) + e] : 0.f;
+    }
+    s_S[e] = (((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]))) +
+             (((acc[8] + acc[9]) + (acc[10] + acc[11])) + ((acc[12] + acc[13]) + (acc[14] + acc[15])));
   }
   __syncthreads();
-  // V_g = (2q B_g S + W U) / G: a wavefront takes two rows at a time, B rows broadcast from LDS, S column in registers
+  // V_g = (2q B_g S + W U) / G: a wavefront takes two rows at a time, B rows broadcast from LDS, S column in registers;
+  // the B values and the K-slice planes of 8 row pairs are loaded up front (72 independent loads per thread)
   {
     const int li = lane & 31, kh = lane >> 5;
     float sc[NU];
@@ -402,27 +416,39 @@ __global__ __launch_bounds__(GL_PTHREADS) void gagm_large_project_kernel(ttdg_gr
     for (int k = 0; k < NU; ++k) sc[k] = s_S[k * NU + li];
     const float qw2 = 2.f * cfg.quad_weight, invG = 1.f / (float)G;
     float* br = s_brow + wave * 64;
-    for (int i0 = wave * 2; i0 < n; i0 += 2 * (GL_PTHREADS / 64)) {
-      const int i = i0 + kh;
-      const bool ok = i < n;
-      const size_t idx = (size_t)(o + i) * NU + li;
-      br[lane] = ok ? w.B[idx] : 0.f;
-      wave_sync();
-      float a0 = 0.f, a1 = 0.f;
+    for (int base = 0; base < n; base += 2 * GL_PWAVES * 8) {
+      float bv[8], wu[8];
 #pragma unroll
-      for (int k = 0; k < NU; k += 4) {
-        const float4 b4 = *reinterpret_cast<const float4*>(br + kh * 32 + k);
-        a0 = fmaf(b4.x, sc[k], a0); a1 = fmaf(b4.y, sc[k + 1], a1);
-        a0 = fmaf(b4.z, sc[k + 2], a0); a1 = fmaf(b4.w, sc[k + 3], a1);
+      for (int j = 0; j < 8; ++j) {
+        const int i = base + j * 2 * GL_PWAVES + wave * 2 + kh;
+        const bool ok = i < n;
+        const size_t idx = (size_t)(o + (ok ? i : 0)) * NU + li;
+        bv[j] = ok ? w.B[idx] : 0.f;
+        float p[GL_MAXKS];
+#pragma unroll
+        for (int z = 0; z < GL_MAXKS; ++z) p[z] = (ok && z < w.ks) ? w.WUp[(size_t)z * MU + idx] : 0.f;
+        wu[j] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
       }
-      float wu = 0.f;
-      if (ok) for (int z = 0; z < w.ks; ++z) wu += w.WUp[(size_t)z * MU + idx];
-      const float v = (qw2 * (a0 + a1) + wu) * invG;
-      if (ok) {
-        w.V[idx] = v;
-        if (total == 0) w.V0[idx] = v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = base + j * 2 * GL_PWAVES + wave * 2 + kh;
+        br[lane] = bv[j];
+        wave_sync();
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NU; k += 4) {
+          const float4 b4 = *reinterpret_cast<const float4*>(br + kh * 32 + k);
+          a0 = fmaf(b4.x, sc[k], a0); a1 = fmaf(b4.y, sc[k + 1], a1);
+          a0 = fmaf(b4.z, sc[k + 2], a0); a1 = fmaf(b4.w, sc[k + 3], a1);
+        }
+        const float v = (qw2 * (a0 + a1) + wu[j]) * invG;
+        if (i < n) {
+          const size_t idx = (size_t)(o + i) * NU + li;
+          w.V[idx] = v;
+          if (total == 0) w.V0[idx] = v;
+        }
+        wave_sync();
       }
-      wave_sync();
     }
   }
   __syncthreads();

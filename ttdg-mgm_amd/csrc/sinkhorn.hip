@@ -57,16 +57,17 @@ __global__ void sinkhorn_pairs_fwd_kernel(const float* __restrict__ part, int ks
 
 // ---- register-resident pair stage for 128 < c <= 256 (BASELINE cfg-3: 256-node graphs) ---------------------------------
 // A 256 x 256 fp32 matrix (256 KB) does not fit the 160 KB LDS, but it fits the register file of ONE workgroup:
-// 512 threads x 128 VGPRs.  Wavefront w owns rows [32w, 32w+32), lane l owns columns 4l..4l+3, so
+// 1024 threads x 64 VGPRs.  Wavefront w owns rows [16w, 16w+16), lane l owns columns 4l..4l+3, so
 //   row sweep : 4 in-lane terms + one DPP wavefront reduction per row, no LDS, no barrier;
-//   col sweep : 32 in-lane terms per column, the 8 wavefront partials meet in LDS (one barrier), and every wavefront
+//   col sweep : 16 in-lane terms per column, the 16 wavefront partials meet in LDS (one barrier), and every wavefront
 //               finishes all 256 columns redundantly (no second barrier, identical values everywhere).
 // After the first row+col pair y = L - f - g <= 0, so the previous potential is a valid stabiliser: sweeps >= 2 are
 // single-pass (no max); a line whose sum leaves [2^-80, 2^80] falls back to the exact two-pass form (rows: per row,
 // wavefront-uniform; columns: ballot over the wavefront, the same decision in every wavefront).
-#define SKR_THREADS 512
-#define SKR_WAVES 8
+#define SKR_THREADS 1024
+#define SKR_WAVES 16
 #define SKR_C 256
+#define SKR_RW (SKR_C / SKR_WAVES)   /* rows per wavefront */
 #define SKR_BIG 1.2e24f
 #define SKR_SMALL 8.3e-25f
 
@@ -94,6 +95,67 @@ __device__ __forceinline__ void sk_pair_problem(const float* part, int ksplit, c
   pb.mult = pb.c - pb.r;
 }
 
+
+// One column sweep of the register-resident kernel.  kExact: two-pass (column maximum through LDS first); otherwise the
+// previous potential g is the stabiliser and the return value says whether some column sum left the sane range (the
+// same ballot in every wavefront, so all of them take the exact path together).
+template <bool kExact>
+__device__ __forceinline__ bool skr_col_sweep(const float (&L)[SKR_RW][4], const float (&f)[SKR_RW], const float (&g)[4], float td0,
+                                              int mult, int p0, int q0, int r, int c, int wave,
+                                              float (&s_part)[2][SKR_WAVES * SKR_C], int& buf, float (&gn)[4]) {
+  float sh[4];
+  if (kExact) {
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int i = 0; i < SKR_RW; ++i)
+      if (p0 + i < r) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mx[j] = fmaxf(mx[j], L[i][j] - f[i]);
+      }
+    *reinterpret_cast<float4*>(&s_part[buf][wave * SKR_C + q0]) = make_float4(mx[0], mx[1], mx[2], mx[3]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sh[j] = td0;
+#pragma unroll
+    for (int w = 0; w < SKR_WAVES; ++w) {
+      const float4 v = *reinterpret_cast<const float4*>(&s_part[buf][w * SKR_C + q0]);
+      sh[0] = fmaxf(sh[0], v.x); sh[1] = fmaxf(sh[1], v.y); sh[2] = fmaxf(sh[2], v.z); sh[3] = fmaxf(sh[3], v.w);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (q0 + j >= c) sh[j] = 0.f;
+    buf ^= 1;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sh[j] = g[j];
+  }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < SKR_RW; ++i)
+    if (p0 + i < r) {
+      const float fi = f[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += fast_exp2(L[i][j] - fi - sh[j]);
+    }
+  *reinterpret_cast<float4*>(&s_part[buf][wave * SKR_C + q0]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  __syncthreads();
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int w = 0; w < SKR_WAVES; ++w) {
+    const float4 v = *reinterpret_cast<const float4*>(&s_part[buf][w * SKR_C + q0]);
+    s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+  }
+  buf ^= 1;
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (mult > 0) s[j] += (float)mult * fast_exp2(td0 - sh[j]);
+    const bool live = q0 + j < c;
+    gn[j] = live ? sh[j] + fast_log2(s[j]) : 0.f;
+    bad |= live && !skr_sane(s[j]);
+  }
+  return !kExact && __ballot(bad) != 0ull;
+}
+
 __global__ __launch_bounds__(SKR_THREADS) void sinkhorn_pairs_fwd_reg_kernel(const float* __restrict__ part, int ksplit,
                                                                              const float* __restrict__ b2, ttdg_graphs_t gr, float tau,
                                                                              int iters, float* __restrict__ Wds,
@@ -113,31 +175,31 @@ __global__ __launch_bounds__(SKR_THREADS) void sinkhorn_pairs_fwd_reg_kernel(con
   float* pt = pot ? pot + (size_t)blockIdx.x * iters * potld : nullptr;
   const int r = pb.r, c = pb.c, mult = pb.mult;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave: provably uniform -> scalar row pointers
-  const int p0 = wave * 32, q0 = lane * 4;
+  const int p0 = wave * SKR_RW, q0 = lane * 4;
 
   // branch-free load: clamped (always valid) addresses, every plane's 128 loads in flight together
   const int sq = (int)pb.sq;
   unsigned qo[4];   // 32-bit BYTE offsets: scalar row base + vector offset addressing (blocks span < 4 GB)
 #pragma unroll
   for (int j = 0; j < 4; ++j) qo[j] = (unsigned)(min(q0 + j, c - 1) * sq) * 4u;
-  float L[32][4];   // single plane only (the host routes K-split inputs to the LDS kernel): no loop for LICM to hoist 128 addresses out of
+  float L[SKR_RW][4];   // single plane only (the host routes K-split inputs to the LDS kernel): no loop for LICM to hoist 128 addresses out of
 #pragma unroll
-  for (int i = 0; i < 32; ++i) {   // 128 unconditional loads in flight (clamped addresses); the empty asm keeps them from being sunk into branches
+  for (int i = 0; i < SKR_RW; ++i) {   // 128 unconditional loads in flight (clamped addresses); the empty asm keeps them from being sunk into branches
     const char* rowp = reinterpret_cast<const char*>(pb.src + (int64_t)min(p0 + i, r - 1) * pb.sp);
 #pragma unroll
     for (int j = 0; j < 4; ++j) L[i][j] = *reinterpret_cast<const float*>(rowp + qo[j]);
   }
 #pragma unroll
-  for (int i = 0; i < 32; ++i)
+  for (int i = 0; i < SKR_RW; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(L[i][j]));
 #pragma unroll
-  for (int i = 0; i < 32; ++i)
+  for (int i = 0; i < SKR_RW; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) L[i][j] = (p0 + i < r && q0 + j < c) ? (L[i][j] + pb.bias) * pb.scale : -INFINITY;
-  float f[32], g[4] = {0.f, 0.f, 0.f, 0.f}, fd = 0.f;
+  float f[SKR_RW], g[4] = {0.f, 0.f, 0.f, 0.f}, fd = 0.f;
 #pragma unroll
-  for (int i = 0; i < 32; ++i) f[i] = 0.f;
+  for (int i = 0; i < SKR_RW; ++i) f[i] = 0.f;
   int buf = 0;
 
   for (int it = 0; it < iters; ++it) {
@@ -145,7 +207,7 @@ __global__ __launch_bounds__(SKR_THREADS) void sinkhorn_pairs_fwd_reg_kernel(con
       // ---- rows: f_p = lse_q(L_pq - g_q) ----
       float flog = 0.f;
 #pragma unroll
-      for (int i = 0; i < 32; ++i) {
+      for (int i = 0; i < SKR_RW; ++i) {
         if (p0 + i < r) {
           const float t0 = L[i][0] - g[0], t1 = L[i][1] - g[1], t2 = L[i][2] - g[2], t3 = L[i][3] - g[3];
           float sh = f[i], s = 0.f;
@@ -174,68 +236,17 @@ __global__ __launch_bounds__(SKR_THREADS) void sinkhorn_pairs_fwd_reg_kernel(con
         fd = skr_sgpr(SK_DUMMY + dm + fast_log2(ds));
       }
       if (pt) {
-        if (lane < 32 && p0 + lane < r) pt[it * potld + p0 + lane] = flog;
+        if (lane < SKR_RW && p0 + lane < r) pt[it * potld + p0 + lane] = flog;
         if (mult > 0 && tid == 0) pt[it * potld + r] = fd;
       }
     } else {
       // ---- cols: g_q = lse over the r real rows and `mult` copies of the dummy row ----
+      // (two straight-line instances instead of a retry loop: the loop form doubles the register pressure)
       const float td0 = (mult > 0) ? SK_DUMMY - fd : -INFINITY;
-      bool exact = it < 2;
       float gn[4];
-      for (;;) {
-        float sh[4];
-        if (exact) {
-          float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-          for (int i = 0; i < 32; ++i)
-            if (p0 + i < r) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) mx[j] = fmaxf(mx[j], L[i][j] - f[i]);
-            }
-          *reinterpret_cast<float4*>(&s_part[buf][wave * SKR_C + q0]) = make_float4(mx[0], mx[1], mx[2], mx[3]);
-          __syncthreads();
-#pragma unroll
-          for (int j = 0; j < 4; ++j) sh[j] = td0;
-#pragma unroll
-          for (int w = 0; w < SKR_WAVES; ++w) {
-            const float4 v = *reinterpret_cast<const float4*>(&s_part[buf][w * SKR_C + q0]);
-            sh[0] = fmaxf(sh[0], v.x); sh[1] = fmaxf(sh[1], v.y); sh[2] = fmaxf(sh[2], v.z); sh[3] = fmaxf(sh[3], v.w);
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) if (q0 + j >= c) sh[j] = 0.f;
-          buf ^= 1;
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) sh[j] = g[j];
-        }
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < 32; ++i)
-          if (p0 + i < r) {
-            const float fi = f[i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] += fast_exp2(L[i][j] - fi - sh[j]);
-          }
-        *reinterpret_cast<float4*>(&s_part[buf][wave * SKR_C + q0]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        __syncthreads();
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int w = 0; w < SKR_WAVES; ++w) {
-          const float4 v = *reinterpret_cast<const float4*>(&s_part[buf][w * SKR_C + q0]);
-          s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-        }
-        buf ^= 1;
-        bool bad = false;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if (mult > 0) s[j] += (float)mult * fast_exp2(td0 - sh[j]);
-          const bool live = q0 + j < c;
-          gn[j] = live ? sh[j] + fast_log2(s[j]) : 0.f;
-          bad |= live && !skr_sane(s[j]);
-        }
-        if (exact || __ballot(bad) == 0ull) break;
-        exact = true;     // the same ballot in every wavefront: all of them redo the sweep in the two-pass form
-      }
+      bool exact = it < 2;
+      if (!exact) exact = skr_col_sweep<false>(L, f, g, td0, mult, p0, q0, r, c, wave, s_part, buf, gn);
+      if (exact) skr_col_sweep<true>(L, f, g, td0, mult, p0, q0, r, c, wave, s_part, buf, gn);
 #pragma unroll
       for (int j = 0; j < 4; ++j) g[j] = gn[j];
       if (pt && wave == 0) {
@@ -248,7 +259,7 @@ __global__ __launch_bounds__(SKR_THREADS) void sinkhorn_pairs_fwd_reg_kernel(con
 #pragma unroll
   for (int j = 0; j < 4; ++j) { oo[j] = (unsigned)((q0 + j) * (int)pb.oq) * 4u; mo[j] = (unsigned)((q0 + j) * (int)pb.mq) * 4u; }
 #pragma unroll
-  for (int i = 0; i < 32; ++i) {
+  for (int i = 0; i < SKR_RW; ++i) {
     const int p = p0 + i;
     if (p < r) {
       char* orow = reinterpret_cast<char*>(pb.out + (int64_t)p * pb.op);
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(SKR_THREADS) void sinkhorn_pairs_bwd_reg_kernel(con
   const int r = pb.r, c = pb.c, mult = pb.mult, potld = cmax + 1;
   const float* pt = pot + (size_t)pair_fwd * iters * potld;
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // wave: provably uniform -> scalar row pointers
-  const int p0 = wave * 32, q0 = lane * 4;
+  const int p0 = wave * SKR_RW, q0 = lane * 4;
   const float bias = pb.bias, scale = pb.scale;
   unsigned qo[4], qd[4], qm[4];   // 32-bit byte offsets of the lane's columns in L / dOut / dM
 #pragma unroll
@@ -453,12 +464,12 @@ __global__ __launch_bounds__(SKR_THREADS) void sinkhorn_pairs_bwd_reg_kernel(con
     qo[j] = (unsigned)(q * (int)pb.sq) * 4u; qd[j] = (unsigned)(q * doq) * 4u; qm[j] = (unsigned)(q * dmq) * 4u;
   }
 
-  float f[32], g[4], fd, dY[32][4], dd[4] = {0.f, 0.f, 0.f, 0.f};
+  float f[SKR_RW], g[4], fd, dY[SKR_RW][4], dd[4] = {0.f, 0.f, 0.f, 0.f};
   // potentials of sweep index kf (rows) / kg (cols); a negative index means "still zero"
 #define SKR_LOAD_POT(kf, kg)                                                                             \
   {                                                                                                      \
-    const float fv = ((kf) >= 0 && lane < 32 && p0 + lane < r) ? pt[(kf) * potld + p0 + lane] : 0.f;     \
-    _Pragma("unroll") for (int i = 0; i < 32; ++i) f[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fv), i)); \
+    const float fv = ((kf) >= 0 && lane < SKR_RW && p0 + lane < r) ? pt[(kf) * potld + p0 + lane] : 0.f;     \
+    _Pragma("unroll") for (int i = 0; i < SKR_RW; ++i) f[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(fv), i)); \
     fd = ((kf) >= 0 && mult > 0) ? pt[(kf) * potld + r] : 0.f;                                           \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) g[j] = ((kg) >= 0 && q0 + j < c) ? pt[(kg) * potld + q0 + j] : 0.f; \
   }
@@ -470,8 +481,8 @@ __global__ __launch_bounds__(SKR_THREADS) void sinkhorn_pairs_bwd_reg_kernel(con
   // dY = dOut * out on the real rows
   skr_load_group(pb, p0, 0, r, qo, Lb[0]);
 #pragma unroll
-  for (int grp = 0; grp < 32 / SKR_GROUP; ++grp) {
-    if (grp + 1 < 32 / SKR_GROUP) skr_load_group(pb, p0, grp + 1, r, qo, Lb[(grp + 1) & 1]);
+  for (int grp = 0; grp < SKR_RW / SKR_GROUP; ++grp) {
+    if (grp + 1 < SKR_RW / SKR_GROUP) skr_load_group(pb, p0, grp + 1, r, qo, Lb[(grp + 1) & 1]);
 #pragma unroll
     for (int a2 = 0; a2 < SKR_GROUP; ++a2) {
       const int i = grp * SKR_GROUP + a2, p = p0 + i;
@@ -495,7 +506,7 @@ __global__ __launch_bounds__(SKR_THREADS) void sinkhorn_pairs_bwd_reg_kernel(con
     if (!rows) {
       float cs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 32; ++i)
+      for (int i = 0; i < SKR_RW; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) cs[j] += dY[i][j];
       *reinterpret_cast<float4*>(&s_part[buf][wave * SKR_C + q0]) = make_float4(cs[0], cs[1], cs[2], cs[3]);
@@ -511,8 +522,8 @@ __global__ __launch_bounds__(SKR_THREADS) void sinkhorn_pairs_bwd_reg_kernel(con
     }
     skr_load_group(pb, p0, 0, r, qo, Lb[0]);
 #pragma unroll
-    for (int grp = 0; grp < 32 / SKR_GROUP; ++grp) {
-      if (grp + 1 < 32 / SKR_GROUP) skr_load_group(pb, p0, grp + 1, r, qo, Lb[(grp + 1) & 1]);
+    for (int grp = 0; grp < SKR_RW / SKR_GROUP; ++grp) {
+      if (grp + 1 < SKR_RW / SKR_GROUP) skr_load_group(pb, p0, grp + 1, r, qo, Lb[(grp + 1) & 1]);
 #pragma unroll
       for (int a2 = 0; a2 < SKR_GROUP; ++a2) {
         const int i = grp * SKR_GROUP + a2;
@@ -542,7 +553,7 @@ __global__ __launch_bounds__(SKR_THREADS) void sinkhorn_pairs_bwd_reg_kernel(con
 #undef SKR_LOAD_POT
   const float inv_tau = 1.f / tau;
 #pragma unroll
-  for (int i = 0; i < 32; ++i) {
+  for (int i = 0; i < SKR_RW; ++i) {
     const int p = p0 + i;
     if (p < r) {
       char* mrow = reinterpret_cast<char*>(dm + (int64_t)p * dmp);
