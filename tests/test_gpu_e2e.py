@@ -101,3 +101,53 @@ def test_eval_pass_and_dice_run_on_device(setup):
     assert len(ev.dice_scores) == sum(counts) and all(0 <= v <= 100 for v in ev.dice_scores)
     assert set(res) == {"Dice Coefficient", "Enhanced Alignment Metric", "Structural Similarity Metric"}
     assert gpu.training is True or gpu.training is False
+
+
+def test_cfg5_polyp_stream_bf16_backbone_fp32_matching():
+    """BASELINE cfg-5 shape of the path: 384x384 3-class polyp-like stream, bf16 autocast for the backbone only, every
+    matching operator in fp32.  Forward in both precisions on the same weights (same node selection, fp32 matching
+    tensors, loss of the same magnitude), then one bf16-backbone adaptation step with fp32 master weights."""
+    from ttdg_mgm_amd import data
+    from ttdg_mgm_amd.config import get_cfg
+    from ttdg_mgm_amd.engine import BaselineTrainer, inference_on_dataset
+    from ttdg_mgm_amd.evaluation import DiceEvaluator
+    from ttdg_mgm_amd.modeling import calibrate_frozen_bn
+    cfg = get_cfg()
+    cfg.TEST.BATCH = 4
+    cfg.INPUT.MIN_SIZE_TEST = 384
+    cfg.MODEL.ROI_HEADS.NUM_CLASSES = 3
+    cfg.MODEL.DEVICE = "cuda:0"
+    data.register_synthetic("cfg5_ds", 8, size=384, cfg_id=5, kind="polyp", num_cls=3)
+    cfg.DATASETS.TEST = ["cfg5_ds"]
+    torch.manual_seed(0)
+    model = BaselineTrainer.build_model(cfg)
+    model.teacher_forced = True
+    BaselineTrainer.rank, BaselineTrainer.world, BaselineTrainer.device = 0, 1, torch.device("cuda:0")
+    batches = list(BaselineTrainer.build_test_loader(cfg, "cfg5_ds"))
+    calibrate_frozen_bn(model, batches[0])
+    ref = copy.deepcopy(model)
+    model.autocast_backbone = True
+    model.train(), ref.train()
+    for m in (model, ref):
+        m.multi_matching_unsup.eval()                       # attention dropout off: compare the two precisions directly
+        m.multi_matching_unsup.keep_trace = True
+    l16, _, _, f16 = model(batches[0], branch="TTT")
+    l32, _, _, f32 = ref(batches[0], branch="TTT")
+    assert l16 is not None and l32 is not None
+    t16, t32 = model.multi_matching_unsup.last, ref.multi_matching_unsup.last
+    assert t16["X"].dtype == torch.float32 and t16["Wds"].dtype == torch.float32        # the matching operators stay in fp32
+    assert t16["sizes"] == t32["sizes"]                                                  # boxes, hence node selection, do not depend on the backbone precision
+    rel = float(torch.linalg.norm(t16["X"] - t32["X"]) / torch.linalg.norm(t32["X"]))
+    print("cfg-5: node features bf16 vs fp32 backbone, relative Frobenius error %.3e; loss %.5f vs %.5f" % (rel, float(l16), float(l32)))
+    # a random-init (untrained, un-normalised) ResNet-50 is a chaotic map: 50 bf16 convolutions deep the node features agree
+    # with the fp32 run to one significant digit only (measured 0.30); the check is that the mixed-precision path is
+    # wired correctly (same graph structure, finite fp32 loss of the same magnitude), not a precision claim
+    assert rel <= 0.6, rel
+    assert torch.isfinite(l16) and 0.2 * float(l32) <= float(l16) <= 5.0 * float(l32) + 1e-3
+    opt = BaselineTrainer.build_optimizer(cfg, model)
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    loss = BaselineTrainer.tta_step(model, opt, batches[1])      # one bf16-backbone adaptation step (MIOpen builds its bf16 kernels on first use: slow once)
+    assert loss is not None and torch.isfinite(loss)
+    assert all(v.dtype == torch.float32 for v in model.parameters())                    # fp32 master weights, fp32 SGD
+    assert all(v.grad is None or v.grad.dtype == torch.float32 for v in model.parameters())
+    assert any(not torch.equal(v.detach(), before[k]) for k, v in model.named_parameters() if k.startswith("backbone.bottom_up.res4"))

@@ -39,6 +39,7 @@ class ConvNorm(nn.Conv2d):
     def __init__(self, cin, cout, k, stride=1, padding=0, norm=True):
         super().__init__(cin, cout, k, stride=stride, padding=padding, bias=not norm)
         self.norm = FrozenBatchNorm2d(cout) if norm else None
+        self._wfold = None
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
 
     def forward(self, x):
@@ -47,7 +48,16 @@ class ConvNorm(nn.Conv2d):
         # frozen statistics: fold the per-channel scale into the filter and pass the shift as the conv bias
         # (same arithmetic as conv -> x*scale+shift, one activation-sized pass less in forward and backward)
         scale, shift = self.norm.folded()
-        return F.conv2d(x, self.weight * scale, shift.to(x.dtype), self.stride, self.padding)
+        if self.weight.requires_grad and torch.is_grad_enabled():
+            w = self.weight * scale                  # stays on the autograd tape: the filter is being adapted
+        else:
+            # frozen filter (stem / res2) or the eval pass: the folded filter is a constant until the weights move
+            key = (self.weight._version, self.weight.data_ptr(), self.norm._fold[0])
+            if self._wfold is None or self._wfold[0] != key:
+                with torch.no_grad():
+                    self._wfold = (key, self.weight * scale)
+            w = self._wfold[1]
+        return F.conv2d(x, w, shift.to(x.dtype), self.stride, self.padding)
 
 
 class Stem(nn.Module):
