@@ -156,6 +156,22 @@ def roofline_from_stamps(run, K):
             "note": "single-workgroup latency-bound solver; fp32 VALU peak == fp32 MFMA peak"}
 
 
+def pmc_traffic(kernel, streaming):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate runs, tools/pmc_summary.py -> profiles/r01_bench_pmc.json).  Counters cannot be read
+    from inside the timed process, so this is the recorded figure, not a live one; None when the file is absent.
+    `streaming`: apply the gfx950 x2 correction of FETCH_SIZE for wide coalesced reads."""
+    path = os.path.join(ROOT, "profiles", "r01_bench_pmc.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f).get(kernel)
+    except (OSError, ValueError):
+        return None
+    if not rec:
+        return None
+    return rec["hbm_bytes_per_launch_streaming_corrected" if streaming else "hbm_bytes_per_launch_raw"]
+
+
 def cpu_baseline(args):
     from oracle import tta_cpu
     # intra-op threads: all host cores up to 64 (beyond that torch's CPU conv/GEMM kernels stop scaling on the
@@ -205,11 +221,15 @@ def main():
             "tta_only_images_per_s": images / run["tta"], "dice": run["dice"],
         }
         out["roofline"] = roofline_from_stamps(run, K)
+        if out["roofline"] is not None:
+            out["roofline"]["traffic"] = pmc_traffic("gagm_kernel", False)
+            out["roofline"]["traffic_note"] = ("HBM bytes per launch from profiles/r01_bench_pmc.json (separate rocprofv3 --pmc FETCH_SIZE / "
+                                               "WRITE_SIZE passes of this command): the solver state is LDS-resident, ~0.4 MB per ~18 ms launch")
         sgd = [(a.elapsed_time(b) * 1e-3, nb) for nm, a, b, nb, _ in run["stamps"] if nm == "sgd"]
         if sgd:   # second hand-written kernel with a meaningful hardware bound: the fused SGD step streams 20 B/parameter
             t, nb = sum(x[0] for x in sgd), sum(x[1] for x in sgd)
             out["roofline_other_kernels"] = [{"kernel": "sgd_multi_tensor_kernel", "bound": "hbm", "achieved": nb / t / 1e9,
-                                              "peak": 8000.0, "unit": "GB/s", "frac": nb / t / 8e12, "traffic": None,
+                                              "peak": 8000.0, "unit": "GB/s", "frac": nb / t / 8e12, "traffic": pmc_traffic("sgd_multi_tensor", True),
                                               "launches": len(sgd), "avg_launch_ms": t / len(sgd) * 1e3,
                                               "bytes_per_launch": nb / len(sgd)}]
         if world == 1 and not args.no_cpu_baseline:

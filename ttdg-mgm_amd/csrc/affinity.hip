@@ -275,8 +275,16 @@ __global__ __launch_bounds__(256) void affinity_bwd_finish_kernel(const float* _
   float s = 0.f;
   for (int m = m0 + wave; m < m1; m += 4) {
     const size_t o = (size_t)m * H + k;
+    // all partial planes of this element in flight together (nsplit <= 16), then a fixed-order sum
+    float sp[16], rp[16];
+#pragma unroll
+    for (int z = 0; z < 16; ++z) {
+      sp[z] = (z < nsplit) ? Spart[z * plane + o] : 0.f;
+      rp[z] = (z < nsplit) ? Rpart[z * plane + o] : 0.f;
+    }
     float sv = 0.f, rv = 0.f;
-    for (int z = 0; z < nsplit; ++z) { sv += Spart[z * plane + o]; rv += Rpart[z * plane + o]; }
+#pragma unroll
+    for (int z = 0; z < 16; ++z) { sv += sp[z]; rv += rp[z]; }
     s += P[o] * sv + Q[o] * rv;
     dP[o] = sv * w;
     dQ[o] = rv * w;
@@ -284,17 +292,19 @@ __global__ __launch_bounds__(256) void affinity_bwd_finish_kernel(const float* _
   red[wave][lane] = s;
   __syncthreads();
   if (wave == 0) dw2part[(size_t)blockIdx.y * H + k] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-  if (blockIdx.x == 0) {   // db2 partial of this row chunk: sum of dM[i, j < off[graph(i)]]
+  {   // db2 partial of this (row chunk, column slice): sum of dM[i, j < off[graph(i)]] over j in the workgroup's slice
     __syncthreads();
+    const int jper = (M + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int jb = blockIdx.x * jper, je = min(M, jb + jper);
     float t = 0.f;
     for (int m = m0 + wave; m < m1; m += 4) {
-      const int lim = gr.off[graph_of(gr, m)];
-      for (int j = lane; j < lim; j += 64) t += dM[(size_t)m * M + j];
+      const int lim = min(je, gr.off[graph_of(gr, m)]);
+      for (int j = jb + lane; j < lim; j += 64) t += dM[(size_t)m * M + j];
     }
     t = wave_sum(t);
     if (lane == 0) red[wave][0] = t;
     __syncthreads();
-    if (threadIdx.x == 0) db2part[blockIdx.y] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    if (threadIdx.x == 0) db2part[blockIdx.y * gridDim.x + blockIdx.x] = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
   }
 }
 
@@ -309,7 +319,7 @@ __global__ __launch_bounds__(64) void affinity_bwd_reduce_kernel(const float* __
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     float t = 0.f;
-    for (int c = 0; c < nchunk; ++c) t += db2part[c];
+    for (int c = 0; c < nchunk * (H / 64); ++c) t += db2part[c];      // one partial per (row chunk, column slice)
     *db2 = t;
   }
 }
@@ -325,7 +335,7 @@ static int affinity_bwd_nsplit(int M, int H) {
 
 extern "C" size_t ttdg_affinity_bwd_workspace_bytes(int M, int H) {
   const int ns = affinity_bwd_nsplit(M, H), nchunk = (M + 63) / 64;
-  return ((size_t)2 * ns * M * H + (size_t)nchunk * H + nchunk + 16) * sizeof(float);
+  return ((size_t)2 * ns * M * H + (size_t)nchunk * H + (size_t)nchunk * (H / TILE) + 16) * sizeof(float);
 }
 
 extern "C" int ttdg_affinity_pairwise_bwd(const float* P, const float* Q, const float* w2, const float* dM, int H,
