@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=64)
     ap.add_argument("--eval-streams", type=int, default=2, help="concurrent eval batches (HIP streams) in the Dice pass; 1 = sequential")
+    ap.add_argument("--eval-coalesce", type=int, default=4, help="loader batches merged into one inference call in the Dice pass; 1 = none")
     ap.add_argument("--free-running", action="store_true", help="use the detector's own boxes instead of teacher forcing")
     ap.add_argument("--bf16-backbone", action="store_true", help="cfg-5 style: bf16 autocast for the backbone only")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (validation on a 1-GPU box)")
@@ -92,7 +93,7 @@ def gpu_run(args, rank, world, device):
                 for b in bs:
                     dice.process(b, model(b))
         else:
-            run_eval_batches(model, bs, dice, args.eval_streams)      # independent batches on concurrent HIP streams
+            run_eval_batches(model, bs, dice, args.eval_streams, args.eval_coalesce)      # independent batches: merged calls on concurrent HIP streams
         model.train()
         return dice.evaluate()
 

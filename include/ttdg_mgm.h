@@ -215,6 +215,22 @@ int ttdg_nms(const float* boxes, const int32_t* group, int N, float thr, void* m
 int ttdg_nms_grouped(const float* boxes, const int32_t* seg, int ngroups, int N, int max_group, float thr,
                      void* mask_ws, unsigned char* flags, ttdg_stream_t stream);
 
+/* Fused box pipelines of the stand-in detector (detectron2 Box2BoxTransform.apply_deltas + Boxes.clip + the validity
+ * filters of find_top_rpn_proposals / fast_rcnn_inference [3P]); candidates that fail a filter get score -inf instead of
+ * being compacted away, so every later step keeps static shapes.  sizes: (B, 2) floats = (height, width) per image.
+ * rpn_decode: one FPN level; deltas (B, A*4, H, W) as produced by the head, anchors (H*W*A, 4), idx/score (B, k) = the
+ *   level's top-k over the (h, w, a) raster; writes boxes (B, K, 4) / scores (B, K) at columns [col0, col0 + k).
+ * box_inference: logits (N, C+1), deltas (N, 4C), rois (N, 5) = (image, x1, y1, x2, y2); softmax, per-class decode with
+ *   weights (wx, wy, ww, wh), clip, score > score_thresh; boxes (N, C, 4), scores (N, C).
+ * paste_masks: soft masks (R, S, S) -> (R, H, W) bytes (0/1): bilinear resampling inside boxes (R, 4), >= threshold. */
+int ttdg_rpn_decode(const float* deltas, const float* anchors, const int64_t* idx, const float* score, const float* sizes,
+                    int B, int k, int A, int H, int W, int K, int col0, float* boxes, float* scores, ttdg_stream_t stream);
+int ttdg_box_inference(const float* logits, const float* deltas, const float* rois, const float* sizes, int N, int C,
+                       float wx, float wy, float ww, float wh, float score_thresh, float* boxes, float* scores,
+                       ttdg_stream_t stream);
+int ttdg_paste_masks(const float* masks, const float* boxes, int R, int S, int H, int W, float threshold,
+                     unsigned char* out, ttdg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

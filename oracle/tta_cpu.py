@@ -24,6 +24,71 @@ class _CpuBackend:
     def nms_collect(launched):
         return list(launched)
 
+    # ---- batch-level box pipelines (same interface as ttdg_mgm_amd.ops, detectron2 formulation in plain torch) ----
+    @staticmethod
+    def image_sizes_tensor(sizes, device):
+        return torch.tensor([(float(h), float(w)) for h, w in sizes], dtype=torch.float32, device=device).reshape(-1, 2)
+
+    @staticmethod
+    def rpn_decode(deltas, anchors, idx, score, sizes_t, boxes, scores, col0):
+        from ttdg_mgm_amd.modeling.detector import apply_deltas
+        B, A4, H, W = deltas.shape
+        k = idx.shape[1]
+        dl = deltas.view(B, -1, 4, H, W).permute(0, 3, 4, 1, 2).reshape(B, -1, 4)
+        bx = apply_deltas(dl.gather(1, idx[..., None].expand(-1, -1, 4)).reshape(-1, 4), anchors[idx.reshape(-1)],
+                          (1.0, 1.0, 1.0, 1.0)).reshape(B, k, 4)
+        ok = torch.isfinite(bx).all(-1) & torch.isfinite(score)
+        h, w = sizes_t[:, 0, None], sizes_t[:, 1, None]
+        bx = torch.stack((torch.minimum(bx[..., 0].clamp(min=0), w), torch.minimum(bx[..., 1].clamp(min=0), h),
+                          torch.minimum(bx[..., 2].clamp(min=0), w), torch.minimum(bx[..., 3].clamp(min=0), h)), -1)
+        ok &= (bx[..., 2] - bx[..., 0] > 0) & (bx[..., 3] - bx[..., 1] > 0)
+        boxes[:, col0:col0 + k] = torch.nan_to_num(bx, nan=0.0)
+        scores[:, col0:col0 + k] = torch.where(ok, score, score.new_full((), float("-inf")))
+
+    @staticmethod
+    def nms_batched(boxes, scores, lvl, nlvl, thr, max_group, topk):
+        B, K = scores.shape
+        idx = torch.zeros(B, min(int(topk), K), dtype=torch.int64)
+        counts = []
+        for b in range(B):
+            live = torch.nonzero(scores[b] > float("-inf")).squeeze(1)
+            keep = live[odet.nms(boxes[b][live], scores[b][live], thr, lvl[live])][:idx.shape[1]]
+            idx[b, :len(keep)] = keep
+            counts.append(int(len(keep)))
+        return idx, counts
+
+    @staticmethod
+    def box_inference(logits, deltas, rois, sizes_t, num_classes, weights, score_thresh):
+        from ttdg_mgm_amd.modeling.detector import apply_deltas
+        n = logits.shape[0]
+        scores = torch.softmax(logits, dim=-1)[:, :-1]
+        boxes = apply_deltas(deltas, rois[:, 1:], weights).view(n, num_classes, 4)
+        img = rois[:, 0].long()
+        h, w = sizes_t[img, 0][:, None], sizes_t[img, 1][:, None]
+        boxes = torch.stack((torch.minimum(boxes[..., 0].clamp(min=0), w), torch.minimum(boxes[..., 1].clamp(min=0), h),
+                             torch.minimum(boxes[..., 2].clamp(min=0), w), torch.minimum(boxes[..., 3].clamp(min=0), h)), -1)
+        ok = torch.isfinite(boxes).all(-1).all(-1) & torch.isfinite(scores).all(-1)
+        good = ok[:, None] & (scores > score_thresh)
+        return torch.nan_to_num(boxes, nan=0.0), torch.where(good, scores, scores.new_full((), float("-inf")))
+
+    @staticmethod
+    def nms_ragged(boxes, scores, rois_per_image, num_classes, thr, topk):
+        out, start = [], 0
+        C = num_classes
+        for n in rois_per_image:
+            sc = scores[start:start + n].reshape(-1)
+            bx = boxes[start:start + n].reshape(-1, 4)
+            live = torch.nonzero(sc > float("-inf")).squeeze(1)
+            keep = live[odet.nms(bx[live], sc[live], thr, live % C)][:topk]
+            out.append(keep + start * C)
+            start += n
+        return out
+
+    @staticmethod
+    def paste_masks(masks, boxes, H, W, threshold=0.5):
+        from ttdg_mgm_amd.modeling.detector import paste_masks_in_image_torch
+        return paste_masks_in_image_torch(masks.reshape(masks.shape[0], 1, masks.shape[-2], masks.shape[-1]), boxes, (H, W), threshold)
+
 
 def _model_and_batches(n_steps, batch, size, teacher_forced):
     from ttdg_mgm_amd import data

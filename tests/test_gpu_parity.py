@@ -690,3 +690,95 @@ def test_cfg3_scale_front_end_and_large_solver(dev):
         assert float(blk.sum()) == 32 and float(blk.sum(0).max()) <= 1 and float(blk.sum(1).max()) <= 1
     assert torch.isfinite(loss) and all(torch.isfinite(x.grad).all() for x in dn)
     assert all(torch.isfinite(p.grad).all() for k, p in m.named_parameters() if k.startswith("node_affinity"))
+
+
+# ------------------------------------------------------------------------------------------- N1: fused box pipelines
+def _cpu_backend():
+    from oracle import tta_cpu
+    return tta_cpu._CpuBackend
+
+
+def test_rpn_decode_and_batched_selection_match_host_formulation(dev):
+    """ttdg_rpn_decode + the batch-level (image, level)-grouped NMS / top-k against the detectron2 formulation in plain
+    torch (oracle.tta_cpu._CpuBackend): same boxes, same validity, same kept proposals in the same order."""
+    from ttdg_mgm_amd import ops
+    cb = _cpu_backend()
+    g = synth.gen(7100)
+    B, A = 3, 3
+    shapes, strides, pre, post = [(24, 24), (12, 12), (6, 6)], [4, 8, 16], 300, 200
+    sizes = [(96, 96), (90, 96), (96, 80)]
+    anchors, logits, deltas = [], [], []
+    for (h, w), s in zip(shapes, strides):
+        ys, xs = np.meshgrid(np.arange(h) * s, np.arange(w) * s, indexing="ij")
+        base = np.array([[-8, -4, 8, 4], [-6, -6, 6, 6], [-4, -8, 4, 8]], np.float32) * (s / 4)
+        an = (np.stack((xs, ys, xs, ys), -1).reshape(-1, 1, 4) + base[None]).reshape(-1, 4).astype(np.float32)
+        anchors.append(torch.from_numpy(an))
+        logits.append(synth.normal(g, (B, A, h, w), 1.0))
+        d = synth.normal(g, (B, A * 4, h, w), 0.5)
+        d[0, 0, 0, 0] = float("nan")                        # a non-finite candidate must be dropped, not propagated
+        deltas.append(d)
+    ks = [min(pre, A * h * w) for h, w in shapes]
+    K = sum(ks)
+    lvl = torch.cat([torch.full((k,), l, dtype=torch.int64) for l, k in enumerate(ks)])
+    res = {}
+    for name, be, dv in (("cpu", cb, torch.device("cpu")), ("gpu", ops, dev)):
+        st = be.image_sizes_tensor(sizes, dv)
+        boxes, scores = torch.empty(B, K, 4, device=dv), torch.empty(B, K, device=dv)
+        col = 0
+        for lg, dl, an, k in zip(logits, deltas, anchors, ks):
+            sc, idx = lg.to(dv).permute(0, 2, 3, 1).reshape(B, -1).topk(k, dim=1)
+            be.rpn_decode(dl.to(dv), an.to(dv), idx, sc, st, boxes, scores, col)
+            col += k
+        keep, counts = be.nms_batched(boxes, scores, lvl.to(dv), len(shapes), 0.7, pre, post)
+        res[name] = (boxes.cpu(), scores.cpu(), keep.cpu(), counts)
+    (bc, sc_, kc, cc), (bg, sg, kg, cg) = res["cpu"], res["gpu"]
+    live = sc_ > float("-inf")
+    assert torch.equal(live, sg > float("-inf")) and int((~live).sum()) >= 1
+    assert maxerr(bg[live], bc[live]) <= 1e-3 and torch.equal(sg[live], sc_[live])
+    assert cc == cg
+    for b in range(B):
+        assert torch.equal(kc[b, :cc[b]], kg[b, :cg[b]]), b
+
+
+def test_box_inference_and_ragged_nms_match_host_formulation(dev):
+    from ttdg_mgm_amd import ops
+    cb = _cpu_backend()
+    g = synth.gen(7200)
+    C, per_image, sizes = 3, [40, 25, 0, 33], [(96, 96), (80, 96), (96, 96), (64, 64)]
+    N = sum(per_image)
+    xy = np.abs(synth.normal(g, (N, 2), 30.0).numpy())
+    wh = np.abs(synth.normal(g, (N, 2), 12.0).numpy()) + 2
+    img = np.repeat(np.arange(len(per_image)), per_image).astype(np.float32)
+    rois = torch.from_numpy(np.concatenate((img[:, None], xy, xy + wh), 1).astype(np.float32))
+    logits, deltas = synth.normal(g, (N, C + 1), 2.0), synth.normal(g, (N, 4 * C), 1.0)
+    deltas[3, 1] = float("nan")
+    out = {}
+    for name, be, dv in (("cpu", cb, torch.device("cpu")), ("gpu", ops, dev)):
+        st = be.image_sizes_tensor(sizes, dv)
+        boxes, scores = be.box_inference(logits.to(dv), deltas.to(dv), rois.to(dv), st, C, (10.0, 10.0, 5.0, 5.0), 0.05)
+        flat = be.nms_ragged(boxes, scores, per_image, C, 0.5, 20)
+        out[name] = (boxes.cpu(), scores.cpu(), [f.cpu() for f in flat])
+    (bc, sc_, fc), (bg, sg, fg) = out["cpu"], out["gpu"]
+    live = sc_ > float("-inf")
+    assert torch.equal(live, sg > float("-inf")) and not bool(live[3].any())
+    assert maxerr(bg[live], bc[live]) <= 1e-3 and maxerr(sg[live], sc_[live]) <= 1e-6
+    for a, b in zip(fc, fg):
+        assert torch.equal(a, b)
+    assert len(fg[2]) == 0
+
+
+def test_paste_masks_matches_grid_sample(dev):
+    from ttdg_mgm_amd import ops
+    from ttdg_mgm_amd.modeling.detector import paste_masks_in_image_torch
+    g = synth.gen(7300)
+    R, S, H, W = 9, 28, 96, 80
+    masks = torch.sigmoid(synth.normal(g, (R, 1, S, S), 2.0))
+    xy = np.abs(synth.normal(g, (R, 2), 20.0).numpy())
+    wh = np.abs(synth.normal(g, (R, 2), 25.0).numpy()) + 3
+    boxes = torch.from_numpy(np.concatenate((xy - 5, xy + wh), 1).astype(np.float32))     # some boxes stick out of the image
+    ref = paste_masks_in_image_torch(masks, boxes, (H, W), 0.5)
+    got = ops.paste_masks(masks.to(dev), boxes.to(dev), H, W, 0.5).cpu()
+    assert got.dtype == torch.bool and got.shape == ref.shape
+    # a pixel may flip only where the interpolated value sits within rounding of the threshold
+    assert int((got != ref).sum()) <= 1e-4 * ref.numel()
+    assert int(ref.sum()) > 0

@@ -221,3 +221,145 @@ extern "C" int ttdg_nms_grouped(const float* boxes, const int32_t* seg, int ngro
   hipLaunchKernelGGL(nms_group_sweep_kernel, dim3(ngroups), dim3(64), 0, st, (const unsigned long long*)mask_ws, seg, words, flags);
   return ttdg_launch_status("nms_grouped");
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Fused box pipelines of the stand-in detector.  The torch formulation spends ~40 tiny launches per FPN level and
+// per image on slicing / exp / clamp / isfinite / boolean indexing; the eval pass is bound by exactly those launches.
+
+#define DET_SCALE_CLAMP 4.135166556742356f   /* log(1000 / 16), detectron2 Box2BoxTransform [3P] */
+
+// returns "every coordinate finite before the clip"; `nonan` = "no coordinate is NaN" (what survives torch.clamp)
+__device__ __forceinline__ bool det_decode(float ax1, float ay1, float ax2, float ay2, float dx, float dy, float dw, float dh,
+                                           float wx, float wy, float ww, float wh, float img_h, float img_w, float4& out,
+                                           bool* nonan = nullptr) {
+  const float w = ax2 - ax1, h = ay2 - ay1;
+  const float cx = ax1 + 0.5f * w, cy = ay1 + 0.5f * h;
+  dx /= wx; dy /= wy;
+  dw = fminf(dw / ww, DET_SCALE_CLAMP); dh = fminf(dh / wh, DET_SCALE_CLAMP);
+  const float pcx = dx * w + cx, pcy = dy * h + cy;
+  const float pw = expf(dw) * w, ph = expf(dh) * h;
+  const float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
+  const bool fin = isfinite(x1) && isfinite(y1) && isfinite(x2) && isfinite(y2);
+  if (nonan) *nonan = !(isnan(x1) || isnan(y1) || isnan(x2) || isnan(y2));
+  out = make_float4(fminf(fmaxf(x1, 0.f), img_w), fminf(fmaxf(y1, 0.f), img_h), fminf(fmaxf(x2, 0.f), img_w), fminf(fmaxf(y2, 0.f), img_h));
+  return fin;
+}
+
+// RPN, one FPN level: the top-k anchors of every image (idx into the (h, w, a) raster) are decoded straight from the
+// NCHW head output, clipped to the image, and tested (finite, non-empty); invalid candidates get score -inf.
+//   deltas (B, A*4, H, W), anchors (H*W*A, 4), idx / score (B, k) -> boxes (B, K, 4) and scores (B, K) at column `col0`
+__global__ __launch_bounds__(256) void rpn_decode_kernel(const float* __restrict__ deltas, const float* __restrict__ anchors,
+                                                         const int64_t* __restrict__ idx, const float* __restrict__ score,
+                                                         const float* __restrict__ sizes, int B, int k, int A, int H, int W,
+                                                         int K, int col0, float* __restrict__ boxes, float* __restrict__ scores) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * k) return;
+  const int b = e / k, j = e - b * k;
+  const int64_t id = idx[e];
+  const int a = (int)(id % A), hw = (int)(id / A);
+  const size_t plane = (size_t)H * W;
+  const float* d = deltas + ((size_t)b * A * 4 + (size_t)a * 4) * plane + hw;
+  const float4 an = reinterpret_cast<const float4*>(anchors)[id];
+  float4 o;
+  const bool fin = det_decode(an.x, an.y, an.z, an.w, d[0], d[plane], d[2 * plane], d[3 * plane], 1.f, 1.f, 1.f, 1.f,
+                              sizes[2 * b], sizes[2 * b + 1], o);
+  const float s = score[e];
+  const bool ok = fin && isfinite(s) && (o.z - o.x > 0.f) && (o.w - o.y > 0.f);
+  const size_t oi = (size_t)b * K + col0 + j;
+  reinterpret_cast<float4*>(boxes)[oi] = o;
+  scores[oi] = ok ? s : -INFINITY;
+}
+
+extern "C" int ttdg_rpn_decode(const float* deltas, const float* anchors, const int64_t* idx, const float* score,
+                               const float* sizes, int B, int k, int A, int H, int W, int K, int col0, float* boxes,
+                               float* scores, ttdg_stream_t stream) {
+  TTDG_REQUIRE(deltas && anchors && idx && score && sizes && boxes && scores, "rpn_decode: null pointer");
+  TTDG_REQUIRE(B >= 0 && k >= 0 && A > 0 && H > 0 && W > 0 && col0 >= 0 && col0 + k <= K, "rpn_decode: bad sizes");
+  if (B * k == 0) return 0;
+  hipLaunchKernelGGL(rpn_decode_kernel, dim3((B * k + 255) / 256), dim3(256), 0, (hipStream_t)stream, deltas, anchors, idx, score,
+                     sizes, B, k, A, H, W, K, col0, boxes, scores);
+  return ttdg_launch_status("rpn_decode");
+}
+
+// Box head inference (detectron2 fast_rcnn_inference [3P] up to the NMS): per proposal softmax over C+1 logits, per
+// class box decode with the head's weights, clip, validity (finite row, as the reference drops the whole proposal),
+// score threshold.  Candidates that fail get score -inf.  rois (N, 5) = (image index, x1, y1, x2, y2).
+__global__ __launch_bounds__(256) void box_inference_kernel(const float* __restrict__ logits, const float* __restrict__ deltas,
+                                                            const float* __restrict__ rois, const float* __restrict__ sizes,
+                                                            int N, int C, float wx, float wy, float ww, float wh, float thr,
+                                                            float* __restrict__ boxes, float* __restrict__ scores) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const float* lg = logits + (size_t)n * (C + 1);
+  float m = lg[0];
+  for (int c = 1; c <= C; ++c) m = fmaxf(m, lg[c]);
+  float den = 0.f;
+  for (int c = 0; c <= C; ++c) den += expf(lg[c] - m);
+  const float* r = rois + (size_t)n * 5;
+  const int b = (int)r[0];
+  const float ih = sizes[2 * b], iw = sizes[2 * b + 1];
+  bool allfin = true;
+  for (int c = 0; c < C; ++c) {
+    const float* d = deltas + (size_t)n * 4 * C + 4 * c;
+    float4 o;
+    bool nonan;    // the reference tests isfinite AFTER the clamp: +-inf is clipped to the border and survives, NaN does not
+    det_decode(r[1], r[2], r[3], r[4], d[0], d[1], d[2], d[3], wx, wy, ww, wh, ih, iw, o, &nonan);
+    allfin &= nonan;
+    reinterpret_cast<float4*>(boxes)[(size_t)n * C + c] = o;
+    const float p = expf(lg[c] - m) / den;
+    allfin &= isfinite(p);
+    scores[(size_t)n * C + c] = p;
+  }
+  for (int c = 0; c < C; ++c) {
+    const float p = scores[(size_t)n * C + c];
+    if (!allfin || !(p > thr)) scores[(size_t)n * C + c] = -INFINITY;
+  }
+}
+
+extern "C" int ttdg_box_inference(const float* logits, const float* deltas, const float* rois, const float* sizes, int N,
+                                  int C, float wx, float wy, float ww, float wh, float score_thresh, float* boxes,
+                                  float* scores, ttdg_stream_t stream) {
+  TTDG_REQUIRE(logits && deltas && rois && sizes && boxes && scores && N >= 0 && C >= 1, "box_inference: bad arguments");
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(box_inference_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, deltas, rois, sizes, N,
+                     C, wx, wy, ww, wh, score_thresh, boxes, scores);
+  return ttdg_launch_status("box_inference");
+}
+
+// Mask paste (detectron2 paste_masks_in_image [3P], grid-sample form): soft masks (R, S, S) are resampled bilinearly
+// (align_corners = False, zeros outside) onto the H x W image grid inside their boxes and thresholded.
+__global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restrict__ masks, const float* __restrict__ boxes, int R, int S,
+                                                          int H, int W, float thr, unsigned char* __restrict__ out) {
+  const int r = blockIdx.y;
+  const float4 b = reinterpret_cast<const float4*>(boxes)[r];
+  const float* m = masks + (size_t)r * S * S;
+  unsigned char* o = out + (size_t)r * H * W;
+  const float sx = (float)S / (b.z - b.x), sy = (float)S / (b.w - b.y);
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < H * W; e += gridDim.x * 256) {
+    const int y = e / W, x = e - y * W;
+    // grid_sample coordinates: g = (p + 0.5 - b0) / (b1 - b0) * 2 - 1;  pixel = ((g + 1) * S - 1) / 2
+    const float gx = ((float)x + 0.5f - b.x) / (b.z - b.x) * 2.f - 1.f, gy = ((float)y + 0.5f - b.y) / (b.w - b.y) * 2.f - 1.f;
+    const float fx = ((gx + 1.f) * (float)S - 1.f) * 0.5f, fy = ((gy + 1.f) * (float)S - 1.f) * 0.5f;
+    (void)sx; (void)sy;
+    const float x0f = floorf(fx), y0f = floorf(fy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float lx = fx - x0f, ly = fy - y0f;
+    float v = 0.f;
+    if (fx > -1.f && fx < (float)S && fy > -1.f && fy < (float)S) {
+      const bool xa = x0 >= 0, xb = x0 + 1 < S, ya = y0 >= 0, yb = y0 + 1 < S;
+      const float v00 = (xa && ya) ? m[y0 * S + x0] : 0.f, v01 = (xb && ya) ? m[y0 * S + x0 + 1] : 0.f;
+      const float v10 = (xa && yb) ? m[(y0 + 1) * S + x0] : 0.f, v11 = (xb && yb) ? m[(y0 + 1) * S + x0 + 1] : 0.f;
+      v = (v00 * (1.f - lx) + v01 * lx) * (1.f - ly) + (v10 * (1.f - lx) + v11 * lx) * ly;
+    }
+    o[e] = v >= thr ? 1 : 0;
+  }
+}
+
+extern "C" int ttdg_paste_masks(const float* masks, const float* boxes, int R, int S, int H, int W, float threshold,
+                                unsigned char* out, ttdg_stream_t stream) {
+  TTDG_REQUIRE(masks && boxes && out && R >= 0 && S > 0 && H > 0 && W > 0, "paste_masks: bad arguments");
+  if (R == 0) return 0;
+  const int bx = (H * W + 255) / 256 < 64 ? (H * W + 255) / 256 : 64;
+  hipLaunchKernelGGL(paste_masks_kernel, dim3(bx, R), dim3(256), 0, (hipStream_t)stream, masks, boxes, R, S, H, W, threshold, out);
+  return ttdg_launch_status("paste_masks");
+}

@@ -17,21 +17,40 @@ from ..optim import FusedSGD
 
 
 EVAL_STREAMS = 2      # concurrent eval batches per GPU (HIP streams, one host thread each); 1 = the plain loop
+EVAL_COALESCE = 4     # loader batches merged into one inference call in the Dice pass (eval-mode inference is per image:
+                      # FrozenBN, no cross-image op, so the merge is invisible in the results); 1 = one call per loader batch
 
 
-def run_eval_batches(model, batches, evaluator, streams=None):
+def _eval_group(model, group, evaluator):
+    """One inference call over the images of `group` (a list of loader batches); the evaluator still sees loader batches."""
+    if len(group) == 1:
+        evaluator.process(group[0], model(group[0]))
+        return
+    outs = model([x for b in group for x in b])
+    start = 0
+    for b in group:
+        evaluator.process(b, outs[start:start + len(b)])
+        start += len(b)
+
+
+def run_eval_batches(model, batches, evaluator, streams=None, coalesce=None):
     """Eval-mode forward + evaluator.process over independent batches.  The weights are frozen during the Dice pass, so
     the batches do not depend on each other: they are spread over `streams` HIP streams, each fed by its own host thread
     (the ~2000 small kernels of one inference are launch/latency bound on a single stream, and a thread blocked in one of
-    the few host reads of the detector - NMS keep lists, mask counts - no longer idles the GPU).  Results are identical
-    to the sequential loop up to the order the evaluator receives the batches in."""
+    the few host reads of the detector - NMS keep lists, mask counts - no longer idles the GPU); `coalesce` consecutive
+    loader batches share one inference call (fewer, fatter launches: sized for the GPU, not for the loader).  Results
+    are identical to the sequential loop up to the order the evaluator receives the batches in."""
     streams = EVAL_STREAMS if streams is None else streams
+    coalesce = EVAL_COALESCE if coalesce is None else coalesce
     batches = list(batches)
     dev_is_gpu = next(model.parameters()).is_cuda
+    if not dev_is_gpu:
+        coalesce = 1
+    batches = [batches[i:i + max(1, coalesce)] for i in range(0, len(batches), max(1, coalesce))]     # groups of loader batches
     if streams <= 1 or not dev_is_gpu or len(batches) < 2:
         with torch.no_grad():
-            for inputs in batches:
-                evaluator.process(inputs, model(inputs))
+            for group in batches:
+                _eval_group(model, group, evaluator)
         return
     import threading
     main = torch.cuda.current_stream()
@@ -42,8 +61,8 @@ def run_eval_batches(model, batches, evaluator, streams=None):
         try:
             torch.cuda.set_device(main.device)
             with torch.cuda.stream(side[k]), torch.no_grad():
-                for inputs in batches[k::streams]:
-                    evaluator.process(inputs, model(inputs))
+                for group in batches[k::streams]:
+                    _eval_group(model, group, evaluator)
         except BaseException as e:       # surfaced on the caller's thread
             errors.append(e)
 

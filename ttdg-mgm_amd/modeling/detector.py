@@ -62,6 +62,7 @@ class PseudoLabRPN(nn.Module):
         self.nms_thresh = nms_thresh
         self.in_features = ("p2", "p3", "p4", "p5", "p6")
         self._anchor_cache = {}
+        self._lvl_cache = {}
 
     def _anchors(self, shapes, device):
         key = (tuple(shapes), str(device))
@@ -87,32 +88,30 @@ class PseudoLabRPN(nn.Module):
             raise NotImplementedError("RPN losses belong to source training, not to test-time adaptation")
         feats = [features[f].detach() for f in self.in_features]
         logits, deltas = self.rpn_head(feats)
-        anchors = self._anchors([f.shape[-2:] for f in feats], feats[0].device)
-        N = feats[0].shape[0]
+        dev = feats[0].device
+        anchors = self._anchors([f.shape[-2:] for f in feats], dev)
+        N, L = feats[0].shape[0], len(feats)
         pre, post = self.pre_nms_topk[self.training], self.post_nms_topk[self.training]
-        tb, ts, tl = [], [], []
-        for lvl, (lg, dl, an) in enumerate(zip(logits, deltas, anchors)):
-            lg = lg.permute(0, 2, 3, 1).reshape(N, -1)
-            dl = dl.view(N, -1, 4, dl.shape[-2], dl.shape[-1]).permute(0, 3, 4, 1, 2).reshape(N, -1, 4)
-            k = min(pre, lg.shape[1])
-            sc, idx = lg.topk(k, dim=1)
-            bx = apply_deltas(dl.gather(1, idx[..., None].expand(-1, -1, 4)).reshape(-1, 4),
-                              an[idx.reshape(-1)], (1.0, 1.0, 1.0, 1.0)).reshape(N, k, 4)
-            tb.append(bx), ts.append(sc), tl.append(torch.full((k,), lvl, dtype=torch.int32, device=lg.device))
-        tb, ts, tl = torch.cat(tb, 1), torch.cat(ts, 1), torch.cat(tl, 0)
-        pend = []
-        for n, size in enumerate(images.image_sizes):
-            b = Boxes(tb[n])
-            s, l = ts[n], tl
-            ok = torch.isfinite(b.tensor).all(1) & torch.isfinite(s)
-            b.clip(size)
-            ok &= b.nonempty(0.0)
-            bt, s, l = b.tensor[ok], s[ok], l[ok]
-            pend.append((size, bt, s, _backend.nms_launch(bt, s, self.nms_thresh, l, len(self.in_features), pre, post)))
-        keeps = _backend.nms_collect([p[3] for p in pend])       # one host sync for the whole batch
+        ks = [min(pre, lg.shape[1] * lg.shape[2] * lg.shape[3]) for lg in logits]
+        K = sum(ks)
+        key = (tuple(ks), str(dev))
+        if self._lvl_cache.get("key") != key:
+            self._lvl_cache = {"key": key, "lvl": torch.cat([torch.full((k,), l, dtype=torch.int64, device=dev) for l, k in enumerate(ks)])}
+        lvl = self._lvl_cache["lvl"]
+        sizes_t = _backend.image_sizes_tensor(images.image_sizes, dev)
+        # every candidate of the batch in two dense tensors; rejected ones carry score -inf (no compaction, no per-image loop)
+        boxes = torch.empty(N, K, 4, device=dev, dtype=torch.float32)
+        scores = torch.empty(N, K, device=dev, dtype=torch.float32)
+        col = 0
+        for lg, dl, an, k in zip(logits, deltas, anchors, ks):
+            sc, idx = lg.permute(0, 2, 3, 1).reshape(N, -1).topk(k, dim=1)
+            _backend.rpn_decode(dl, an, idx, sc.float(), sizes_t, boxes, scores, col)      # decode + clip + validity, fused
+            col += k
+        keep, counts = _backend.nms_batched(boxes, scores, lvl, L, self.nms_thresh, pre, post)   # one host sync per batch
         proposals = []
-        for (size, bt, s, _), keep in zip(pend, keeps):
-            proposals.append(Instances(size, proposal_boxes=Boxes(bt[keep]), objectness_logits=s[keep]))
+        for n, size in enumerate(images.image_sizes):
+            sel = keep[n, :counts[n]]
+            proposals.append(Instances(size, proposal_boxes=Boxes(boxes[n, sel]), objectness_logits=scores[n, sel]))
         return proposals, {}
 
 
@@ -122,8 +121,14 @@ class ROIPooler:
         self.min_level, self.max_level = 2, 2 + len(scales) - 1
         self.cbs, self.cl = canonical_box_size, canonical_level
 
-    def __call__(self, feats, box_lists):
-        rois = torch.cat([torch.cat((b.tensor.new_full((len(b), 1), float(i)), b.tensor), 1) for i, b in enumerate(box_lists)], 0)
+    @staticmethod
+    def make_rois(box_lists):
+        """(R, 5) = (image index, x1, y1, x2, y2) for the boxes of a batch."""
+        return torch.cat([torch.cat((b.tensor.new_full((len(b), 1), float(i)), b.tensor), 1) for i, b in enumerate(box_lists)], 0)
+
+    def __call__(self, feats, box_lists, rois=None):
+        if rois is None:
+            rois = self.make_rois(box_lists)
         R = rois.shape[0]
         out = feats[0].new_zeros((R, feats[0].shape[1], self.P, self.P), dtype=torch.float32)
         if R == 0:
@@ -195,27 +200,19 @@ class StandardROIHeadsPseudoLab(nn.Module):
 
     @torch.no_grad()
     def _forward_box(self, feats, proposals):
-        x = self.box_pooler(feats, [p.proposal_boxes for p in proposals])
+        C = self.num_classes
+        rois = ROIPooler.make_rois([p.proposal_boxes for p in proposals])
+        x = self.box_pooler(feats, None, rois)
         logits, deltas = self.box_predictor(self.box_head(x))
-        pend, start = [], 0
-        for p in proposals:
-            n = len(p)
-            lg, dl = logits[start:start + n], deltas[start:start + n]
-            start += n
-            scores = F.softmax(lg, dim=-1)[:, :-1]
-            boxes = apply_deltas(dl, p.proposal_boxes.tensor, self.bbox_weights).view(n, self.num_classes, 4)
-            h, w = p.image_size
-            boxes = torch.stack((boxes[..., 0].clamp(0, w), boxes[..., 1].clamp(0, h), boxes[..., 2].clamp(0, w), boxes[..., 3].clamp(0, h)), -1)
-            ok = torch.isfinite(boxes).all(-1).all(-1) & torch.isfinite(scores).all(-1)
-            boxes, scores = boxes[ok], scores[ok]
-            fm = scores > self.score_thresh
-            idx = fm.nonzero()
-            bsel, ssel = boxes[fm], scores[fm]
-            pend.append((p.image_size, bsel, ssel, idx, _backend.nms_launch(bsel, ssel, self.nms_thresh, idx[:, 1], self.num_classes, None, self.topk)))
-        keeps = _backend.nms_collect([q[4] for q in pend])
+        sizes_t = _backend.image_sizes_tensor([p.image_size for p in proposals], rois.device)
+        # softmax + per-class decode + clip + validity + score threshold for the whole batch, then per-class NMS and the
+        # top-k per image in one pass (rejected candidates carry score -inf; one host sync per batch)
+        boxes, scores = _backend.box_inference(logits, deltas, rois, sizes_t, C, self.bbox_weights, self.score_thresh)
+        flat = _backend.nms_ragged(boxes, scores, [len(p) for p in proposals], C, self.nms_thresh, self.topk)
+        bflat, sflat = boxes.reshape(-1, 4), scores.reshape(-1)
         out = []
-        for (size, bsel, ssel, idx, _), keep in zip(pend, keeps):
-            out.append(Instances(size, pred_boxes=Boxes(bsel[keep]), scores=ssel[keep], pred_classes=idx[keep, 1]))
+        for p, idx in zip(proposals, flat):
+            out.append(Instances(p.image_size, pred_boxes=Boxes(bflat[idx]), scores=sflat[idx], pred_classes=idx % C))
         return out
 
     @torch.no_grad()
@@ -223,12 +220,14 @@ class StandardROIHeadsPseudoLab(nn.Module):
         feats = [features[f].detach() for f in self.mask_in_features]
         x = self.mask_pooler(feats, [i.pred_boxes for i in instances])
         logits = self.mask_head(x)
+        R = logits.shape[0]
+        cls = torch.cat([i.pred_classes for i in instances]) if R else logits.new_zeros(0, dtype=torch.int64)
+        prob = logits[torch.arange(R, device=logits.device), cls].sigmoid()[:, None]     # the predicted class' channel, whole batch
         start = 0
         for inst in instances:
             n = len(inst)
-            lg = logits[start:start + n]
+            inst.pred_masks = prob[start:start + n]
             start += n
-            inst.pred_masks = lg[torch.arange(n, device=lg.device), inst.pred_classes].sigmoid()[:, None]
         return instances
 
     def forward(self, images, features, proposals, targets=None, compute_loss=True, branch=""):
@@ -241,8 +240,9 @@ class StandardROIHeadsPseudoLab(nn.Module):
         return self.forward_with_given_boxes(features, pred), {}
 
 
-def paste_masks_in_image(masks, boxes, image_shape, threshold=0.5):
-    """detectron2 paste_masks_in_image [3P] (grid-sample variant): (R,1,M,M) soft masks -> (R,H,W) bool."""
+def paste_masks_in_image_torch(masks, boxes, image_shape, threshold=0.5):
+    """detectron2 paste_masks_in_image [3P] (grid-sample variant) in plain torch: (R,1,M,M) soft masks -> (R,H,W) bool.
+    Reference formulation for the fused kernel (ops.paste_masks); used by the host-side test harness."""
     H, W = image_shape
     R = masks.shape[0]
     if R == 0:
@@ -260,15 +260,48 @@ def paste_masks_in_image(masks, boxes, image_shape, threshold=0.5):
     return torch.cat(out, 0)
 
 
+def paste_masks_in_image(masks, boxes, image_shape, threshold=0.5):
+    """(R,1,M,M) soft masks -> (R,H,W) bool inside their boxes (one fused launch for all R)."""
+    if masks.shape[0] == 0:
+        return masks.new_zeros((0, image_shape[0], image_shape[1]), dtype=torch.bool)
+    return _backend.paste_masks(masks, boxes, image_shape[0], image_shape[1], threshold)
+
+
+def detector_postprocess_batch(results, out_sizes, mask_threshold=0.5):
+    """detector_postprocess [3P] for a whole batch: rescale + clip + drop empty boxes per image, then ONE mask paste for
+    every image that shares an output size (all of them on this path)."""
+    outs, scaled = [], []
+    for r, (out_h, out_w) in zip(results, out_sizes):
+        sx, sy = out_w / r.image_size[1], out_h / r.image_size[0]
+        boxes = Boxes(r.pred_boxes.tensor.clone())
+        boxes.scale(sx, sy)
+        boxes.clip((out_h, out_w))
+        scaled.append(boxes)
+    keeps = [b.nonempty() for b in scaled]
+    all_keep = bool(torch.cat(keeps).all()) if keeps else True       # one host read; empties only arise from degenerate boxes
+    srcs = []
+    for r, boxes, keep, (out_h, out_w) in zip(results, scaled, keeps, out_sizes):
+        has = r.has("pred_masks")
+        if all_keep:
+            outs.append(Instances((out_h, out_w), pred_boxes=boxes, scores=r.scores, pred_classes=r.pred_classes))
+            srcs.append(r.pred_masks if has else None)
+        else:
+            outs.append(Instances((out_h, out_w), pred_boxes=Boxes(boxes.tensor[keep]), scores=r.scores[keep], pred_classes=r.pred_classes[keep]))
+            srcs.append(r.pred_masks[keep] if has else None)
+    groups = {}
+    for o, m in zip(outs, srcs):
+        if m is not None:
+            groups.setdefault(o.image_size, []).append((o, m))
+    for size, members in groups.items():
+        pasted = paste_masks_in_image(torch.cat([m for _, m in members]), torch.cat([o.pred_boxes.tensor for o, _ in members]),
+                                      size, mask_threshold)
+        start = 0
+        for o, m in members:
+            o.pred_masks = pasted[start:start + m.shape[0]]
+            start += m.shape[0]
+    return outs
+
+
 def detector_postprocess(results, out_h, out_w, mask_threshold=0.5):
-    """Rescale boxes to the original image size and paste masks (detectron2 detector_postprocess [3P])."""
-    sx, sy = out_w / results.image_size[1], out_h / results.image_size[0]
-    boxes = Boxes(results.pred_boxes.tensor.clone())
-    boxes.scale(sx, sy)
-    boxes.clip((out_h, out_w))
-    keep = boxes.nonempty()
-    res = Instances((out_h, out_w), pred_boxes=Boxes(boxes.tensor[keep]), scores=results.scores[keep],
-                    pred_classes=results.pred_classes[keep])
-    if results.has("pred_masks"):
-        res.pred_masks = paste_masks_in_image(results.pred_masks[keep], res.pred_boxes.tensor, (out_h, out_w), mask_threshold)
-    return res
+    """Rescale boxes to the original image size and paste masks (detectron2 detector_postprocess [3P]), one image."""
+    return detector_postprocess_batch([results], [(out_h, out_w)], mask_threshold)[0]

@@ -7,7 +7,7 @@ import torch.nn as nn
 
 from ..GModule import MGM3_unsup, PrototypeComputation, U_sup
 from .backbone import FPN
-from .detector import PseudoLabRPN, StandardROIHeadsPseudoLab, detector_postprocess
+from .detector import PseudoLabRPN, StandardROIHeadsPseudoLab, detector_postprocess, detector_postprocess_batch  # noqa: F401
 from .structures import Boxes, ImageList, Instances
 
 
@@ -45,7 +45,13 @@ class DAobjTwoStagePseudoLabGeneralizedRCNN(nn.Module):
         return self.pixel_mean.device
 
     def preprocess_image(self, batched_inputs):
-        images = [(x["image"].to(self.device, non_blocking=True).float() - self.pixel_mean) / self.pixel_std for x in batched_inputs]
+        raw = [x["image"] for x in batched_inputs]
+        d = self.backbone.size_divisibility
+        if len({tuple(t.shape) for t in raw}) == 1 and raw[0].shape[-2] % max(d, 1) == 0 and raw[0].shape[-1] % max(d, 1) == 0:
+            # one normalisation for the batch (same-size, already divisible images: the test streams of this path)
+            x = torch.stack([t.to(self.device, non_blocking=True) for t in raw]).float()
+            return ImageList((x - self.pixel_mean) / self.pixel_std, [tuple(t.shape[-2:]) for t in raw])
+        images = [(t.to(self.device, non_blocking=True).float() - self.pixel_mean) / self.pixel_std for t in raw]
         return ImageList.from_tensors(images, self.backbone.size_divisibility)
 
     def _backbone(self, x):
@@ -85,10 +91,8 @@ class DAobjTwoStagePseudoLabGeneralizedRCNN(nn.Module):
         results, _ = self.roi_heads(images, features, proposals, None, compute_loss=False, branch="")
         if not do_postprocess:
             return results
-        out = []
-        for r, x in zip(results, batched_inputs):
-            out.append({"instances": detector_postprocess(r, x.get("height", r.image_size[0]), x.get("width", r.image_size[1]))})
-        return out
+        sizes = [(x.get("height", r.image_size[0]), x.get("width", r.image_size[1])) for r, x in zip(results, batched_inputs)]
+        return [{"instances": r} for r in detector_postprocess_batch(results, sizes)]
 
 
 @torch.no_grad()

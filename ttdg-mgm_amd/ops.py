@@ -457,6 +457,121 @@ def nms_collect(launched):
     return [h[1] if h[0] == "empty" else h[1][:next(counts)] for h in launched]
 
 
+_SIZES_CACHE = {}
+
+
+def image_sizes_tensor(sizes, device):
+    """(B, 2) float tensor of (height, width) per image, cached per (sizes, device) - the fused box kernels clip with it."""
+    key = (tuple((int(h), int(w)) for h, w in sizes), str(device))
+    t = _SIZES_CACHE.get(key)
+    if t is None:
+        if len(_SIZES_CACHE) > 64:
+            _SIZES_CACHE.clear()
+        t = torch.tensor(key[0], dtype=torch.float32).reshape(-1, 2).to(device)
+        _SIZES_CACHE[key] = t
+    return t
+
+
+def rpn_decode(deltas, anchors, idx, score, sizes_t, boxes, scores, col0):
+    """One FPN level of find_top_rpn_proposals [3P]: decode the top-k anchors from the NCHW head output, clip, validity
+    -> columns [col0, col0+k) of boxes (B, K, 4) / scores (B, K); invalid candidates get score -inf."""
+    B, A4, H, W = deltas.shape
+    k = idx.shape[1]
+    call("ttdg_rpn_decode", ptr(deltas.contiguous()), ptr(anchors), ptr(idx.contiguous()), ptr(score.contiguous()), ptr(sizes_t),
+         B, k, A4 // 4, H, W, boxes.shape[1], int(col0), ptr(boxes), ptr(scores), stream())
+
+
+def _grouped_flags(bx, sc, gf, ngroups, max_group, thr):
+    """keep mask (N,) of greedy NMS inside each group; group id == ngroups marks candidates that take no part."""
+    N = sc.numel()
+    order = torch.argsort(sc, descending=True)
+    gs = gf[order]
+    o2 = torch.argsort(gs, stable=True)                          # (group, descending score)
+    final = order[o2]
+    seg = torch.searchsorted(gs[o2].contiguous(), torch.arange(ngroups + 1, device=sc.device, dtype=gs.dtype)).to(torch.int32)
+    b = bx[final].contiguous()
+    mg = max(1, min(int(max_group), N))
+    ws = torch.empty(N * ((mg + 63) // 64), dtype=torch.int64, device=sc.device)
+    flags = torch.zeros(N, dtype=torch.uint8, device=sc.device)
+    call("ttdg_nms_grouped", ptr(b), ptr(seg), int(ngroups), N, mg, float(thr), ptr(ws), ptr(flags), stream())
+    keep = torch.zeros(N, dtype=torch.bool, device=sc.device)
+    keep[final] = flags.bool()
+    return keep
+
+
+def nms_batched(boxes, scores, lvl, nlvl, thr, max_group, topk):
+    """RPN selection for a whole batch in one pass: boxes (B, K, 4), scores (B, K) with -inf for dead candidates, lvl (K,)
+    level of every column.  Greedy NMS inside every (image, level) group - all groups swept concurrently - then the
+    `topk` best survivors per image.  Returns (idx (B, topk) sorted by descending score, counts list[int]); ONE host
+    synchronisation."""
+    B, K = scores.shape
+    dev = scores.device
+    sc = scores.reshape(-1)
+    valid = sc > float("-inf")
+    g = (torch.arange(B, device=dev, dtype=torch.int64)[:, None] * nlvl + lvl.to(torch.int64)[None, :]).reshape(-1)
+    g = torch.where(valid, g, torch.full_like(g, B * nlvl))
+    keep = _grouped_flags(boxes.reshape(-1, 4).float(), sc.float(), g, B * nlvl, max_group, thr)
+    masked = torch.where(keep.view(B, K), scores, scores.new_full((), float("-inf")))
+    top = masked.topk(min(int(topk), K), dim=1)
+    counts = (top.values > float("-inf")).sum(1).tolist()
+    return top.indices, counts
+
+
+def box_inference(logits, deltas, rois, sizes_t, num_classes, weights, score_thresh):
+    """fast_rcnn_inference [3P] up to the NMS, fused: softmax, per-class decode, clip, validity, score threshold.
+    Returns boxes (N, C, 4) and scores (N, C) with -inf for rejected candidates."""
+    N = logits.shape[0]
+    boxes = torch.empty(N, num_classes, 4, device=logits.device, dtype=torch.float32)
+    scores = torch.empty(N, num_classes, device=logits.device, dtype=torch.float32)
+    call("ttdg_box_inference", ptr(logits.float().contiguous()), ptr(deltas.float().contiguous()), ptr(rois.float().contiguous()),
+         ptr(sizes_t), N, int(num_classes), float(weights[0]), float(weights[1]), float(weights[2]), float(weights[3]),
+         float(score_thresh), ptr(boxes), ptr(scores), stream())
+    return boxes, scores
+
+
+def nms_ragged(boxes, scores, rois_per_image, num_classes, thr, topk):
+    """Per-class NMS + top-k per image over the candidates of a whole batch: boxes (N, C, 4), scores (N, C) (-inf = dead);
+    image b owns rows [sum(rois_per_image[:b]), ...).  Returns, per image, the flat (row * C + class) indices of its
+    detections by descending score; ONE host synchronisation."""
+    N, C = scores.shape
+    dev = scores.device
+    B = len(rois_per_image)
+    if N == 0:
+        return [torch.empty(0, dtype=torch.int64, device=dev) for _ in range(B)]
+    sc = scores.reshape(-1)
+    img = torch.repeat_interleave(torch.arange(B, device=dev, dtype=torch.int64),
+                                  torch.tensor(rois_per_image, device=dev, dtype=torch.int64), output_size=N)
+    g = (img[:, None] * C + torch.arange(C, device=dev, dtype=torch.int64)[None, :]).reshape(-1)
+    g = torch.where(sc > float("-inf"), g, torch.full_like(g, B * C))
+    keep = _grouped_flags(boxes.reshape(-1, 4), sc, g, B * C, max(rois_per_image), thr)
+    masked = torch.where(keep, sc, sc.new_full((), float("-inf")))
+    # dense (B, maxlen) view of the ragged per-image candidate ranges
+    lens = [n * C for n in rois_per_image]
+    maxlen = max(lens)
+    starts = [0]
+    for n in lens[:-1]:
+        starts.append(starts[-1] + n)
+    ar = torch.arange(maxlen, device=dev, dtype=torch.int64)
+    st = torch.tensor(starts, device=dev, dtype=torch.int64)[:, None]
+    ln = torch.tensor(lens, device=dev, dtype=torch.int64)[:, None]
+    idxmat = (st + ar[None, :]).clamp(max=N * C - 1)
+    dense = torch.where(ar[None, :] < ln, masked[idxmat], masked.new_full((), float("-inf")))
+    top = dense.topk(min(int(topk), maxlen), dim=1)
+    flat = idxmat.gather(1, top.indices)
+    counts = (top.values > float("-inf")).sum(1).tolist()
+    return [flat[b, :counts[b]] for b in range(B)]
+
+
+def paste_masks(masks, boxes, H, W, threshold=0.5):
+    """paste_masks_in_image [3P]: soft masks (R, S, S) or (R, 1, S, S) -> (R, H, W) bool, one launch for the batch."""
+    R = masks.shape[0]
+    out = torch.empty(R, int(H), int(W), dtype=torch.uint8, device=masks.device)
+    if R:
+        m = masks.reshape(R, masks.shape[-2], masks.shape[-1]).float().contiguous()
+        call("ttdg_paste_masks", ptr(m), ptr(boxes.float().contiguous()), R, m.shape[-1], int(H), int(W), float(threshold), ptr(out), stream())
+    return out.view(torch.bool)
+
+
 def nms(boxes, scores, thr, group=None):
     """Greedy NMS; returns kept indices (into the input order) sorted by descending score."""
     ng = None if group is None else int(group.max().item()) + 1 if group.numel() else 1
