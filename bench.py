@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=64)
     ap.add_argument("--eval-streams", type=int, default=2, help="concurrent eval batches (HIP streams) in the Dice pass; 1 = sequential")
-    ap.add_argument("--eval-coalesce", type=int, default=4, help="loader batches merged into one inference call in the Dice pass; 1 = none")
+    ap.add_argument("--eval-coalesce", type=int, default=1, help="loader batches merged into one inference call in the Dice pass; 1 = none")
     ap.add_argument("--free-running", action="store_true", help="use the detector's own boxes instead of teacher forcing")
     ap.add_argument("--bf16-backbone", action="store_true", help="cfg-5 style: bf16 autocast for the backbone only")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (validation on a 1-GPU box)")

@@ -17,8 +17,10 @@ from ..optim import FusedSGD
 
 
 EVAL_STREAMS = 2      # concurrent eval batches per GPU (HIP streams, one host thread each); 1 = the plain loop
-EVAL_COALESCE = 4     # loader batches merged into one inference call in the Dice pass (eval-mode inference is per image:
-                      # FrozenBN, no cross-image op, so the merge is invisible in the results); 1 = one call per loader batch
+EVAL_COALESCE = 1     # loader batches merged into one inference call in the Dice pass (eval-mode inference is per image:
+                      # FrozenBN, no cross-image op, so the merge is invisible in the results).  Off by default: measured on
+                      # MI355X the fp32 convolutions gain nothing at batch 16 (44.8 vs 49.3 images/s) and a batch size the
+                      # warm-up has not seen costs a one-time MIOpen solver search of ~25 s
 
 
 def _eval_group(model, group, evaluator):
