@@ -462,7 +462,7 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
           const int nr = tr ? NU : n, nc = tr ? n : NU;
           for (int e = lane; e < n * NU; e += 64) Ub[e] = 0.f;
           if (CWMAX == 1 || nc <= 64) {
-            const int b = lap_wave_solve_reg(nr, nc, Vb, tr ? 1 : NU, tr ? NU : 1);
+            const int b = lap_wave_solve_reg<0, true>(nr, nc, Vb, tr ? 1 : NU, tr ? NU : 1);
             wave_sync();
             if (lane < nr) { if (tr) Ub[b * NU + lane] = 1.f; else Ub[lane * NU + b] = 1.f; }
           } else {
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(512) void debug_project_kernel(const float* __restr
         const bool tr = n > NU;
         const int nr = tr ? NU : n, nc = tr ? n : NU;
         for (int e = lane; e < n * NU; e += 64) Ub[e] = 0.f;
-        const int b = lap_wave_solve_reg(nr, nc, Vb, tr ? 1 : NU, tr ? NU : 1);
+        const int b = lap_wave_solve_reg<0, true>(nr, nc, Vb, tr ? 1 : NU, tr ? NU : 1);
         wave_sync();
         if (lane < nr) { if (tr) Ub[b * NU + lane] = 1.f; else Ub[lane * NU + b] = 1.f; }
       }

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(GL_PTHREADS) void gagm_large_project_kernel(ttdg_gr
     __syncthreads();
     if (wave == 0) {
       if (nc <= 64) {
-        const int b = lap_wave_solve_reg<0>(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1);
+        const int b = lap_wave_solve_reg<0, true>(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1);
         wave_sync();
         if (lane < nr) { if (tr) Unew[b * NU + lane] = 1.f; else Unew[lane * NU + b] = 1.f; }
       } else if (nc <= 256) {   // 2 or 4 columns per lane, still register-resident

@@ -2,7 +2,8 @@
 // One wavefront (one 64-thread workgroup) per matrix; algorithm in lap_device.h.
 #include "lap_device.h"
 
-static int g_lap_variant = 0;   // 0 = compiler-lowered fp64 DPP min (default), 1 = hand-scheduled inline asm (A/B benchmarking only)
+static int g_lap_variant = 0;   // 0 = default (compiler-lowered fp64 DPP min, cost column in registers: 14-17 % faster than reading the costs
+                                // per step, tools/bench_lap.py), 1 = hand-scheduled inline-asm min, 2 = costs read from memory per step (A/B only)
 extern "C" int ttdg_debug_set_lap_variant(int v) { g_lap_variant = v; return 0; }
 
 __global__ __launch_bounds__(64) void lap_batched_kernel(const float* __restrict__ s, int R, int C, float* __restrict__ x, int variant) {
@@ -14,7 +15,10 @@ __global__ __launch_bounds__(64) void lap_batched_kernel(const float* __restrict
   const bool tr = C < R;  // tall matrices are solved transposed (scipy does the same)
   const int nr = tr ? C : R, nc = tr ? R : C;
   if (nc <= 64) {   // register-resident solver
-    const int j = variant ? lap_wave_solve_reg<1>(nr, nc, m, tr ? 1 : C, tr ? C : 1) : lap_wave_solve_reg<0>(nr, nc, m, tr ? 1 : C, tr ? C : 1);
+    int j;
+    if (variant == 0 && nr <= 32) j = lap_wave_solve_reg<0, true>(nr, nc, m, tr ? 1 : C, tr ? C : 1);     // default: cost column in registers
+    else if (variant == 1) j = lap_wave_solve_reg<1>(nr, nc, m, tr ? 1 : C, tr ? C : 1);
+    else j = lap_wave_solve_reg<0>(nr, nc, m, tr ? 1 : C, tr ? C : 1);
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     if (lane < nr) { if (tr) o[(size_t)j * C + lane] = 1.f; else o[(size_t)lane * C + j] = 1.f; }
     return;

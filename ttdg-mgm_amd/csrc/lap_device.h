@@ -212,12 +212,21 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // returns this lane's assigned column (valid for lanes < nr)
 // kMinImpl: 0 = compiler-lowered fp64 DPP min (default: measured 6 % faster on MI355X, tools/bench_lap.py),
 //           1 = hand-scheduled inline-asm stages (kept for A/B runs)
-template <int kMinImpl = 0>
+// kRegCost: the lane's column of the cost matrix (nr <= 32 rows) is preloaded into 32 registers and read back with a
+//           wavefront-uniform dynamic index (s_set_gpr_idx / v_movrel): the cost read leaves the per-step dependency chain
+//           (an LDS or L2 round trip per step otherwise)
+template <int kMinImpl = 0, bool kRegCost = false>
 __device__ __forceinline__ int lap_wave_solve_reg(int nr, int nc, const float* val, int si, int sj) {
   const int lane = threadIdx.x & 63;
   double u = 0.0, v = 0.0, spc = INFINITY;
   int col4row = -1, row4col = -1, path = -1, pos = 0;
   const bool is_col = lane < nc;
+  typedef float f32x32 __attribute__((ext_vector_type(32)));
+  f32x32 cost;
+  if (kRegCost) {
+#pragma unroll
+    for (int r = 0; r < 32; ++r) cost[r] = (is_col && r < nr) ? val[r * si + lane * sj] : 0.f;
+  }
   for (int cur = 0; cur < nr; ++cur) {
     double minVal = 0.0;
     int nrem = nc, i = cur, sink = -1;
@@ -227,8 +236,9 @@ __device__ __forceinline__ int lap_wave_solve_reg(int nr, int nc, const float* v
     while (sink == -1) {
       if (lane == i) SR = true;
       const double ui = readlane_f64(u, i);
+      const float ci = kRegCost ? cost[i] : 0.f;       // i is wavefront-uniform
       if (active) {
-        const double r = minVal + (-(double)val[i * si + lane * sj]) - ui - v;
+        const double r = minVal + (-(double)(kRegCost ? ci : val[i * si + lane * sj])) - ui - v;
         if (r < spc) { path = i; spc = r; }
       }
       const double gmin = (kMinImpl == 1) ? wave_min_f64_fast(active ? spc : INFINITY, nc > 32)
