@@ -145,6 +145,18 @@ __device__ __forceinline__ double wave_min_f64_dpp(double v) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
   return __hiloint2double(hi, lo);
 }
+// 32-lane form (columns 0..31 only, the upper half-wave holds +inf): the row_bcast31 stage is skipped, result in lane 31
+__device__ __forceinline__ double wave_min_f64_dpp32(double v) {
+#define OP(C, R)                                                                           \
+  {                                                                                        \
+    const int lo = dpp_mov<C, R>(__double2loint(v)), hi = dpp_mov<C, R>(__double2hiint(v)); \
+    v = fmin(v, __hiloint2double(hi, lo));                                                 \
+  }
+  OP(0xB1, 0xf) OP(0x4E, 0xf) OP(0x141, 0xf) OP(0x140, 0xf) OP(0x142, 0xa)
+#undef OP
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 31), hi = __builtin_amdgcn_readlane(__double2hiint(v), 31);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ int wave_min_i32_dpp(int v) {
 #define OP(C, R) v = min(v, dpp_mov<C, R>(v));
   TTDG_DPP_REDUCE(OP)
@@ -215,8 +227,8 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // kRegCost: the lane's column of the cost matrix (nr <= 32 rows) is preloaded into 32 registers and read back with a
 //           wavefront-uniform dynamic index (s_set_gpr_idx / v_movrel): the cost read leaves the per-step dependency chain
 //           (an LDS or L2 round trip per step otherwise)
-template <int kMinImpl = 0, bool kRegCost = false>
-__device__ __forceinline__ int lap_wave_solve_reg(int nr, int nc, const float* val, int si, int sj) {
+template <int kMinImpl = 0, bool kRegCost = false, bool kNarrow = false>
+__device__ __forceinline__ int lap_wave_solve_reg_impl(int nr, int nc, const float* val, int si, int sj) {
   const int lane = threadIdx.x & 63;
   double u = 0.0, v = 0.0, spc = INFINITY;
   int col4row = -1, row4col = -1, path = -1, pos = 0;
@@ -242,7 +254,8 @@ __device__ __forceinline__ int lap_wave_solve_reg(int nr, int nc, const float* v
         if (r < spc) { path = i; spc = r; }
       }
       const double gmin = (kMinImpl == 1) ? wave_min_f64_fast(active ? spc : INFINITY, nc > 32)
-                                           : wave_min_f64_dpp(active ? spc : INFINITY);
+                          : kNarrow      ? wave_min_f64_dpp32(active ? spc : INFINITY)
+                                         : wave_min_f64_dpp(active ? spc : INFINITY);
       const bool is_min = active && spc == gmin;
       const unsigned long long minmask = __ballot(is_min);
       int jsel;
@@ -281,6 +294,13 @@ __device__ __forceinline__ int lap_wave_solve_reg(int nr, int nc, const float* v
     }
   }
   return col4row;
+}
+
+// nc <= 32 (every graph of <= 32 nodes: 32 universe columns) runs the five-stage half-wave minimum
+template <int kMinImpl = 0, bool kRegCost = false>
+__device__ __forceinline__ int lap_wave_solve_reg(int nr, int nc, const float* val, int si, int sj) {
+  if (kMinImpl == 0 && nc <= 32) return lap_wave_solve_reg_impl<0, kRegCost, true>(nr, nc, val, si, sj);
+  return lap_wave_solve_reg_impl<kMinImpl, kRegCost, false>(nr, nc, val, si, sj);
 }
 
 // ---------------------------------------------------------------------------------------------------
