@@ -151,3 +151,9 @@ def test_cfg5_polyp_stream_bf16_backbone_fp32_matching():
     assert all(v.dtype == torch.float32 for v in model.parameters())                    # fp32 master weights, fp32 SGD
     assert all(v.grad is None or v.grad.dtype == torch.float32 for v in model.parameters())
     assert any(not torch.equal(v.detach(), before[k]) for k, v in model.named_parameters() if k.startswith("backbone.bottom_up.res4"))
+
+
+def test_graft_entry_smoke():
+    """The driver's smoke() entry point must pass on this build."""
+    import __graft_entry__
+    __graft_entry__.smoke()
