@@ -231,6 +231,12 @@ int ttdg_box_inference(const float* logits, const float* deltas, const float* ro
 int ttdg_paste_masks(const float* masks, const float* boxes, int R, int S, int H, int W, float threshold,
                      unsigned char* out, ttdg_stream_t stream);
 
+/* y (N, C, H*W) <- act(y + bias[c] (+ residual) (+ bias2[c])) in place; bias / residual / bias2 may be NULL; relu != 0
+ * applies max(., 0).  The shift of a folded FrozenBN, the residual add and the ReLU of a bottleneck in one pass
+ * (forward-only: frozen stem / res2, the eval pass, the RPN head). */
+int ttdg_bias_act(float* y, const float* bias, const float* residual, const float* bias2, int N, int C, int HW,
+                  int relu, ttdg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

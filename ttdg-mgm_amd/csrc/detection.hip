@@ -363,3 +363,48 @@ extern "C" int ttdg_paste_masks(const float* masks, const float* boxes, int R, i
   hipLaunchKernelGGL(paste_masks_kernel, dim3(bx, R), dim3(256), 0, (hipStream_t)stream, masks, boxes, R, S, H, W, threshold, out);
   return ttdg_launch_status("paste_masks");
 }
+
+// ---------------------------------------------------------------------------------------------------
+// y <- act(y + bias[c] (+ residual) (+ bias2[c])) in place on an NCHW activation: the per-channel shift of a folded
+// FrozenBN (or a conv bias), the residual add and the ReLU of a bottleneck in ONE pass over the tensor instead of three
+// or four (each pass over a 164 MB res2 activation costs ~65 us of HBM time).  Forward-only: used where no gradient
+// flows (frozen stem / res2, the eval pass, the RPN head).
+__global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias,
+                                                       const float* __restrict__ res, const float* __restrict__ bias2, int C, int HW,
+                                                       size_t total, int relu) {
+  if ((HW & 3) == 0) {
+    const size_t nvec = total >> 2;
+    for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (size_t)gridDim.x * 256) {
+      const int c = (int)((v * 4 / HW) % C);
+      float b = bias ? bias[c] : 0.f;
+      if (bias2) b += bias2[c];
+      float4 t = reinterpret_cast<float4*>(y)[v];
+      if (res) {
+        const float4 r = reinterpret_cast<const float4*>(res)[v];
+        t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
+      }
+      t.x += b; t.y += b; t.z += b; t.w += b;
+      if (relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+      reinterpret_cast<float4*>(y)[v] = t;
+    }
+  } else {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+      const int c = (int)((e / HW) % C);
+      float t = y[e] + (bias ? bias[c] : 0.f) + (bias2 ? bias2[c] : 0.f);
+      if (res) t += res[e];
+      y[e] = relu ? fmaxf(t, 0.f) : t;
+    }
+  }
+}
+
+extern "C" int ttdg_bias_act(float* y, const float* bias, const float* residual, const float* bias2, int N, int C, int HW,
+                             int relu, ttdg_stream_t stream) {
+  TTDG_REQUIRE(y && N >= 0 && C > 0 && HW > 0, "bias_act: bad arguments");
+  const size_t total = (size_t)N * C * HW;
+  if (total == 0) return 0;
+  const size_t work = (HW & 3) == 0 ? total / 4 : total;
+  const size_t want = (work + 255) / 256;
+  const int blocks = (int)(want < 8192 ? want : 8192);
+  hipLaunchKernelGGL(bias_act_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, bias, residual, bias2, C, HW, total, relu);
+  return ttdg_launch_status("bias_act");
+}

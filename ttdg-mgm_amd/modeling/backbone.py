@@ -5,6 +5,24 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
+
+
+import os
+
+# module switch (calibrate_frozen_bn turns it off: its statistics hooks sit on ConvNorm.forward); TTDG_FUSED_EPILOGUE=0 for A/B runs
+FUSED_EPILOGUE = os.environ.get("TTDG_FUSED_EPILOGUE", "1") != "0"
+
+
+def _fusable(x, *mods):
+    """True when no gradient can flow through this piece (frozen filters on a constant input, or no_grad): the fp32 GPU
+    forward may then run in place with the fused shift / residual / ReLU kernel (ops.bias_act_)."""
+    if not (FUSED_EPILOGUE and x.is_cuda and x.dtype == torch.float32) or torch.is_autocast_enabled():
+        return False              # (under autocast the convolution output is bf16: the fp32 kernel must not touch it)
+    if not torch.is_grad_enabled():
+        return True
+    return not x.requires_grad and not any(p.requires_grad for m in mods for p in m.parameters())
+
 
 class FrozenBatchNorm2d(nn.Module):
     def __init__(self, c, eps=1e-5):
@@ -42,6 +60,15 @@ class ConvNorm(nn.Conv2d):
         self._wfold = None
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
 
+    def raw(self, x):
+        """(convolution with the folded filter, WITHOUT its shift; the shift) - for the fused in-place epilogue."""
+        scale, shift = self.norm.folded()
+        key = (self.weight._version, self.weight.data_ptr(), self.norm._fold[0])
+        if self._wfold is None or self._wfold[0] != key:
+            with torch.no_grad():
+                self._wfold = (key, self.weight * scale)
+        return F.conv2d(x, self._wfold[1], None, self.stride, self.padding), shift
+
     def forward(self, x):
         if self.norm is None:
             return super().forward(x)
@@ -66,6 +93,9 @@ class Stem(nn.Module):
         self.conv1 = ConvNorm(3, 64, 7, stride=2, padding=3)
 
     def forward(self, x):
+        if _fusable(x, self):
+            y, b = self.conv1.raw(x)
+            return F.max_pool2d(ops.bias_act_(y, b), kernel_size=3, stride=2, padding=1)
         return F.max_pool2d(F.relu_(self.conv1(x)), kernel_size=3, stride=2, padding=1)
 
 
@@ -78,6 +108,15 @@ class Bottleneck(nn.Module):
         self.conv3 = ConvNorm(mid, cout, 1)
 
     def forward(self, x):
+        if _fusable(x, self):
+            # no gradient through this block: three in-place epilogues instead of eight elementwise passes
+            y, b = self.conv1.raw(x)
+            y, b = self.conv2.raw(ops.bias_act_(y, b))
+            y, b = self.conv3.raw(ops.bias_act_(y, b))
+            if self.shortcut is not None:
+                sc, bs = self.shortcut.raw(x)
+                return ops.bias_act_(y, b, sc, bs)
+            return ops.bias_act_(y, b, x.contiguous())
         out = F.relu_(self.conv1(x))
         out = F.relu_(self.conv2(out))
         out = self.conv3(out)

@@ -41,8 +41,13 @@ class RPNHead(nn.Module):
 
     def forward(self, feats):
         logits, deltas = [], []
+        fused = (not torch.is_grad_enabled() and feats[0].is_cuda and feats[0].dtype == torch.float32
+                 and not torch.is_autocast_enabled())
         for x in feats:
-            t = F.relu(self.conv(x))
+            if fused:      # proposals carry no gradient: conv + (bias, ReLU) in one in-place epilogue
+                t = ops.bias_act_(F.conv2d(x, self.conv.weight, None, 1, 1), self.conv.bias)
+            else:
+                t = F.relu(self.conv(x))
             logits.append(self.objectness_logits(t))
             deltas.append(self.anchor_deltas(t))
         return logits, deltas

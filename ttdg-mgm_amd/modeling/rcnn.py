@@ -113,10 +113,15 @@ def calibrate_frozen_bn(model, batched_inputs):
     for m in model.modules():
         if isinstance(m, ConvNorm) and m.norm is not None:
             hooks.append(m.register_forward_pre_hook(pre))
+    from . import backbone as _bb
     images = model.preprocess_image(batched_inputs)
-    model.backbone(images.tensor)
-    for h in hooks:
-        h.remove()
+    saved, _bb.FUSED_EPILOGUE = _bb.FUSED_EPILOGUE, False        # the statistics hooks sit on ConvNorm.forward
+    try:
+        model.backbone(images.tensor)
+    finally:
+        _bb.FUSED_EPILOGUE = saved
+        for h in hooks:
+            h.remove()
     return model
 
 

@@ -457,6 +457,19 @@ def nms_collect(launched):
     return [h[1] if h[0] == "empty" else h[1][:next(counts)] for h in launched]
 
 
+def bias_act_(y, bias=None, residual=None, bias2=None, relu=True):
+    """In place on a contiguous fp32 NCHW tensor: y <- act(y + bias[c] (+ residual) (+ bias2[c])).  Forward-only."""
+    for t in (y, bias, residual, bias2):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+            raise TypeError("bias_act_: contiguous float32 tensors only (got %s)" % t.dtype)
+    if residual is not None and residual.shape != y.shape:
+        raise ValueError("bias_act_: residual shape %s != %s" % (tuple(residual.shape), tuple(y.shape)))
+    N, C = y.shape[0], y.shape[1]
+    HW = y.numel() // max(1, N * C)
+    call("ttdg_bias_act", ptr(y), ptr(bias), ptr(residual), ptr(bias2), N, C, HW, int(bool(relu)), stream())
+    return y
+
+
 _SIZES_CACHE = {}
 
 
