@@ -262,6 +262,7 @@ __global__ __launch_bounds__(256) void gagm_large_mul_kernel(const float* __rest
 
 #define GL_PTHREADS 1024
 #define GL_PWAVES (GL_PTHREADS / 64)
+#define GL_VL_OFF 1024   /* floats of dynamic LDS in front of the V_g tile (projector scratch) */
 
 // ---- Sinkhorn projector of one graph block with n >= 32 nodes: rows = universe (32), columns = nodes -----------------
 // One column per thread, held in registers (32 values): the column sweep is lane-local and exact (in-lane max); the row
@@ -280,7 +281,7 @@ __device__ __forceinline__ void gl_reduce33(const float (&val)[33], float* s_par
   if (lane < 33) s_part[wave * 33 + lane] = mine;
 }
 
-__device__ __forceinline__ void gl_project_cols(const float* __restrict__ Vg, int n, float scale, int iters, float* __restrict__ Unew,
+__device__ __forceinline__ void gl_project_cols(const float* vl, int n, float scale, int iters, float* __restrict__ Unew,
                                                 float* smem) {
   float* s_f = smem;                    // 33 potentials (index 32 = dummy row) + pad
   float* s_stab = smem + 36;            // 33 stabilisers of the sweep in flight
@@ -293,12 +294,9 @@ __device__ __forceinline__ void gl_project_cols(const float* __restrict__ Vg, in
   const int mult = n - NU;
   float L[NU];
   {
-    const float4* row = reinterpret_cast<const float4*>(Vg + (size_t)(live ? tid : 0) * NU);
+    const float* row = vl + (live ? tid : 0) * 33;       // V_g tile in LDS, row stride 33: conflict-free per-thread rows
 #pragma unroll
-    for (int k = 0; k < NU / 4; ++k) {
-      const float4 v = row[k];
-      L[4 * k] = v.x * scale; L[4 * k + 1] = v.y * scale; L[4 * k + 2] = v.z * scale; L[4 * k + 3] = v.w * scale;
-    }
+    for (int k = 0; k < NU; ++k) L[k] = row[k] * scale;
   }
   float g = 0.f;
   if (tid < 36) s_f[tid] = 0.f;
@@ -392,6 +390,21 @@ __global__ __launch_bounds__(GL_PTHREADS) void gagm_large_project_kernel(ttdg_gr
   float* Unew = w.ring + (size_t)((total + 1) % 3) * MU + (size_t)o * NU;
   const float* Uprev = w.ring + (size_t)((total + 2) % 3) * MU + (size_t)o * NU;
 
+  const int li = lane & 31, kh = lane >> 5;
+  constexpr int CHUNK = 2 * GL_PWAVES * 8;          // rows per pass of the V loop (256): a wavefront takes two rows at a time
+  float bv[8], wu[8];
+  // operands of the first V chunk: issued before the S reduction so that both sets of L2 round trips overlap
+#define GL_LOAD_V_OPERANDS(base)                                                                        \
+  _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                       \
+    const int i = (base) + j * 2 * GL_PWAVES + wave * 2 + kh;                                            \
+    const bool ok = i < n;                                                                               \
+    const size_t idx = (size_t)(o + (ok ? i : 0)) * NU + li;                                             \
+    bv[j] = ok ? w.B[idx] : 0.f;                                                                         \
+    float p[GL_MAXKS];                                                                                   \
+    _Pragma("unroll") for (int z = 0; z < GL_MAXKS; ++z) p[z] = (ok && z < w.ks) ? w.WUp[(size_t)z * MU + idx] : 0.f; \
+    wu[j] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));                           \
+  }
+  GL_LOAD_V_OPERANDS(0)
   // S = sum of the tile shares: one element per thread, 16 independent loads in flight per round (the plain
   // accumulate-as-you-go loop pays one L2 round trip per tile)
   {
@@ -407,28 +420,17 @@ __global__ __launch_bounds__(GL_PTHREADS) void gagm_large_project_kernel(ttdg_gr
              (((acc[8] + acc[9]) + (acc[10] + acc[11])) + ((acc[12] + acc[13]) + (acc[14] + acc[15])));
   }
   __syncthreads();
-  // V_g = (2q B_g S + W U) / G: a wavefront takes two rows at a time, B rows broadcast from LDS, S column in registers;
-  // the B values and the K-slice planes of 8 row pairs are loaded up front (72 independent loads per thread)
+  // V_g = (2q B_g S + W U) / G: B rows broadcast from LDS, S column in registers.  V_g goes to the workspace (trace /
+  // next launch) AND to an LDS tile with row stride 33 that both projectors read (no global round trip in between)
+  float* vl = gl_smem + GL_VL_OFF;
   {
-    const int li = lane & 31, kh = lane >> 5;
     float sc[NU];
 #pragma unroll
     for (int k = 0; k < NU; ++k) sc[k] = s_S[k * NU + li];
     const float qw2 = 2.f * cfg.quad_weight, invG = 1.f / (float)G;
     float* br = s_brow + wave * 64;
-    for (int base = 0; base < n; base += 2 * GL_PWAVES * 8) {
-      float bv[8], wu[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int i = base + j * 2 * GL_PWAVES + wave * 2 + kh;
-        const bool ok = i < n;
-        const size_t idx = (size_t)(o + (ok ? i : 0)) * NU + li;
-        bv[j] = ok ? w.B[idx] : 0.f;
-        float p[GL_MAXKS];
-#pragma unroll
-        for (int z = 0; z < GL_MAXKS; ++z) p[z] = (ok && z < w.ks) ? w.WUp[(size_t)z * MU + idx] : 0.f;
-        wu[j] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-      }
+    for (int base = 0; base < n; base += CHUNK) {
+      if (base > 0) { GL_LOAD_V_OPERANDS(base) }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int i = base + j * 2 * GL_PWAVES + wave * 2 + kh;
@@ -445,12 +447,14 @@ __global__ __launch_bounds__(GL_PTHREADS) void gagm_large_project_kernel(ttdg_gr
         if (i < n) {
           const size_t idx = (size_t)(o + i) * NU + li;
           w.V[idx] = v;
+          vl[i * 33 + li] = v;
           if (total == 0) w.V0[idx] = v;
         }
         wave_sync();
       }
     }
   }
+#undef GL_LOAD_V_OPERANDS
   __syncthreads();
   const float* Vg = w.V + (size_t)o * NU;
 
@@ -467,14 +471,13 @@ __global__ __launch_bounds__(GL_PTHREADS) void gagm_large_project_kernel(ttdg_gr
       pb.pot = nullptr; pb.potld = 0;
       sk_forward<true>(pb, gl_smem, cfg.sk_iter);
     } else {
-      gl_project_cols(Vg, n, pb.scale, cfg.sk_iter, Unew, gl_smem);
+      gl_project_cols(vl, n, pb.scale, cfg.sk_iter, Unew, gl_smem);
     }
   } else {
     const bool tr = n > NU;
     const int nr = tr ? NU : n, nc = tr ? n : NU;
-    float* vl = gl_smem;                                   // V_g, row stride 33
-    for (int e = tid; e < n * NU; e += GL_PTHREADS) { vl[(e >> 5) * 33 + (e & 31)] = Vg[e]; Unew[e] = 0.f; }
-    __syncthreads();
+    for (int e = tid; e < n * NU; e += GL_PTHREADS) Unew[e] = 0.f;       // (V_g is already in the LDS tile)
+    __syncthreads();                                                     // zeros land before wavefront 0 writes the ones
     if (wave == 0) {
       if (nc <= 64) {
         const int b = lap_wave_solve_reg<0, true>(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1);
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(GL_PTHREADS) void gagm_large_project_kernel(ttdg_gr
         wave_sync();
         if (lane < nr) { if (tr) Unew[b * NU + lane] = 1.f; else Unew[lane * NU + b] = 1.f; }
       } else {
-        LapScratch sc = lap_carve(vl + ((n * 33 + 3) & ~3), nr, nc);
+        LapScratch sc = lap_carve(vl + ((n * 33 + 3) & ~3), nr, nc);      // behind the V_g tile
         lap_wave_solve(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1, sc);
         wave_sync();
         for (int a = lane; a < nr; a += 64) {
@@ -581,9 +584,9 @@ int ttdg_gagm_large_solve(const float* Apack, const float* W, const float* U0, t
   GlWs w = gl_carve((float*)ws, gr);
   // dynamic LDS of the projection launch: Sinkhorn (f, g, oriented matrix) or LAP (V_g copy + scratch), whichever is larger
   const int r = cmax < NU ? cmax : NU, c = cmax < NU ? NU : cmax;
-  const size_t sk = (size_t)(2 * c + 1 + (size_t)r * (c | 1) + 4) * sizeof(float);
-  const size_t lp = (size_t)((cmax * 33 + 3) & ~3) * sizeof(float) + lap_scratch_bytes(r, c) + 16;
-  const size_t bytes = sk > lp ? sk : lp;
+  // [projector scratch: GL_VL_OFF floats][V_g tile: n x 33][LAP scratch]; the generic Sinkhorn of a < 32-node graph in
+  // a large batch (rows = nodes) needs 2*32+1 + 31*33 floats and runs after the tile was consumed (it re-reads V from L2)
+  const size_t bytes = (size_t)(GL_VL_OFF + ((cmax * 33 + 3) & ~3)) * sizeof(float) + lap_scratch_bytes(r, c) + 16;
   TTDG_ALLOW_LDS(gagm_large_project_kernel, bytes);
   const int M = gr.off[gr.G];
   const int cblocks = (M * NU + 255) / 256 < 256 ? (M * NU + 255) / 256 : 256;
