@@ -49,12 +49,15 @@ def run_eval_batches(model, batches, evaluator, streams=None, coalesce=None):
     if not dev_is_gpu:
         coalesce = 1
     batches = [batches[i:i + max(1, coalesce)] for i in range(0, len(batches), max(1, coalesce))]     # groups of loader batches
-    if streams <= 1 or not dev_is_gpu or len(batches) < 2:
+    if streams <= 1 or not dev_is_gpu or len(batches) < 3:
         with torch.no_grad():
             for group in batches:
                 _eval_group(model, group, evaluator)
         return
     import threading
+    with torch.no_grad():       # the first group runs on the caller's stream: every lazily built constant (folded filters,
+        _eval_group(model, batches[0], evaluator)     # anchors, size tables) exists before the side streams start
+    batches = batches[1:]
     main = torch.cuda.current_stream()
     side = [torch.cuda.Stream() for _ in range(streams)]
     errors = []

@@ -14,6 +14,14 @@ import os
 FUSED_EPILOGUE = os.environ.get("TTDG_FUSED_EPILOGUE", "1") != "0"
 
 
+def _publish(t):
+    """A lazily built constant is about to be cached and may be consumed from ANOTHER HIP stream (the Dice pass runs
+    inference on several streams): make sure the kernels that produce it have finished before it becomes visible."""
+    if t.is_cuda:
+        torch.cuda.current_stream(t.device).synchronize()
+    return t
+
+
 def _fusable(x, *mods):
     """True when no gradient can flow through this piece (frozen filters on a constant input, or no_grad): the fp32 GPU
     forward may then run in place with the fused shift / residual / ReLU kernel (ops.bias_act_)."""
@@ -42,7 +50,7 @@ class FrozenBatchNorm2d(nn.Module):
         if self._fold is None or self._fold[0] != key:
             with torch.no_grad():
                 scale = self.weight * (self.running_var + self.eps).rsqrt()
-                shift = self.bias - self.running_mean * scale
+                shift = _publish(self.bias - self.running_mean * scale)
             self._fold = (key, scale.view(-1, 1, 1, 1), shift)
         return self._fold[1], self._fold[2]
 
@@ -66,7 +74,7 @@ class ConvNorm(nn.Conv2d):
         key = (self.weight._version, self.weight.data_ptr(), self.norm._fold[0])
         if self._wfold is None or self._wfold[0] != key:
             with torch.no_grad():
-                self._wfold = (key, self.weight * scale)
+                self._wfold = (key, _publish(self.weight * scale))
         return F.conv2d(x, self._wfold[1], None, self.stride, self.padding), shift
 
     def forward(self, x):
@@ -82,7 +90,7 @@ class ConvNorm(nn.Conv2d):
             key = (self.weight._version, self.weight.data_ptr(), self.norm._fold[0])
             if self._wfold is None or self._wfold[0] != key:
                 with torch.no_grad():
-                    self._wfold = (key, self.weight * scale)
+                    self._wfold = (key, _publish(self.weight * scale))
             w = self._wfold[1]
         return F.conv2d(x, w, shift.to(x.dtype), self.stride, self.padding)
 

@@ -84,6 +84,8 @@ class PseudoLabRPN(nn.Module):
                                         torch.arange(w, device=device, dtype=torch.float32) * stride, indexing="ij")
                 sh = torch.stack((xs, ys, xs, ys), dim=-1).reshape(-1, 1, 4)
                 out.append((sh + base[None]).reshape(-1, 4))
+            if out and out[0].is_cuda:
+                torch.cuda.current_stream(out[0].device).synchronize()     # cached constants may be read from other streams
             self._anchor_cache[key] = out
         return self._anchor_cache[key]
 
@@ -101,7 +103,10 @@ class PseudoLabRPN(nn.Module):
         K = sum(ks)
         key = (tuple(ks), str(dev))
         if self._lvl_cache.get("key") != key:
-            self._lvl_cache = {"key": key, "lvl": torch.cat([torch.full((k,), l, dtype=torch.int64, device=dev) for l, k in enumerate(ks)])}
+            lv = torch.cat([torch.full((k,), l, dtype=torch.int64, device=dev) for l, k in enumerate(ks)])
+            if lv.is_cuda:
+                torch.cuda.current_stream(dev).synchronize()
+            self._lvl_cache = {"key": key, "lvl": lv}
         lvl = self._lvl_cache["lvl"]
         sizes_t = _backend.image_sizes_tensor(images.image_sizes, dev)
         # every candidate of the batch in two dense tensors; rejected ones carry score -inf (no compaction, no per-image loop)

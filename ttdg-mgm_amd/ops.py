@@ -481,6 +481,8 @@ def image_sizes_tensor(sizes, device):
         if len(_SIZES_CACHE) > 64:
             _SIZES_CACHE.clear()
         t = torch.tensor(key[0], dtype=torch.float32).reshape(-1, 2).to(device)
+        if t.is_cuda:
+            torch.cuda.current_stream(t.device).synchronize()       # cached constants may be read from other streams
         _SIZES_CACHE[key] = t
     return t
 
