@@ -95,6 +95,8 @@ def gpu_run(args, rank, world, device):
         else:
             run_eval_batches(model, bs, dice, args.eval_streams, args.eval_coalesce)      # independent batches: merged calls on concurrent HIP streams
         model.train()
+        if world > 1:
+            dice.gather_scores()     # Mode R's one collective: all-gather of the per-rank score lists over RCCL
         return dice.evaluate()
 
     model.train()

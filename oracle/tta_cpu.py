@@ -46,7 +46,7 @@ class _CpuBackend:
         scores[:, col0:col0 + k] = torch.where(ok, score, score.new_full((), float("-inf")))
 
     @staticmethod
-    def nms_batched(boxes, scores, lvl, nlvl, thr, max_group, topk):
+    def nms_batched(boxes, scores, lvl, nlvl, thr, max_group, topk, device_counts=False):
         B, K = scores.shape
         idx = torch.zeros(B, min(int(topk), K), dtype=torch.int64)
         counts = []
@@ -55,7 +55,7 @@ class _CpuBackend:
             keep = live[odet.nms(boxes[b][live], scores[b][live], thr, lvl[live])][:idx.shape[1]]
             idx[b, :len(keep)] = keep
             counts.append(int(len(keep)))
-        return idx, counts
+        return idx, (torch.tensor(counts) if device_counts else counts)
 
     @staticmethod
     def box_inference(logits, deltas, rois, sizes_t, num_classes, weights, score_thresh):

@@ -91,6 +91,8 @@ def inference_on_dataset(model, data_loader, evaluator, cfg=None):
     evaluator.reset()
     run_eval_batches(model, data_loader, evaluator)
     model.train(was_training)
+    if hasattr(evaluator, "gather_scores"):
+        evaluator.gather_scores()      # no-op on one rank; the all-gather the reference omits (it reports rank-local means)
     results = evaluator.evaluate()
     return (results if results is not None else {}), evaluator
 

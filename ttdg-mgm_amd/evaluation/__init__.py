@@ -134,16 +134,26 @@ class DiceEvaluator:
                 self.dice_scores.append(d), self.ea_scores.append(e), self.sm_scores.append(s)
 
     def gather_scores(self):
-        """All-gather of the per-rank score lists (the reference reports rank-local means)."""
+        """All-gather of the per-rank score lists (the reference reports rank-local means, dice_metric.py:80-92): sizes
+        first, then one padded all_gather of a (max_len, 3) tensor - RCCL on the GPUs (backend nccl), gloo on CPU."""
         import torch.distributed as dist
         self._flush()
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
-        parts = [None] * dist.get_world_size()
-        dist.all_gather_object(parts, (self.dice_scores, self.ea_scores, self.sm_scores))
-        self.dice_scores = [x for p in parts for x in p[0]]
-        self.ea_scores = [x for p in parts for x in p[1]]
-        self.sm_scores = [x for p in parts for x in p[2]]
+        world = dist.get_world_size()
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        n = torch.tensor([len(self.dice_scores)], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros_like(n) for _ in range(world)]
+        dist.all_gather(sizes, n)
+        sizes = [int(x.item()) for x in sizes]
+        mx = max(max(sizes), 1)
+        mine = torch.full((mx, 3), float("nan"), dtype=torch.float64, device=dev)
+        if sizes[dist.get_rank()]:
+            mine[:len(self.dice_scores)] = torch.tensor(list(zip(self.dice_scores, self.ea_scores, self.sm_scores)), dtype=torch.float64, device=dev)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        rows = torch.cat([p[:k] for p, k in zip(parts, sizes)]).cpu().tolist()
+        self.dice_scores, self.ea_scores, self.sm_scores = [r[0] for r in rows], [r[1] for r in rows], [r[2] for r in rows]
 
     def evaluate(self):
         self._flush()

@@ -93,6 +93,14 @@ class PseudoLabRPN(nn.Module):
     def forward(self, images, features, gt_instances=None, compute_loss=True, danchor=False):
         if compute_loss:
             raise NotImplementedError("RPN losses belong to source training, not to test-time adaptation")
+        boxes, scores, keep, counts = self.forward_dense(features, images.image_sizes)
+        return self.finalize(boxes, scores, keep, counts.tolist(), images.image_sizes), {}     # the one host sync of the stage
+
+    @torch.no_grad()
+    def forward_dense(self, features, image_sizes):
+        """Everything up to the per-image slicing, with static shapes and no host synchronisation (capturable in a HIP
+        graph): candidates of the batch in dense tensors boxes (B, K, 4) / scores (B, K) (-inf = rejected), the kept
+        indices (B, post) by descending score and their counts (B,) as a device tensor."""
         feats = [features[f].detach() for f in self.in_features]
         logits, deltas = self.rpn_head(feats)
         dev = feats[0].device
@@ -108,7 +116,7 @@ class PseudoLabRPN(nn.Module):
                 torch.cuda.current_stream(dev).synchronize()
             self._lvl_cache = {"key": key, "lvl": lv}
         lvl = self._lvl_cache["lvl"]
-        sizes_t = _backend.image_sizes_tensor(images.image_sizes, dev)
+        sizes_t = _backend.image_sizes_tensor(image_sizes, dev)
         # every candidate of the batch in two dense tensors; rejected ones carry score -inf (no compaction, no per-image loop)
         boxes = torch.empty(N, K, 4, device=dev, dtype=torch.float32)
         scores = torch.empty(N, K, device=dev, dtype=torch.float32)
@@ -117,12 +125,16 @@ class PseudoLabRPN(nn.Module):
             sc, idx = lg.permute(0, 2, 3, 1).reshape(N, -1).topk(k, dim=1)
             _backend.rpn_decode(dl, an, idx, sc.float(), sizes_t, boxes, scores, col)      # decode + clip + validity, fused
             col += k
-        keep, counts = _backend.nms_batched(boxes, scores, lvl, L, self.nms_thresh, pre, post)   # one host sync per batch
+        keep, counts = _backend.nms_batched(boxes, scores, lvl, L, self.nms_thresh, pre, post, device_counts=True)
+        return boxes, scores, keep, counts
+
+    @staticmethod
+    def finalize(boxes, scores, keep, counts, image_sizes):
         proposals = []
-        for n, size in enumerate(images.image_sizes):
+        for n, size in enumerate(image_sizes):
             sel = keep[n, :counts[n]]
             proposals.append(Instances(size, proposal_boxes=Boxes(boxes[n, sel]), objectness_logits=scores[n, sel]))
-        return proposals, {}
+        return proposals
 
 
 class ROIPooler:

@@ -514,11 +514,11 @@ def _grouped_flags(bx, sc, gf, ngroups, max_group, thr):
     return keep
 
 
-def nms_batched(boxes, scores, lvl, nlvl, thr, max_group, topk):
+def nms_batched(boxes, scores, lvl, nlvl, thr, max_group, topk, device_counts=False):
     """RPN selection for a whole batch in one pass: boxes (B, K, 4), scores (B, K) with -inf for dead candidates, lvl (K,)
     level of every column.  Greedy NMS inside every (image, level) group - all groups swept concurrently - then the
     `topk` best survivors per image.  Returns (idx (B, topk) sorted by descending score, counts list[int]); ONE host
-    synchronisation."""
+    synchronisation - or none with ``device_counts`` (counts stay a device tensor: the whole call is capturable)."""
     B, K = scores.shape
     dev = scores.device
     sc = scores.reshape(-1)
@@ -528,8 +528,8 @@ def nms_batched(boxes, scores, lvl, nlvl, thr, max_group, topk):
     keep = _grouped_flags(boxes.reshape(-1, 4).float(), sc.float(), g, B * nlvl, max_group, thr)
     masked = torch.where(keep.view(B, K), scores, scores.new_full((), float("-inf")))
     top = masked.topk(min(int(topk), K), dim=1)
-    counts = (top.values > float("-inf")).sum(1).tolist()
-    return top.indices, counts
+    counts = (top.values > float("-inf")).sum(1)
+    return top.indices, (counts if device_counts else counts.tolist())
 
 
 def box_inference(logits, deltas, rois, sizes_t, num_classes, weights, score_thresh):
