@@ -237,6 +237,13 @@ int ttdg_paste_masks(const float* masks, const float* boxes, int R, int S, int H
 int ttdg_bias_act(float* y, const float* bias, const float* residual, const float* bias2, int N, int C, int HW,
                   int relu, ttdg_stream_t stream);
 
+/* detectron2 ROIPooler [3P] in one launch: every ROI (image, x1, y1, x2, y2) picks its FPN level
+ * clamp(floor(canonical_level + log2(sqrt(area) / canonical_size + 1e-8)), min_level, min_level + fp.n - 1) inside the
+ * kernel and is ROIAlign-ed (aligned, adaptive sampling) from that level's map; lv.stride[l] gives the level scales.
+ * out (R, C, P, P).  No per-level compaction, hence no host read. */
+int ttdg_roi_align_multilevel(ttdg_fpn_t fp, ttdg_levels_t lv, const float* rois, int R, int P, float canonical_size,
+                              int canonical_level, int min_level, float* out, ttdg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,6 +85,22 @@ class _CpuBackend:
         return out
 
     @staticmethod
+    def roi_align_multilevel(feats, rois, strides, P, canonical_size=224, canonical_level=4, min_level=2):
+        """detectron2 ROIPooler [3P], level by level (the formulation the fused kernel replaces)."""
+        R = rois.shape[0]
+        out = feats[0].new_zeros((R, feats[0].shape[1], P, P), dtype=torch.float32)
+        if R == 0:
+            return out
+        area = (rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2])
+        lvl = torch.floor(canonical_level + torch.log2(torch.sqrt(area.clamp(min=0)) / canonical_size + 1e-8))
+        lvl = lvl.clamp(min_level, min_level + len(feats) - 1).long() - min_level
+        for l, (f, s) in enumerate(zip(feats, strides)):
+            idx = torch.nonzero(lvl == l).squeeze(1)
+            if idx.numel():
+                out[idx] = odet.roi_align(f, rois[idx], 1.0 / s, P)
+        return out
+
+    @staticmethod
     def paste_masks(masks, boxes, H, W, threshold=0.5):
         from ttdg_mgm_amd.modeling.detector import paste_masks_in_image_torch
         return paste_masks_in_image_torch(masks.reshape(masks.shape[0], 1, masks.shape[-2], masks.shape[-1]), boxes, (H, W), threshold)

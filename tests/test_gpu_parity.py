@@ -809,3 +809,23 @@ def test_fused_bias_residual_relu_epilogue(dev):
         finally:
             bb.FUSED_EPILOGUE = True
     assert maxerr(fused, plain) <= 1e-4 * max(1.0, float(plain.abs().max()))
+
+
+def test_roi_align_multilevel_matches_per_level_pooler(dev):
+    """ttdg_roi_align_multilevel (level chosen inside the kernel) against detectron2's ROIPooler formulation
+    (level by level: assign, compact, ROIAlign, scatter) on the host."""
+    from ttdg_mgm_amd import ops
+    cb = _cpu_backend()
+    g = synth.gen(7500)
+    B, C = 2, 8
+    feats = [synth.normal(g, (B, C, 64 // s, 64 // s), 1.0) for s in (1, 2, 4, 8)]      # strides 4, 8, 16, 32 of a 256 px image
+    R = 60
+    xy = np.abs(synth.normal(g, (R, 2), 60.0).numpy())
+    wh = np.abs(synth.normal(g, (R, 2), 80.0).numpy()) + 1.0          # from a few pixels to beyond the canonical 224
+    img = g.integers(0, B, size=R).astype(np.float32)
+    rois = torch.from_numpy(np.concatenate((img[:, None], xy, xy + wh), 1).astype(np.float32))
+    rois[0, 1:] = torch.tensor([10.0, 10.0, 10.0, 10.0])             # degenerate box
+    for P in (7, 14):
+        ref = cb.roi_align_multilevel(feats, rois, [4, 8, 16, 32], P)
+        got = ops.roi_align_multilevel([f.to(dev) for f in feats], rois.to(dev), [4, 8, 16, 32], P)
+        assert maxerr(got, ref) <= 1e-4, P

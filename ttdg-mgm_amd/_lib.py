@@ -77,6 +77,7 @@ SIGNATURES = {
     "ttdg_nms_grouped": (C.c_int, [_P, _P, _I, _I, _I, _F, _P, _P, _S]),
     "ttdg_rpn_decode": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _S]),
     "ttdg_box_inference": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _P, _P, _S]),
+    "ttdg_roi_align_multilevel": (C.c_int, [Fpn, Levels, _P, _I, _I, _F, _I, _I, _P, _S]),
     "ttdg_bias_act": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _S]),
     "ttdg_paste_masks": (C.c_int, [_P, _P, _I, _I, _I, _I, _F, _P, _S]),
 }

@@ -408,3 +408,58 @@ extern "C" int ttdg_bias_act(float* y, const float* bias, const float* residual,
   hipLaunchKernelGGL(bias_act_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, bias, residual, bias2, C, HW, total, relu);
   return ttdg_launch_status("bias_act");
 }
+
+// ---------------------------------------------------------------------------------------------------
+// detectron2 ROIPooler [3P] in ONE launch: every ROI picks its FPN level inside the kernel
+//   level = clamp(floor(canonical_level + log2(sqrt(area) / canonical_size + 1e-8)), min_level, max_level) - min_level
+// and is sampled from that level's map (same adaptive bilinear sampling as roi_align_fwd_kernel).  The torch formulation
+// is a per-level nonzero() (a host read each) + index + ROIAlign + index_put: 4 syncs and ~40 launches per call.
+__global__ __launch_bounds__(256) void roi_align_ml_kernel(ttdg_fpn_t fp, ttdg_levels_t lv, const float* __restrict__ rois, int R, int P,
+                                                           float canon_size, int canon_level, int min_level,
+                                                           float* __restrict__ out) {
+  const int C = fp.C;
+  const long total = (long)R * C * P * P;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int pw = idx % P, ph = (idx / P) % P, c = (idx / ((long)P * P)) % C;
+    const int r = idx / ((long)P * P * C);
+    const float* roi = rois + (size_t)r * 5;
+    const int b = (int)roi[0];
+    const float area = fmaxf((roi[3] - roi[1]) * (roi[4] - roi[2]), 0.f);
+    int l = (int)floorf((float)canon_level + log2f(sqrtf(area) / canon_size + 1e-8f));
+    l = min(max(l, min_level), min_level + fp.n - 1) - min_level;
+    const int H = fp.h[l], W = fp.w[l];
+    const float scale = 1.f / (float)lv.stride[l];
+    const float x1 = roi[1] * scale - 0.5f, y1 = roi[2] * scale - 0.5f;
+    const float rw = roi[3] * scale - 0.5f - x1, rh = roi[4] * scale - 0.5f - y1;
+    const float bw = rw / P, bh = rh / P;
+    const int gh = max(1, (int)ceilf(rh / P)), gw = max(1, (int)ceilf(rw / P));
+    const float* f = fp.feat[l] + ((size_t)b * C + c) * H * W;
+    float acc = 0.f;
+    for (int iy = 0; iy < gh; ++iy) {
+      float y = y1 + ph * bh + (iy + 0.5f) * bh / gh;
+      for (int ix = 0; ix < gw; ++ix) {
+        float x = x1 + pw * bw + (ix + 0.5f) * bw / gw;
+        if (y < -1.f || y > H || x < -1.f || x > W) continue;
+        float yy = fmaxf(y, 0.f), xx = fmaxf(x, 0.f);
+        int y0 = (int)yy, x0 = (int)xx, y1i, x1i;
+        if (y0 >= H - 1) { y0 = y1i = H - 1; yy = (float)y0; } else y1i = y0 + 1;
+        if (x0 >= W - 1) { x0 = x1i = W - 1; xx = (float)x0; } else x1i = x0 + 1;
+        const float ly = yy - y0, lx = xx - x0, hy = 1.f - ly, hx = 1.f - lx;
+        acc += hy * hx * f[y0 * W + x0] + hy * lx * f[y0 * W + x1i] + ly * hx * f[y1i * W + x0] + ly * lx * f[y1i * W + x1i];
+      }
+    }
+    out[idx] = acc / (float)(gh * gw);
+  }
+}
+
+extern "C" int ttdg_roi_align_multilevel(ttdg_fpn_t fp, ttdg_levels_t lv, const float* rois, int R, int P, float canonical_size,
+                                         int canonical_level, int min_level, float* out, ttdg_stream_t stream) {
+  TTDG_REQUIRE(rois && out && R >= 0 && P > 0 && fp.n >= 1 && fp.n <= TTDG_MAX_LEVELS && fp.C > 0 && lv.n == fp.n,
+               "roi_align_multilevel: bad arguments");
+  if (R == 0) return 0;
+  const long total = (long)R * fp.C * P * P;
+  const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+  hipLaunchKernelGGL(roi_align_ml_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, fp, lv, rois, R, P, canonical_size,
+                     canonical_level, min_level, out);
+  return ttdg_launch_status("roi_align_multilevel");
+}

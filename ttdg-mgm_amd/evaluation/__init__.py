@@ -110,14 +110,26 @@ class DiceEvaluator:
         return self._gt_cache[key]
 
     def process(self, inputs, outputs):
-        """Enqueues everything on the device; the only synchronisation is the class-id list of the kept predictions."""
-        for inp, out in zip(inputs, outputs):
-            inst = out["instances"]
-            keep = inst.scores >= self.score_threshold
-            masks, classes = inst.pred_masks[keep], inst.pred_classes[keep]
-            gts = self._gt(inp["image_id"], masks.device)
-            zero = torch.zeros((), dtype=torch.float64, device=masks.device)
-            for pc, pm in zip(classes.tolist(), masks):
+        """Enqueues everything on the device; ONE host read per batch (which predictions pass the score threshold and their
+        classes), none when nothing passes."""
+        insts = [out["instances"] for out in outputs]
+        lens = [len(i) for i in insts]
+        if sum(lens) == 0:
+            return
+        scores = torch.cat([i.scores for i in insts])
+        classes = torch.cat([i.pred_classes for i in insts])
+        sel = torch.where(scores >= self.score_threshold, classes, torch.full_like(classes, -1)).tolist()      # the one read
+        start = 0
+        for inp, inst, n in zip(inputs, insts, lens):
+            mine = sel[start:start + n]
+            start += n
+            kept = [k for k, c in enumerate(mine) if c >= 0]
+            if not kept:
+                continue
+            gts = self._gt(inp["image_id"], inst.pred_masks.device)
+            zero = torch.zeros((), dtype=torch.float64, device=inst.pred_masks.device)
+            for k in kept:
+                pc, pm = mine[k], inst.pred_masks[k]
                 bd = be = bs = zero
                 for gc, gm, cen in gts:
                     if pc == gc:

@@ -149,19 +149,11 @@ class ROIPooler:
         return torch.cat([torch.cat((b.tensor.new_full((len(b), 1), float(i)), b.tensor), 1) for i, b in enumerate(box_lists)], 0)
 
     def __call__(self, feats, box_lists, rois=None):
+        """One launch for the whole batch: every ROI picks its level inside the kernel (no per-level nonzero / host read)."""
         if rois is None:
             rois = self.make_rois(box_lists)
-        R = rois.shape[0]
-        out = feats[0].new_zeros((R, feats[0].shape[1], self.P, self.P), dtype=torch.float32)
-        if R == 0:
-            return out
-        area = (rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2])
-        lvl = torch.floor(self.cl + torch.log2(torch.sqrt(area.clamp(min=0)) / self.cbs + 1e-8)).clamp(self.min_level, self.max_level).long() - self.min_level
-        for l, (f, s) in enumerate(zip(feats, self.scales)):
-            idx = torch.nonzero(lvl == l).squeeze(1)
-            if idx.numel():
-                out[idx] = _backend.roi_align(f, rois[idx], s, self.P)
-        return out
+        strides = [int(round(1.0 / s)) for s in self.scales]
+        return _backend.roi_align_multilevel(feats, rois, strides, self.P, self.cbs, self.cl, self.min_level)
 
 
 class FastRCNNConvFCHead(nn.Module):

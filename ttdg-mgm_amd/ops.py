@@ -417,6 +417,28 @@ def roi_align(feat, rois, scale, P):
     return out
 
 
+def roi_align_multilevel(feats, rois, strides, P, canonical_size=224, canonical_level=4, min_level=2):
+    """ROIPooler [3P] in one launch: feats = the FPN maps of levels min_level.. (fp32 NCHW), rois (R, 5); every ROI picks
+    its level inside the kernel.  Returns (R, C, P, P).  No host read."""
+    rois = rois.detach().float().contiguous()
+    R = rois.shape[0]
+    Cc = feats[0].shape[1]
+    fp = _lib.Fpn()
+    fp.n, fp.C = len(feats), Cc
+    keep = []
+    for l, f in enumerate(feats):
+        f = f.detach()
+        if f.dtype != torch.float32 or not f.is_contiguous():
+            f = f.float().contiguous()
+        keep.append(f)
+        fp.h[l], fp.w[l], fp.feat[l] = f.shape[2], f.shape[3], ptr(f)
+    lv = levels_desc([f.shape[2:] for f in keep], strides=tuple(strides) + (0,) * (8 - len(strides)), ranges=((0, 0),) * len(keep))
+    out = torch.empty(R, Cc, P, P, device=rois.device, dtype=torch.float32)
+    call("ttdg_roi_align_multilevel", fp, lv, ptr(rois), R, int(P), float(canonical_size), int(canonical_level), int(min_level),
+         ptr(out), stream())
+    return out
+
+
 def nms_launch(boxes, scores, thr, group=None, ngroups=None, max_group=None, topk=None):
     """Enqueue greedy NMS without synchronising.  With ``group`` (ids in [0, ngroups)) the groups are independent
     problems swept concurrently (one wavefront each); ``max_group`` bounds the largest group (default N).
