@@ -101,7 +101,12 @@ int ttdg_sinkhorn_pairs_bwd(const float* part, int ksplit, const float* b2, cons
  * out is (b, r, c) contiguous.  Orientation, dummy rows and padding as SURVEY.md Appendix B. */
 int ttdg_sinkhorn_batched_fwd(const float* s, int64_t sb, int64_t sr, int64_t sc, int b, int r, int c,
                               const int32_t* n1, const int32_t* n2, int dummy_row, float tau, int iters,
-                              float* out, ttdg_stream_t stream);
+                              float* out, float* pot, ttdg_stream_t stream);
+/* pot (optional, forward): (b, iters, max(r,c)+1) floats of per-sweep potentials, iters <= 64; required by the backward:
+ * dout = d loss / d out (b, r, c) contiguous -> ds = d loss / d s (b, r, c) contiguous, zero on the padding. */
+int ttdg_sinkhorn_batched_bwd(const float* s, int64_t sb, int64_t sr, int64_t sc, int b, int r, int c,
+                              const int32_t* n1, const int32_t* n2, int dummy_row, float tau, int iters,
+                              const float* pot, const float* dout, float* ds, ttdg_stream_t stream);
 
 /* ---- A3 intra-graph attention adjacency (utils/attentions.py:60-86, v2, 1 head) --
  * q, k: (M, d) projections (ttdg_gemm_f32).  Apack receives, per graph, softmax(q k^T * scale)

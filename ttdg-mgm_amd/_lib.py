@@ -58,7 +58,8 @@ SIGNATURES = {
     "ttdg_affinity_pairwise_bwd": (C.c_int, [_P, _P, _P, _P, _I, Graphs, _P, _P, _P, _P, _P, _S]),
     "ttdg_sinkhorn_pairs_fwd": (C.c_int, [_P, _I, _P, Graphs, _F, _I, _P, _P, _S]),
     "ttdg_sinkhorn_pairs_bwd": (C.c_int, [_P, _I, _P, _P, _P, Graphs, _F, _I, _P, _S]),
-    "ttdg_sinkhorn_batched_fwd": (C.c_int, [_P, _L, _L, _L, _I, _I, _I, _P, _P, _I, _F, _I, _P, _S]),
+    "ttdg_sinkhorn_batched_fwd": (C.c_int, [_P, _L, _L, _L, _I, _I, _I, _P, _P, _I, _F, _I, _P, _P, _S]),
+    "ttdg_sinkhorn_batched_bwd": (C.c_int, [_P, _L, _L, _L, _I, _I, _I, _P, _P, _I, _F, _I, _P, _P, _P, _S]),
     "ttdg_mha_adjacency": (C.c_int, [_P, _P, _I, Graphs, _F, _F, C.c_uint64, _I, _P, _S]),
     "ttdg_gagm_workspace_bytes": (C.c_size_t, [_I]),
     "ttdg_gagm_solve": (C.c_int, [_P, _P, _P, Graphs, GagmCfg, _P, _P, _P, _S]),

@@ -321,31 +321,13 @@ extern "C" int ttdg_sinkhorn_pairs_fwd(const float* part, int ksplit, const floa
 //   line sums  S = sum over the line of dY   (dummy row counted `mult` times in column lines)
 //   dY -= exp(y^(k)) * S,   y^(k) = L - f^(k) - g^(k) rebuilt from the logged potentials.
 // dL = dY after sweep 0;  dM = dL / tau.
+// Backward of one oriented Sinkhorn problem (shared by the pair stage and the stand-alone batched operator).
+// pt: logged potentials of the forward (iters x potld); dout(p,q) / dm(p,q) addressed with the given strides.
+// smem carve: [f: c+1][g: c][ls: c+1][dd: c][L: r*ldm (kLds)][dY: r*ldm (kLds)]
 template <bool kLds>
-__global__ void sinkhorn_pairs_bwd_kernel(const float* __restrict__ part, int ksplit, const float* __restrict__ b2,
-                                          const float* __restrict__ pot, const float* __restrict__ dWds,
-                                          ttdg_graphs_t gr, float tau, int iters, float* __restrict__ dM, int cmax) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  // pairs with a > b only: index over (1,0),(2,0),(2,1),...
-  int a = 1, idx = blockIdx.x;
-  while (idx >= a) { idx -= a; ++a; }
-  const int b = idx;
-  const int pair_fwd = a * (a + 1) / 2 + b;
-  const int M = gr.off[gr.G];
-  const int na = gr.off[a + 1] - gr.off[a], nb = gr.off[b + 1] - gr.off[b];
-  const float* blk = part + (size_t)gr.off[a] * M + gr.off[b];
-  const float* dout = dWds + (size_t)gr.off[b] * M + gr.off[a];  // loss reads Wds[b-rows, a-cols] = out^T
-  float* dm = dM + (size_t)gr.off[a] * M + gr.off[b];
-  SkProb pb;
-  pb.src = blk; pb.splane = (int64_t)M * M; pb.nplanes = ksplit;
-  pb.bias = b2 ? *b2 : 0.f; pb.scale = TTDG_LOG2E / tau;
-  int64_t dop, doq, dmp, dmq;  // strides of dOut / dM in oriented (p,q) coordinates
-  if (nb >= na) { pb.r = na; pb.c = nb; pb.sp = M; pb.sq = 1; dop = 1; doq = M; dmp = M; dmq = 1; }
-  else          { pb.r = nb; pb.c = na; pb.sp = 1; pb.sq = M; dop = M; doq = 1; dmp = 1; dmq = M; }
-  pb.mult = pb.c - pb.r;
-  const int r = pb.r, c = pb.c, mult = pb.mult, potld = cmax + 1;
-  const float* pt = pot + (size_t)pair_fwd * iters * potld;
-
+__device__ void sk_backward(const SkProb& pb, const float* __restrict__ pt, int potld, const float* __restrict__ dout, int64_t dop,
+                            int64_t doq, float* __restrict__ dm, int64_t dmp, int64_t dmq, float* smem, int iters, float tau) {
+  const int r = pb.r, c = pb.c, mult = pb.mult;
   const int ldm = c | 1;
   float* f = smem;            // r+1
   float* g = f + c + 1;       // c
@@ -420,6 +402,31 @@ __global__ void sinkhorn_pairs_bwd_kernel(const float* __restrict__ part, int ks
   }
 }
 
+template <bool kLds>
+__global__ void sinkhorn_pairs_bwd_kernel(const float* __restrict__ part, int ksplit, const float* __restrict__ b2,
+                                          const float* __restrict__ pot, const float* __restrict__ dWds,
+                                          ttdg_graphs_t gr, float tau, int iters, float* __restrict__ dM, int cmax) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // pairs with a > b only: index over (1,0),(2,0),(2,1),...
+  int a = 1, idx = blockIdx.x;
+  while (idx >= a) { idx -= a; ++a; }
+  const int b = idx;
+  const int pair_fwd = a * (a + 1) / 2 + b;
+  const int M = gr.off[gr.G];
+  const int na = gr.off[a + 1] - gr.off[a], nb = gr.off[b + 1] - gr.off[b];
+  const float* blk = part + (size_t)gr.off[a] * M + gr.off[b];
+  const float* dout = dWds + (size_t)gr.off[b] * M + gr.off[a];  // loss reads Wds[b-rows, a-cols] = out^T
+  float* dm = dM + (size_t)gr.off[a] * M + gr.off[b];
+  SkProb pb;
+  pb.src = blk; pb.splane = (int64_t)M * M; pb.nplanes = ksplit;
+  pb.bias = b2 ? *b2 : 0.f; pb.scale = TTDG_LOG2E / tau;
+  int64_t dop, doq, dmp, dmq;  // strides of dOut / dM in oriented (p,q) coordinates
+  if (nb >= na) { pb.r = na; pb.c = nb; pb.sp = M; pb.sq = 1; dop = 1; doq = M; dmp = M; dmq = 1; }
+  else          { pb.r = nb; pb.c = na; pb.sp = 1; pb.sq = M; dop = M; doq = 1; dmp = 1; dmq = M; }
+  pb.mult = pb.c - pb.r;
+  const int potld = cmax + 1;
+  sk_backward<kLds>(pb, pot + (size_t)pair_fwd * iters * potld, potld, dout, dop, doq, dm, dmp, dmq, smem, iters, tau);
+}
 
 // register-resident backward for 128 < c <= 256: dY lives in registers (32 x 4 per lane, same ownership as the forward
 // kernel), L is streamed from L2 every sweep in groups of 4 rows (the next group's 16 loads are in flight under the
@@ -599,7 +606,7 @@ extern "C" int ttdg_sinkhorn_pairs_bwd(const float* part, int ksplit, const floa
 template <bool kLds>
 __global__ void sinkhorn_batched_kernel(const float* __restrict__ s, int64_t sb, int64_t sr, int64_t sc, int R, int C,
                                         const int32_t* __restrict__ n1, const int32_t* __restrict__ n2, int dummy,
-                                        float tau, int iters, float* __restrict__ out) {
+                                        float tau, int iters, float* __restrict__ out, float* __restrict__ pot) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int bi = blockIdx.x;
   // Appendix B steps 1-3: the valid block is nr x nc inside the (R, C) frame; orient it rows <= cols.
@@ -619,15 +626,67 @@ __global__ void sinkhorn_batched_kernel(const float* __restrict__ s, int64_t sb,
   else       { pb.r = nc; pb.c = nr; pb.sp = sc; pb.sq = sr; pb.op = 1; pb.oq = C; }
   pb.out = o; pb.mir = nullptr; pb.mp = pb.mq = 0;
   pb.mult = dummy ? pb.c - pb.r : 0;
-  pb.pot = nullptr; pb.potld = 0;
+  pb.potld = (R > C ? R : C) + 1;
+  pb.pot = pot ? pot + (size_t)bi * iters * pb.potld : nullptr;
   sk_forward<kLds>(pb, smem, iters);
+}
+
+// backward of the stand-alone operator: ds = d loss / d s from dout = d loss / d out and the logged potentials
+template <bool kLds>
+__global__ void sinkhorn_batched_bwd_kernel(const float* __restrict__ s, int64_t sb, int64_t sr, int64_t sc, int R, int C,
+                                            const int32_t* __restrict__ n1, const int32_t* __restrict__ n2, int dummy,
+                                            float tau, int iters, const float* __restrict__ pot,
+                                            const float* __restrict__ dout, float* __restrict__ ds) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int bi = blockIdx.x;
+  int nr = n1 ? n1[bi] : R, nc = n2 ? n2[bi] : C;
+  float* d = ds + (size_t)bi * R * C;
+  for (int e = threadIdx.x; e < R * C; e += blockDim.x) d[e] = 0.f;      // padding takes no gradient
+  __syncthreads();
+  if (nr <= 0 || nc <= 0) return;
+  SkProb pb;
+  pb.src = s + bi * sb; pb.splane = 0; pb.nplanes = 1; pb.bias = 0.f; pb.scale = TTDG_LOG2E / tau;
+  bool flip = (C < R);
+  int fr = flip ? nc : nr, fc = flip ? nr : nc;
+  if (fr > fc) flip = !flip;
+  int64_t op, oq;      // strides of the contiguous (R, C) gradient buffers in oriented (p, q) coordinates
+  if (!flip) { pb.r = nr; pb.c = nc; pb.sp = sr; pb.sq = sc; op = C; oq = 1; }
+  else       { pb.r = nc; pb.c = nr; pb.sp = sc; pb.sq = sr; op = 1; oq = C; }
+  pb.mult = dummy ? pb.c - pb.r : 0;
+  const int potld = (R > C ? R : C) + 1;
+  sk_backward<kLds>(pb, pot + (size_t)bi * iters * potld, potld, dout + (size_t)bi * R * C, op, oq, d, op, oq, smem, iters, tau);
+}
+
+extern "C" int ttdg_sinkhorn_batched_bwd(const float* s, int64_t sb, int64_t sr, int64_t sc, int b, int r, int c,
+                                         const int32_t* n1, const int32_t* n2, int dummy_row, float tau, int iters,
+                                         const float* pot, const float* dout, float* ds, ttdg_stream_t stream) {
+  TTDG_REQUIRE(s && pot && dout && ds && b >= 0 && r > 0 && c > 0 && tau > 0.f, "sinkhorn_batched_bwd: bad arguments");
+  TTDG_REQUIRE(iters >= 1 && iters <= SK_MAXK, "sinkhorn_batched_bwd: iters out of range (the potentials of every sweep are logged)");
+  if (b == 0) return 0;
+  const int lo = r < c ? r : c, hi = r < c ? c : r;
+  const size_t base = (size_t)(4 * (hi + 1) + 4) * sizeof(float);
+  const size_t need = base + (size_t)2 * lo * (hi | 1) * sizeof(float);
+  const bool lds = need <= SK_LDS_CAP;
+  const size_t bytes = lds ? need : base;
+  const int threads = hi <= 64 ? 256 : 1024;
+  hipStream_t st = (hipStream_t)stream;
+  if (lds) {
+    TTDG_ALLOW_LDS((sinkhorn_batched_bwd_kernel<true>), bytes);
+    hipLaunchKernelGGL((sinkhorn_batched_bwd_kernel<true>), dim3(b), dim3(threads), bytes, st, s, sb, sr, sc, r, c, n1, n2, dummy_row,
+                       tau, iters, pot, dout, ds);
+  } else {
+    hipLaunchKernelGGL((sinkhorn_batched_bwd_kernel<false>), dim3(b), dim3(threads), bytes, st, s, sb, sr, sc, r, c, n1, n2,
+                       dummy_row, tau, iters, pot, dout, ds);
+  }
+  return ttdg_launch_status("sinkhorn_batched_bwd");
 }
 
 extern "C" int ttdg_sinkhorn_batched_fwd(const float* s, int64_t sb, int64_t sr, int64_t sc, int b, int r, int c,
                                          const int32_t* n1, const int32_t* n2, int dummy_row, float tau, int iters,
-                                         float* out, ttdg_stream_t stream) {
+                                         float* out, float* pot, ttdg_stream_t stream) {
   TTDG_REQUIRE(s && out && b >= 0 && r > 0 && c > 0 && tau > 0.f, "sinkhorn_batched: bad arguments");
   TTDG_REQUIRE(iters >= 0 && iters <= 4096, "sinkhorn_batched: iters out of range");
+  TTDG_REQUIRE(!pot || iters <= SK_MAXK, "sinkhorn_batched: potentials can be logged for at most 64 sweeps");
   if (b == 0) return 0;
   const int lo = r < c ? r : c, hi = r < c ? c : r;
   const bool lds = sk_lds_bytes(lo, hi, true, 1) <= SK_LDS_CAP;
@@ -637,10 +696,10 @@ extern "C" int ttdg_sinkhorn_batched_fwd(const float* s, int64_t sb, int64_t sr,
   if (lds) {
     TTDG_ALLOW_LDS((sinkhorn_batched_kernel<true>), bytes);
     hipLaunchKernelGGL((sinkhorn_batched_kernel<true>), dim3(b), dim3(threads), bytes, st, s, sb, sr, sc, r, c, n1, n2,
-                       dummy_row, tau, iters, out);
+                       dummy_row, tau, iters, out, pot);
   } else {
     hipLaunchKernelGGL((sinkhorn_batched_kernel<false>), dim3(b), dim3(threads), bytes, st, s, sb, sr, sc, r, c, n1, n2,
-                       dummy_row, tau, iters, out);
+                       dummy_row, tau, iters, out, pot);
   }
   return ttdg_launch_status("sinkhorn_batched");
 }

@@ -122,16 +122,46 @@ def sinkhorn_pairs_bwd(part, b2, pot, dWds, gr, tau, iters):
     return dM
 
 
-def sinkhorn_batched(s, n1=None, n2=None, dummy_row=False, tau=1.0, iters=10):
-    """(b, r, c) -> (b, r, c); any strides on the input."""
+def sinkhorn_batched(s, n1=None, n2=None, dummy_row=False, tau=1.0, iters=10, want_pot=False):
+    """(b, r, c) -> (b, r, c); any strides on the input.  ``want_pot`` also returns the per-sweep potentials the backward
+    needs ((b, iters, max(r,c)+1), iters <= 64)."""
     assert s.dim() == 3 and s.dtype == torch.float32
     b, r, c = s.shape
     out = torch.empty(b, r, c, device=s.device, dtype=torch.float32)
     n1 = None if n1 is None else n1.to(device=s.device, dtype=torch.int32).contiguous()
     n2 = None if n2 is None else n2.to(device=s.device, dtype=torch.int32).contiguous()
+    pot = torch.zeros(b, int(iters), max(r, c) + 1, device=s.device, dtype=torch.float32) if want_pot else None
     call("ttdg_sinkhorn_batched_fwd", ptr(s), s.stride(0), s.stride(1), s.stride(2), b, r, c, ptr(n1), ptr(n2),
-         int(bool(dummy_row)), float(tau), int(iters), ptr(out), stream())
-    return out
+         int(bool(dummy_row)), float(tau), int(iters), ptr(out), ptr(pot), stream())
+    return (out, pot) if want_pot else out
+
+
+def sinkhorn_batched_bwd(s, pot, dout, n1=None, n2=None, dummy_row=False, tau=1.0, iters=10):
+    b, r, c = s.shape
+    n1 = None if n1 is None else n1.to(device=s.device, dtype=torch.int32).contiguous()
+    n2 = None if n2 is None else n2.to(device=s.device, dtype=torch.int32).contiguous()
+    ds = torch.empty(b, r, c, device=s.device, dtype=torch.float32)
+    call("ttdg_sinkhorn_batched_bwd", ptr(s), s.stride(0), s.stride(1), s.stride(2), b, r, c, ptr(n1), ptr(n2),
+         int(bool(dummy_row)), float(tau), int(iters), ptr(pot), ptr(dout.float().contiguous()), ptr(ds), stream())
+    return ds
+
+
+class SinkhornFn(torch.autograd.Function):
+    """Differentiable stand-alone Sinkhorn (utils/sinkhorn.py:58-87): forward logs 20-odd small potential vectors, the
+    backward rebuilds every sweep from them (no K stored matrices, no autograd graph through the sweeps)."""
+
+    @staticmethod
+    def forward(ctx, s, n1, n2, dummy_row, tau, iters):
+        out, pot = sinkhorn_batched(s, n1, n2, dummy_row, tau, iters, want_pot=True)
+        ctx.save_for_backward(s, pot)
+        ctx.args = (n1, n2, dummy_row, tau, iters)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        s, pot = ctx.saved_tensors
+        n1, n2, dummy_row, tau, iters = ctx.args
+        return sinkhorn_batched_bwd(s, pot, dout, n1, n2, dummy_row, tau, iters), None, None, None, None, None
 
 
 def mha_adjacency(q, k, gr, sizes, scale, drop_p=0.0, seed=0, zero_diag=True):
