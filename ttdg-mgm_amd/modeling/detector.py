@@ -211,6 +211,7 @@ class StandardROIHeadsPseudoLab(nn.Module):
         self.mask_head = MaskRCNNConvUpsampleHead(num_classes)
         self.score_thresh, self.nms_thresh, self.topk = score_thresh, nms_thresh, topk_per_image
         self.bbox_weights = (10.0, 10.0, 5.0, 5.0)
+        self._const_cache = {}
 
     @torch.no_grad()
     def _forward_box(self, feats, proposals):
@@ -243,6 +244,72 @@ class StandardROIHeadsPseudoLab(nn.Module):
             inst.pred_masks = prob[start:start + n]
             start += n
         return instances
+
+    # ---- dense (padded) inference: no host read between the RPN and the final results ------------------------------
+    def _const(self, key, build):
+        c = self._const_cache.get(key)
+        if c is None:
+            c = build()
+            if c.is_cuda:
+                torch.cuda.current_stream(c.device).synchronize()      # cached constants may be read from other streams
+            self._const_cache[key] = c
+        return c
+
+    @torch.no_grad()
+    def box_dense(self, features, boxes, scores, keep, image_sizes):
+        """Box head on the RPN's dense output (boxes (B, K, 4), scores (B, K), keep (B, post) by descending score; slots
+        beyond an image's proposal count carry score -inf and yield no detection).  Returns the detections padded to
+        ``topk`` per image: boxes (B, topk, 4), scores (B, topk) (-inf = empty slot), classes (B, topk), counts (B,) device."""
+        C, dev = self.num_classes, boxes.device
+        B, post = keep.shape
+        feats = [features[f].detach() for f in self.box_in_features]
+        pb = boxes.gather(1, keep[..., None].expand(-1, -1, 4))
+        ps = scores.gather(1, keep)
+        img = self._const(("img", B, post, str(dev)), lambda: torch.arange(B, device=dev, dtype=torch.float32).repeat_interleave(post)[:, None])
+        rois = torch.cat((img, pb.reshape(-1, 4)), 1)
+        logits, deltas = self.box_predictor(self.box_head(self.box_pooler(feats, None, rois)))
+        sizes_t = _backend.image_sizes_tensor(image_sizes, dev)
+        cb, cs = _backend.box_inference(logits, deltas, rois, sizes_t, C, self.bbox_weights, self.score_thresh)
+        cs = torch.where(ps.reshape(-1, 1) > float("-inf"), cs, cs.new_full((), float("-inf")))       # padded proposals
+        col_cls = self._const(("cls", post, C, str(dev)), lambda: torch.arange(post * C, device=dev, dtype=torch.int64) % C)
+        cbv, csv = cb.view(B, post * C, 4), cs.view(B, post * C)
+        didx, dcounts = _backend.nms_batched(cbv, csv, col_cls, C, self.nms_thresh, post, self.topk, device_counts=True)
+        dscores = csv.gather(1, didx)
+        live = dscores > float("-inf")
+        dboxes = torch.where(live[..., None], cbv.gather(1, didx[..., None].expand(-1, -1, 4)), cbv.new_zeros(()))
+        return dboxes, dscores, didx % C, dcounts
+
+    @torch.no_grad()
+    def inference_dense(self, features, boxes, scores, keep, image_sizes, out_size, mask_threshold=0.5):
+        """Whole eval-mode ROI stage + detector_postprocess on padded tensors, ONE host read at the end.  All images share
+        the output size `out_size` (H, W).  Returns the per-image Instances of detector_postprocess."""
+        dev = boxes.device
+        dboxes, dscores, dcls, _ = self.box_dense(features, boxes, scores, keep, image_sizes)
+        B, T = dscores.shape
+        feats = [features[f].detach() for f in self.mask_in_features]
+        img = self._const(("img", B, T, str(dev)), lambda: torch.arange(B, device=dev, dtype=torch.float32).repeat_interleave(T)[:, None])
+        mlogits = self.mask_head(self.mask_pooler(feats, None, torch.cat((img, dboxes.reshape(-1, 4)), 1)))
+        ar = self._const(("ar", B * T, str(dev)), lambda: torch.arange(B * T, device=dev))
+        prob = mlogits[ar, dcls.reshape(-1)].sigmoid()
+        # detector_postprocess: rescale to the output size, clip, drop empty boxes
+        H, W = out_size
+        sc = self._const(("scale", tuple(image_sizes), H, W, str(dev)), lambda: torch.tensor(
+            [[W / s[1], H / s[0], W / s[1], H / s[0]] for s in image_sizes], dtype=torch.float32).to(dev)[:, None, :])
+        ob = dboxes * sc
+        ob = torch.stack((ob[..., 0].clamp(0, W), ob[..., 1].clamp(0, H), ob[..., 2].clamp(0, W), ob[..., 3].clamp(0, H)), -1)
+        valid = (dscores > float("-inf")) & (ob[..., 2] - ob[..., 0] > 0) & (ob[..., 3] - ob[..., 1] > 0)
+        pasted = paste_masks_in_image(prob[:, None], ob.reshape(-1, 4), (H, W), mask_threshold).view(B, T, H, W)
+        vl = valid.tolist()                                        # the one host read of the stage
+        out = []
+        for b in range(B):
+            idx = [k for k, v in enumerate(vl[b]) if v]
+            if idx == list(range(len(idx))):
+                sel = slice(0, len(idx))                           # the usual case: survivors are a prefix
+            else:
+                sel = torch.tensor(idx, dtype=torch.int64, device=dev)
+            out.append(Instances((H, W), pred_boxes=Boxes(ob[b, sel]), scores=dscores[b, sel], pred_classes=dcls[b, sel],
+                                 pred_masks=pasted[b, sel]))
+        return out
 
     def forward(self, images, features, proposals, targets=None, compute_loss=True, branch=""):
         if compute_loss:

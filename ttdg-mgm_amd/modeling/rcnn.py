@@ -22,6 +22,9 @@ class FCDiscriminator_img(nn.Module):
         self.classifier = nn.Conv2d(ndf2, 1, 3, padding=1)
 
 
+DENSE_INFERENCE = True      # eval-mode inference on padded tensors (one host read per batch); False = the list-of-Instances path
+
+
 class DAobjTwoStagePseudoLabGeneralizedRCNN(nn.Module):
     def __init__(self, *, backbone, proposal_generator, roi_heads, pixel_mean, pixel_std, input_format=None,
                  vis_period=0, dis_type="p2"):
@@ -87,6 +90,12 @@ class DAobjTwoStagePseudoLabGeneralizedRCNN(nn.Module):
     def inference(self, batched_inputs, do_postprocess=True):
         images = self.preprocess_image(batched_inputs)
         features = self._backbone(images.tensor)
+        out_sizes = [(x.get("height", sz[0]), x.get("width", sz[1])) for x, sz in zip(batched_inputs, images.image_sizes)]
+        if do_postprocess and DENSE_INFERENCE and len(set(out_sizes)) == 1:
+            # padded tensors from the RPN to the pasted masks: one host read per batch instead of four
+            boxes, scores, keep, _ = self.proposal_generator.forward_dense(features, images.image_sizes)
+            res = self.roi_heads.inference_dense(features, boxes, scores, keep, images.image_sizes, out_sizes[0])
+            return [{"instances": r} for r in res]
         proposals, _ = self.proposal_generator(images, features, None, compute_loss=False)
         results, _ = self.roi_heads(images, features, proposals, None, compute_loss=False, branch="")
         if not do_postprocess:
