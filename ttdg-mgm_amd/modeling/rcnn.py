@@ -70,10 +70,21 @@ class DAobjTwoStagePseudoLabGeneralizedRCNN(nn.Module):
         images = self.preprocess_image(batched_inputs)
         features = self._backbone(images.tensor)
         if branch == "TTT":
-            proposals_rpn, _ = self.proposal_generator(images, features, None, compute_loss=False)
-            proposals_roih, _ = self.roi_heads(images, features, proposals_rpn, targets=None, compute_loss=False, branch=branch)
-            if self.teacher_forced:
-                proposals_roih = [self._forced(x, sz) for x, sz in zip(batched_inputs, images.image_sizes)]
+            if DENSE_INFERENCE:
+                # RPN + box head on padded tensors: one host read (the detection counts) instead of two - none at all
+                # when the detections are replaced by the teacher-forced boxes (the kernels still run)
+                boxes, scores, keep, _ = self.proposal_generator.forward_dense(features, images.image_sizes)
+                dboxes, dscores, dcls, dcounts = self.roi_heads.box_dense(features, boxes, scores, keep, images.image_sizes)
+                if self.teacher_forced:
+                    proposals_roih = [self._forced(x, sz) for x, sz in zip(batched_inputs, images.image_sizes)]
+                else:
+                    proposals_roih = [Instances(sz, pred_boxes=Boxes(dboxes[b, :n]), scores=dscores[b, :n], pred_classes=dcls[b, :n])
+                                      for b, (n, sz) in enumerate(zip(dcounts.tolist(), images.image_sizes))]
+            else:
+                proposals_rpn, _ = self.proposal_generator(images, features, None, compute_loss=False)
+                proposals_roih, _ = self.roi_heads(images, features, proposals_rpn, targets=None, compute_loss=False, branch=branch)
+                if self.teacher_forced:
+                    proposals_roih = [self._forced(x, sz) for x, sz in zip(batched_inputs, images.image_sizes)]
             feats = [features[k] for k in ("p2", "p3", "p4", "p5", "p6")]
             nodes, labels = self.graph_generator(feats, proposals_roih)
             loss = self.multi_matching_unsup(nodes, labels, self.multi_matching_sup.U)
