@@ -113,3 +113,29 @@ def test_family_means_like_the_reference_trainer():
         for k, v in value.items():
             fam[key.split('_')[0]][k].append(v)
     assert {k: sum(v) / len(v) for k, v in fam["a"].items()}["Dice Coefficient"] == 2.0
+
+
+def test_dense_and_list_inference_agree_on_the_host_backend():
+    """The padded (dense) eval inference and the list-of-Instances formulation are the same map: with the host backend
+    (deterministic torch-CPU kernels + the oracle's detection helpers) the detections are bit-identical."""
+    import torch
+    from oracle import tta_cpu
+    from ttdg_mgm_amd.modeling import detector, rcnn
+    cfg, model, batches, det, name = tta_cpu._model_and_batches(1, 2, 128, True)
+    saved = detector._backend
+    detector._backend = tta_cpu._CpuBackend
+    model.eval()
+    try:
+        with torch.no_grad():
+            rcnn.DENSE_INFERENCE = True
+            a = model(batches[0])
+            rcnn.DENSE_INFERENCE = False
+            b = model(batches[0])
+    finally:
+        rcnn.DENSE_INFERENCE = True
+        detector._backend = saved
+    for x, y in zip(a, b):
+        ia, ib = x["instances"], y["instances"]
+        assert len(ia) == len(ib) > 0
+        assert torch.equal(ia.pred_boxes.tensor, ib.pred_boxes.tensor) and torch.equal(ia.scores, ib.scores)
+        assert torch.equal(ia.pred_classes, ib.pred_classes) and torch.equal(ia.pred_masks, ib.pred_masks)
