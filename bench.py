@@ -8,7 +8,9 @@ with random-init weights (no checkpoints offline), TEST.BATCH = 4, 20-sweep Sink
 the eval-mode Dice pass over the same batches (reference order, engine/trainer.py:469-485).  Detections are
 "teacher-forced" (GT boxes jittered +-2 px) because a random-init detector finds nothing; RPN and box
 head still run inside the timed region.  One "step" = one adapted batch (TTA step + its share of the eval pass).
-Each rank adapts its own shard (InferenceSampler semantics, no data-path collective): weak scaling.
+Each rank adapts its own shard (InferenceSampler semantics, no data-path collective): weak scaling; at N > 1 the one
+collective of the path is the all-gather of the per-rank Dice score lists at the end of the eval pass (RCCL).  The eval
+pass feeds its independent batches from two host threads on two HIP streams (--eval-streams).
 
 Prints ONE JSON line on rank 0 with the contract fields plus `roofline` (dominant hand-written kernel, timed live
 with HIP events on the launch stream) and, at N = 1, `cpu_baseline` (the oracle "port" on the host cores, bounded
