@@ -27,6 +27,16 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // acc + w * |x| in ONE instruction.  Left to itself hipcc materialises |x| with v_and_b32 so that it can pair the
 // multiply-adds into v_pk_fma_f32 (packed operands have no abs modifier): 2 instructions per element instead of 1.5.
+// exact 0/1 step of a packed pair: 1 where d > 0 (down to the smallest denormal), else 0 -- two packed multiplies whose
+// [0,1] output clamp is a free modifier
+__device__ __forceinline__ f32x2 relu_step2(f32x2 d) {
+  const f32x2 big = {8.507059173023462e37f, 8.507059173023462e37f};     // 2^126
+  f32x2 t;
+  asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(t) : "v"(d), "v"(big));
+  asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(t) : "v"(t), "v"(big));
+  return t;
+}
+
 __device__ __forceinline__ float fma_abs(float w, float x, float acc) {
   asm("v_fma_f32 %0, %1, |%2|, %0" : "+v"(acc) : "v"(w), "v"(x));
   return acc;
@@ -180,15 +190,14 @@ __global__ __launch_bounds__(256) void affinity_bwd_kernel(const float* __restri
     cbeg = b0;
   }
 
-  float x[4][4], acc[4][4];
+  f32x2 x2[4][2], acc2[4][2];
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int r = r0 + ty * 4 + a;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r < M) v = *reinterpret_cast<const float4*>(X + (size_t)r * H + k0 + tx * 4);
-    x[a][0] = v.x; x[a][1] = v.y; x[a][2] = v.z; x[a][3] = v.w;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+    x2[a][0] = (f32x2){v.x, v.y}; x2[a][1] = (f32x2){v.z, v.w};
+    acc2[a][0] = acc2[a][1] = (f32x2){0.f, 0.f};
   }
 
   for (int c0 = cbeg; c0 < cend; c0 += BC) {
@@ -241,11 +250,16 @@ __global__ __launch_bounds__(256) void affinity_bwd_kernel(const float* __restri
       const float4 d = *reinterpret_cast<const float4*>(&Dt[cc][ty * 4]);
       const float4 y = *reinterpret_cast<const float4*>(&Ys[cc][tx * 4]);
       const float dv[4] = {d.x, d.y, d.z, d.w};
-      const float yv[4] = {y.x, y.y, y.z, y.w};
+      const f32x2 y01 = {y.x, y.y}, y23 = {y.z, y.w};
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] += (x[a][b] > yv[b]) ? dv[a] : 0.f;
+      for (int a = 0; a < 4; ++a) {
+        // relu'(x + y) = [x > -y] as an exact 0/1 step WITHOUT a compare (no VCC round trip between v_cmp and
+        // v_cndmask): step = clamp(clamp((x - (-y)) * 2^126) * 2^126), the clamps being the free [0,1] output modifier
+        // of the packed multiply; positive differences down to the smallest denormal saturate to 1, the rest to 0.
+        // acc += step * d is then bit-identical to the select-add, in 4 packed instructions per two k.
+        acc2[a][0] = __builtin_elementwise_fma(relu_step2(x2[a][0] - y01), (f32x2){dv[a], dv[a]}, acc2[a][0]);
+        acc2[a][1] = __builtin_elementwise_fma(relu_step2(x2[a][1] - y23), (f32x2){dv[a], dv[a]}, acc2[a][1]);
+      }
     }
     __syncthreads();
   }
@@ -253,7 +267,7 @@ __global__ __launch_bounds__(256) void affinity_bwd_kernel(const float* __restri
   for (int a = 0; a < 4; ++a) {
     const int r = r0 + ty * 4 + a;
     if (r < M)
-      *reinterpret_cast<float4*>(O + (size_t)r * H + k0 + tx * 4) = make_float4(acc[a][0], acc[a][1], acc[a][2], acc[a][3]);
+      *reinterpret_cast<float4*>(O + (size_t)r * H + k0 + tx * 4) = make_float4(acc2[a][0].x, acc2[a][0].y, acc2[a][1].x, acc2[a][1].y);
   }
 }
 
