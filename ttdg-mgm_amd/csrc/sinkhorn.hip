@@ -428,7 +428,7 @@ __global__ void sinkhorn_pairs_bwd_kernel(const float* __restrict__ part, int ks
   sk_backward<kLds>(pb, pot + (size_t)pair_fwd * iters * potld, potld, dout, dop, doq, dm, dmp, dmq, smem, iters, tau);
 }
 
-// register-resident backward for 128 < c <= 256: dY lives in registers (32 x 4 per lane, same ownership as the forward
+// register-resident backward for 128 < c <= 256: dY lives in registers (16 x 4 per lane, same ownership as the forward
 // kernel), L is streamed from L2 every sweep in groups of 4 rows (the next group's 16 loads are in flight under the
 // current group's exps), potentials come from the forward log; row sums are DPP wavefront reductions, column sums meet
 // in LDS with one barrier per column sweep (double-buffered, every wavefront finishes all columns).
