@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=64)
     ap.add_argument("--eval-streams", type=int, default=2, help="concurrent eval batches (HIP streams) in the Dice pass; 1 = sequential")
+    ap.add_argument("--no-overlap-detector", action="store_true", help="A/B: keep the teacher-forced RPN + box head on the main stream")
     ap.add_argument("--eval-coalesce", type=int, default=1, help="loader batches merged into one inference call in the Dice pass; 1 = none")
     ap.add_argument("--free-running", action="store_true", help="use the detector's own boxes instead of teacher forcing")
     ap.add_argument("--bf16-backbone", action="store_true", help="cfg-5 style: bf16 autocast for the backbone only")
@@ -62,6 +63,9 @@ def build(cfg_id, n_images, args, device, rank, world):
     torch.manual_seed(0)
     model = BaselineTrainer.build_model(cfg)
     model.teacher_forced = not args.free_running
+    if args.no_overlap_detector:
+        from ttdg_mgm_amd.modeling import rcnn as _rcnn
+        _rcnn.OVERLAP_DETECTOR = False
     model.autocast_backbone = args.bf16_backbone
     opt = BaselineTrainer.build_optimizer(cfg, model)
     BaselineTrainer.rank, BaselineTrainer.world, BaselineTrainer.device = rank, world, device

@@ -22,6 +22,8 @@ class FCDiscriminator_img(nn.Module):
         self.classifier = nn.Conv2d(ndf2, 1, 3, padding=1)
 
 
+_SIDE_STREAMS = {}          # device -> the second HIP stream of the TTT branch
+OVERLAP_DETECTOR = True     # teacher-forced TTT steps: run the (unused) RPN + box head on a second HIP stream next to the solver
 DENSE_INFERENCE = True      # eval-mode inference on padded tensors (one host read per batch); False = the list-of-Instances path
 
 
@@ -73,8 +75,23 @@ class DAobjTwoStagePseudoLabGeneralizedRCNN(nn.Module):
             if DENSE_INFERENCE:
                 # RPN + box head on padded tensors: one host read (the detection counts) instead of two - none at all
                 # when the detections are replaced by the teacher-forced boxes (the kernels still run)
-                boxes, scores, keep, _ = self.proposal_generator.forward_dense(features, images.image_sizes)
-                dboxes, dscores, dcls, dcounts = self.roi_heads.box_dense(features, boxes, scores, keep, images.image_sizes)
+                side = None
+                if self.teacher_forced and OVERLAP_DETECTOR and images.tensor.is_cuda:
+                    # teacher-forced detections: the RPN and the box head still run, but nothing downstream waits for
+                    # them, so they go to a second HIP stream and overlap the (single-CU, latency-bound) matching solver;
+                    # joined before the step returns.  With the detector's own boxes the chain is sequential and this
+                    # branch is not taken.
+                    cur = torch.cuda.current_stream()
+                    side = _SIDE_STREAMS.get(images.tensor.device)
+                    if side is None:
+                        side = _SIDE_STREAMS[images.tensor.device] = torch.cuda.Stream(device=images.tensor.device)
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):
+                        boxes, scores, keep, _ = self.proposal_generator.forward_dense(features, images.image_sizes)
+                        side_out = self.roi_heads.box_dense(features, boxes, scores, keep, images.image_sizes)      # alive until the join
+                else:
+                    boxes, scores, keep, _ = self.proposal_generator.forward_dense(features, images.image_sizes)
+                    dboxes, dscores, dcls, dcounts = self.roi_heads.box_dense(features, boxes, scores, keep, images.image_sizes)
                 if self.teacher_forced:
                     proposals_roih = [self._forced(x, sz) for x, sz in zip(batched_inputs, images.image_sizes)]
                 else:
@@ -88,6 +105,9 @@ class DAobjTwoStagePseudoLabGeneralizedRCNN(nn.Module):
             feats = [features[k] for k in ("p2", "p3", "p4", "p5", "p6")]
             nodes, labels = self.graph_generator(feats, proposals_roih)
             loss = self.multi_matching_unsup(nodes, labels, self.multi_matching_sup.U)
+            if DENSE_INFERENCE and side is not None:
+                torch.cuda.current_stream().wait_stream(side)      # join: backward / SGD start after the detector work
+                del side_out
             return loss, [], [], feats
         raise NotImplementedError("branch {!r} is a source-training branch; only 'TTT' and eval inference are on the "
                                   "test-time-adaptation path".format(branch))
