@@ -399,6 +399,20 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
         const float* ub = Ucur + o * NU + u;
         float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
         int j = 0;
+        // eight columns per round, all sixteen LDS reads issued before the first FMA (the two-at-a-time loop below pays
+        // one LDS round trip per pair); same two accumulators, same order: bit-identical sums
+        for (; j + 8 <= n; j += 8) {
+          float a[8];
+          float4 x[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { a[q] = arow[j + q]; x[q] = *reinterpret_cast<const float4*>(ub + (j + q) * NU); }
+#pragma unroll
+          for (int q = 0; q < 8; q += 2) {
+            c0.x = fmaf(a[q], x[q].x, c0.x); c0.y = fmaf(a[q], x[q].y, c0.y); c0.z = fmaf(a[q], x[q].z, c0.z); c0.w = fmaf(a[q], x[q].w, c0.w);
+            c1.x = fmaf(a[q + 1], x[q + 1].x, c1.x); c1.y = fmaf(a[q + 1], x[q + 1].y, c1.y);
+            c1.z = fmaf(a[q + 1], x[q + 1].z, c1.z); c1.w = fmaf(a[q + 1], x[q + 1].w, c1.w);
+          }
+        }
         for (; j + 2 <= n; j += 2) {
           const float a0 = arow[j], a1 = arow[j + 1];
           const float4 x0 = *reinterpret_cast<const float4*>(ub + j * NU), x1 = *reinterpret_cast<const float4*>(ub + (j + 1) * NU);
