@@ -229,6 +229,98 @@ def mgm3_unsup_forward(p, nodes, labels, U, n_univ=UNIV_SIZE, dropout_masks=None
     return loss / npairs
 
 
+# --------------------------------------------------------------------------- N3 (source-training matching loss)
+HIPPI_MAX_ITER, HIPPI_SK_ITER, HIPPI_SK_TAU, HIPPI_TOL = 50, 20, 1 / 200., 1e-5
+USUP_LOSS_W, USUP_LOSS_LAM = 0.1, 1e-4
+
+
+def mha_full(p, x, prefix="Net_U.g_gene.", attn_mask=None, out_mask=None):
+    """utils/attentions.py:60-86 (version 'v2', 1 head) returning BOTH results: output = LayerNorm(x + dropout(
+    linear_final(attention @ v))) and the attention map.  ``attn_mask`` (n,n) / ``out_mask`` (n,256) of 0/1 reproduce
+    train-mode dropout draws (attentions.py:40,85); None = eval mode."""
+    d = x.shape[1]
+    k = F.linear(x, p[prefix + "linear_k.weight"], p[prefix + "linear_k.bias"])
+    v = F.linear(x, p[prefix + "linear_v.weight"], p[prefix + "linear_v.bias"])
+    q = F.linear(x, p[prefix + "linear_q.weight"], p[prefix + "linear_q.bias"])
+    att = torch.softmax((q @ k.t()) * (d ** -0.5), dim=1)
+    if attn_mask is not None:
+        att = att * attn_mask / 0.9
+    out = F.linear(att @ v, p[prefix + "linear_final.weight"], p[prefix + "linear_final.bias"])
+    if out_mask is not None:
+        out = out * out_mask / 0.9
+    out = F.layer_norm(x + out, (d,), p[prefix + "layer_norm.weight"], p[prefix + "layer_norm.bias"])
+    return out, att
+
+
+def g_universe(p, nodes, U):
+    """G_Universe.forward, multi_graph_matching.py:90-112 (+ cos_similarity :114-117).  N = cat(node_g U^T); the edge
+    list is attention / (D + 1e-8) with D = 1 - sum(x^2)/||x||^2, which is zero up to fp32 rounding: the edges are
+    ~1e7-scaled with rounding-decided signs."""
+    N_list, E_list = [], []
+    for x in nodes:
+        node, edge = mha_full(p, x)
+        norms = torch.norm(node, p=2, dim=1, keepdim=True)
+        D = 1 - torch.sum(node * node, dim=1, keepdim=True) / norms ** 2
+        E_list.append(edge * (1 / (D + 1e-8)))
+        N_list.append(node @ U.t())
+    return torch.cat(N_list, dim=0), E_list
+
+
+def hippi(W, U0, ms, d=UNIV_SIZE, projector="sinkhorn", max_iter=HIPPI_MAX_ITER, sk_iter=HIPPI_SK_ITER, tau=HIPPI_SK_TAU,
+          trace=None):
+    """HiPPI.forward, multi_graph_matching.py:414-449: V = (W U) U^T (W U) (chain_matmul = cheapest association),
+    per-graph Sinkhorn (dummy rows, tau 1/200, 20 sweeps) or Hungarian, stop when ||U - lastU||_F < 1e-5."""
+    ms = [int(m) for m in ms]
+    U = U0
+    for i in range(max_iter):
+        lastU = U
+        WU = W @ U
+        V = torch.linalg.multi_dot([WU, U.t(), WU])
+        if trace is not None and "V0" not in trace:
+            trace["V0"] = V.clone()
+        parts, start = [], 0
+        for m in ms:
+            blk = V[start:start + m, :d]
+            if projector == "sinkhorn":
+                parts.append(_sinkhorn(blk, dummy_row=True, max_iter=sk_iter, tau=tau, batched_operation=False))
+            elif projector == "hungarian":
+                parts.append(hungarian(blk))
+            else:
+                raise NameError("Unknown projector {}.".format(projector))
+            start += m
+        U = torch.cat(parts, dim=0)
+        if torch.norm(U - lastU) < HIPPI_TOL:
+            break
+    if trace is not None:
+        trace["iters"] = i + 1
+    return U
+
+
+def label_block_matrix(labels, num_classes):
+    """U_sup.forward :146-152 with build_label_wise/one_hot :161-166: W[a,b] = 1 iff the two nodes carry the same label."""
+    oh = torch.cat([torch.eye(num_classes)[l.long() - 1, :] for l in labels], dim=0)
+    return oh @ oh.t()
+
+
+def u_sup_forward(p, nodes, labels, num_classes=2, n_univ=UNIV_SIZE, forced_target=None, trace=None):
+    """U_sup.forward + U_loss, multi_graph_matching.py:136-169.  ``p`` = U_sup state dict (``U`` + ``Net_U.*``).
+    ``forced_target`` replaces the HiPPI result (which is detached in the loss, :156-158), the way the parity tests pin
+    everything that carries gradient independently of the rounding-driven edge weights."""
+    ms = [len(l) for l in labels]
+    N, edges = g_universe(p, nodes, p["U"])
+    Us = _sinkhorn(N, max_iter=PAIR_SK_ITER, tau=PAIR_SK_TAU, batched_operation=False)
+    if forced_target is None:
+        A = torch.block_diag(*edges)
+        Wl = label_block_matrix(labels, num_classes)
+        A_ = Wl.t() @ A @ Wl
+        target = hippi(A_, Us, ms, n_univ)
+    else:
+        target = forced_target
+    if trace is not None:
+        trace.update(N=N.detach().clone(), Us=Us.detach().clone(), target=target.detach().clone())
+    return USUP_LOSS_W * F.mse_loss(Us, target.detach()) + USUP_LOSS_LAM * torch.norm(p["U"], p="fro")
+
+
 # --------------------------------------------------------------------------- A2
 STRIDES = (4, 8, 16, 32, 64)
 SIZE_RANGES = ((-1, 64), (64, 128), (128, 256), (256, 512), (512, 100000000))

@@ -148,3 +148,38 @@ def dice_mask_pairs():
     return [(ell(48, 40, 20, 18), ell(50, 42, 22, 17)), (ell(30, 30, 12, 12), ell(60, 50, 15, 10)),
             (empty, ell(48, 40, 20, 18)), (ell(48, 40, 20, 18), full), (ell(48, 40, 20, 18), empty),
             (ell(48, 40, 30, 25), ell(48, 40, 12, 10))]
+
+
+# ----------------------------------------------------------------------------- N3: HiPPI / U_sup
+HIPPI_CASES = (  # name, sizes, seed, projector
+    ("sk_a", (22, 30, 26, 19), 700, "sinkhorn"),
+    ("sk_wide", (12, 40, 7), 701, "sinkhorn"),
+    ("sk_eq", (32, 32, 32), 702, "sinkhorn"),
+    ("hung", (22, 30, 26, 19), 703, "hungarian"),
+)
+USUP_CASES = (  # name, sizes, seed
+    ("a", (22, 30, 26, 19), 710),
+    ("b", (9, 40, 33), 711),
+)
+USUP_PARAM_SEED = 13
+
+
+def hippi_inputs(sizes, seed):
+    """Planted multi-graph similarity: W = P P^T + symmetric noise with P a planted partial permutation per graph;
+    U0 = a noisy soft version of P."""
+    g = synth.gen(seed)
+    Mtot = sum(sizes)
+    P = torch.zeros(Mtot, 32)
+    off = 0
+    for n in sizes:
+        cols = g.permutation(max(n, 32))[:n] % 32 if n > 32 else g.permutation(32)[:n]
+        P[torch.arange(off, off + n), torch.from_numpy(np.asarray(cols))] = 1
+        off += n
+    noise = torch.from_numpy(g.uniform(-0.5, 0.5, size=(Mtot, Mtot)).astype(np.float32)) * 0.1
+    W = P @ P.t() + (noise + noise.t()) * 0.5
+    U0 = 0.5 * P + torch.from_numpy(g.uniform(0, 1, size=(Mtot, 32)).astype(np.float32)) * 0.05
+    return W, U0
+
+
+def usup_inputs(sizes, seed):
+    return synth.node_sets(seed, sizes, scale=0.5)

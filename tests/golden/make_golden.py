@@ -225,8 +225,59 @@ def gold_dice():
     np.savez_compressed(os.path.join(OUT, "dice.npz"), **out)
 
 
+def gold_usup(mgm):
+    """N3: HiPPI on planted similarities, and U_sup.forward with the HiPPI result captured so that everything carrying
+    gradient can be pinned independently of the rounding-driven edge weights."""
+    out = {}
+    solver = mgm.HiPPI()
+    for name, sizes, seed, proj in HIPPI_CASES:
+        W, U0 = hippi_inputs(sizes, seed)
+        out[f"hippi_{name}_U"] = npy(solver(W, U0, torch.tensor(sizes), 32, projector=proj))
+        WU = W @ U0
+        out[f"hippi_{name}_V0"] = npy(torch.chain_matmul(WU, U0.t(), WU))
+    for name, sizes, seed in USUP_CASES:
+        m = mgm.U_sup(2, 32)
+        m.load_state_dict(synth.usup_params(USUP_PARAM_SEED), strict=True)
+        m.eval()
+        nodes, labels = usup_inputs(sizes, seed)
+        nodes = [x.requires_grad_() for x in nodes]
+        cap = {}
+        net, match, sk = m.Net_U.forward, m.matching.forward, m.sinkhorn.forward
+
+        def spy_net(*a, _o=net, **k):
+            N, E = _o(*a, **k)
+            cap["N"], cap["E"] = N.detach().clone(), [e.detach().clone() for e in E]
+            return N, E
+
+        def spy_match(W, U, ms, d, _o=match, **k):
+            cap["A_"], cap["Us"] = W.detach().clone(), U.detach().clone()
+            cap["target"] = _o(W, U, ms, d, **k).detach().clone()
+            return cap["target"]
+
+        m.Net_U.forward, m.matching.forward = spy_net, spy_match
+        loss = m(nodes, labels)
+        loss.backward()
+        out[f"usup_{name}_N"] = npy(cap["N"])
+        out[f"usup_{name}_Us"] = npy(cap["Us"])
+        out[f"usup_{name}_target"] = npy(cap["target"])
+        out[f"usup_{name}_loss"] = npy(loss)
+        out[f"usup_{name}_edge_absmax"] = npy(torch.stack([e.abs().max() for e in cap["E"]]))
+        for g, x in enumerate(nodes):
+            out[f"usup_{name}_dnode{g}"] = npy(x.grad)
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                if k == "U":
+                    out[f"usup_{name}_d_U"] = npy(p.grad)
+                else:
+                    pgrad(out, f"usup_{name}_d_{k}", p.grad)
+    np.savez_compressed(os.path.join(OUT, "usup.npz"), **out)
+
+
 def main():
     mgm, bg = ref_import.load()
+    if len(sys.argv) > 1 and sys.argv[1] == "usup":
+        gold_usup(mgm)
+        return
     gold_dice()
     gold_affinity(mgm)
     gold_mha(mgm)
@@ -235,6 +286,7 @@ def main():
     gold_gagm(mgm)
     gold_mgm3(mgm)
     gold_proto(bg)
+    gold_usup(mgm)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

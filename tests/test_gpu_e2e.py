@@ -230,3 +230,27 @@ def test_eval_dice_matches_host_pipeline(setup):
     assert len(evg.dice_scores) == len(evc.dice_scores) > 0
     for k in rg:
         assert abs(rg[k] - rc[k]) <= 0.05, (k, rg[k], rc[k])
+
+
+def test_supervised_matching_branch(setup):
+    """branch='supervised' (rcnn.py:262-266): nodes sampled inside the ground-truth boxes -> U_sup.forward; the loss must be
+    finite and reach the universe, the universe network and the trainable part of the backbone."""
+    from ttdg_mgm_amd.modeling.structures import Boxes, Instances
+    cfg, cpu, gpu, batch = setup
+    m = copy.deepcopy(gpu).train()
+    inputs = []
+    for x in batch:
+        y = dict(x)
+        y["instances"] = Instances((y["image"].shape[-2], y["image"].shape[-1]), gt_boxes=Boxes(x["tf_boxes"].float()),
+                                   gt_classes=x["tf_classes"])
+        inputs.append(y)
+    losses, _, _, feats = m(inputs, branch="supervised")
+    loss = losses["loss_matching"]
+    assert torch.isfinite(loss) and float(loss.detach()) > 0
+    loss.backward()
+    assert m.multi_matching_sup.U.grad is not None and float(m.multi_matching_sup.U.grad.abs().sum()) > 0
+    assert m.multi_matching_sup.Net_U.g_gene.linear_v.weight.grad is not None
+    got = [n for n, p in m.backbone.named_parameters() if p.grad is not None and float(p.grad.abs().sum()) > 0]
+    assert got, "no backbone gradient from the supervised matching loss"
+    with pytest.raises(NotImplementedError):
+        m(inputs, branch="supervised_target")

@@ -871,3 +871,79 @@ def test_roi_align_multilevel_matches_per_level_pooler(dev):
         ref = cb.roi_align_multilevel(feats, rois, [4, 8, 16, 32], P)
         got = ops.roi_align_multilevel([f.to(dev) for f in feats], rois.to(dev), [4, 8, 16, 32], P)
         assert maxerr(got, ref) <= 1e-4, P
+
+
+# ------------------------------------------------------------------------------------------- N3: HiPPI / U_sup
+@pytest.mark.parametrize("name,sizes,seed,proj", cases.HIPPI_CASES)
+def test_hippi_golden(dev, golden, name, sizes, seed, proj):
+    """HiPPI.forward (multi_graph_matching.py:414-449) against the reference's own result on planted similarities."""
+    from ttdg_mgm_amd.GModule.multi_graph_matching import HiPPI
+    gold = golden("usup")
+    W, U0 = cases.hippi_inputs(sizes, seed)
+    h = HiPPI()
+    V0 = h.power_step(W.to(dev), U0.to(dev))
+    ref = gold[f"hippi_{name}_V0"]
+    assert maxerr(V0, ref) <= 1e-5 * float(np.abs(ref).max())
+    U = h(W.to(dev), U0.to(dev), torch.tensor(sizes), 32, projector=proj)
+    assert maxerr(U, gold[f"hippi_{name}_U"]) <= (0.0 if proj == "hungarian" else 2e-3), h.last_iters
+
+
+@pytest.mark.parametrize("sizes,seed", [((22, 30, 26, 19), 1), ((40, 12, 33), 2), ((32, 32), 3), ((5,), 4)])
+def test_hippi_one_step(dev, sizes, seed):
+    """One projected power step from a random state against the oracle (ragged graphs, some with more nodes than the
+    universe): the well-posed unit of the iteration."""
+    from oracle import gmodule as og
+    from ttdg_mgm_amd.GModule.multi_graph_matching import HiPPI
+    g = synth.gen(9000 + seed)
+    M = sum(sizes)
+    W = torch.from_numpy(g.uniform(0, 1, size=(M, M)).astype(np.float32)) / M
+    U0 = torch.from_numpy(g.uniform(0, 1, size=(M, 32)).astype(np.float32)) / 8      # V = O(1): V / tau = O(200), fp32 ulp 1e-5
+    ref = og.hippi(W, U0, sizes, 32, max_iter=1)
+    h = HiPPI(max_iter=1)
+    U = h(W.to(dev), U0.to(dev), torch.tensor(sizes), 32)
+    assert maxerr(U, ref) <= 2e-4
+
+
+def test_hippi_bad_projector(dev):
+    from ttdg_mgm_amd.GModule.multi_graph_matching import HiPPI
+    W, U0 = cases.hippi_inputs((5, 6), 1)
+    with pytest.raises(NameError):
+        HiPPI()(W.to(dev), U0.to(dev), torch.tensor([5, 6]), 32, projector="nope")
+
+
+@pytest.mark.parametrize("name,sizes,seed", cases.USUP_CASES)
+def test_u_sup_forward_backward(dev, golden, name, sizes, seed):
+    """U_sup.forward (:136-169) with the detached HiPPI target taken from the reference run: N, Sinkhorn(N), loss and every
+    gradient against the reference; the free-running loss (rounding-driven edges) must be finite."""
+    from ttdg_mgm_amd.GModule.multi_graph_matching import U_sup
+    gold = golden("usup")
+    m = U_sup(2, 32).to(dev).eval()
+    m.load_state_dict(synth.usup_params(cases.USUP_PARAM_SEED), strict=True)
+    nodes, labels = cases.usup_inputs(sizes, seed)
+    nodes = [x.to(dev).requires_grad_() for x in nodes]
+    labels = [l.to(dev) for l in labels]
+    tr = {}
+    loss = m(nodes, labels, forced_target=torch.from_numpy(gold[f"usup_{name}_target"]).to(dev), trace=tr)
+    loss.backward()
+    assert maxerr(tr["N"], gold[f"usup_{name}_N"]) <= TOL
+    assert maxerr(tr["Us"], gold[f"usup_{name}_Us"]) <= TOL
+    assert abs(float(loss.detach()) - float(gold[f"usup_{name}_loss"])) <= 1e-6
+    for g, x in enumerate(nodes):
+        assert maxerr(x.grad, gold[f"usup_{name}_dnode{g}"]) <= 1e-6
+    assert maxerr(m.U.grad, gold[f"usup_{name}_d_U"]) <= 1e-6
+    for k in ("linear_k.weight", "linear_v.weight", "linear_q.weight", "linear_final.weight", "linear_final.bias", "layer_norm.weight"):
+        check_pgrad(gold, f"usup_{name}_d_Net_U.g_gene.{k}", getattr(m.Net_U.g_gene, k.split(".")[0]).__getattr__(k.split(".")[1]).grad, 1e-6)
+    with torch.no_grad():
+        free = m([x.detach() for x in nodes], labels)
+    assert torch.isfinite(free) and m.matching.last_iters >= 1
+
+
+def test_u_sup_label_matrix(dev):
+    from ttdg_mgm_amd.GModule.multi_graph_matching import U_sup
+    m = U_sup(3, 32).to(dev)
+    la, lb = torch.tensor([1, 3, 0], device=dev), torch.tensor([3, 2], device=dev)
+    W = m.label_matrix([la, lb]).cpu()
+    oh = torch.cat([m.one_hot(la), m.one_hot(lb)]).cpu()
+    assert torch.equal(W, oh @ oh.t())                  # label 0 wraps to the last class, as eye[x - 1] does
+    with pytest.raises(IndexError):
+        m.label_matrix([torch.tensor([4], device=dev)])

@@ -143,3 +143,43 @@ def test_mgm3_planted_cases(golden, name):
     assert max(tr["iters"]) < 200
     for gi, x in enumerate(nodes):
         close(x.grad, gold[f"{name}_dnode{gi}"], 1e-5)
+
+
+# ----------------------------------------------------------------------------- N3: HiPPI / U_sup
+@pytest.mark.parametrize("name,sizes,seed,proj", cases.HIPPI_CASES)
+def test_hippi(golden, name, sizes, seed, proj):
+    gold = golden("usup")
+    W, U0 = cases.hippi_inputs(sizes, seed)
+    tr = {}
+    U = og.hippi(W, U0, sizes, 32, projector=proj, trace=tr)
+    close(tr["V0"], gold[f"hippi_{name}_V0"], 1e-5)
+    close(U, gold[f"hippi_{name}_U"], 1e-5)
+
+
+def test_hippi_bad_projector():
+    W, U0 = cases.hippi_inputs((5, 6), 1)
+    with pytest.raises(NameError):
+        og.hippi(W, U0, (5, 6), 32, projector="nope")
+
+
+@pytest.mark.parametrize("name,sizes,seed", cases.USUP_CASES)
+def test_u_sup_forward_backward(golden, name, sizes, seed):
+    """Everything that carries gradient in U_sup.forward (:136-158), with the (detached) HiPPI target taken from the
+    reference run; the free-running target is rounding-driven (edges ~1e7) and only has to be finite."""
+    gold = golden("usup")
+    p = {k: v.clone().requires_grad_() for k, v in synth.usup_params(cases.USUP_PARAM_SEED).items()}
+    nodes, labels = cases.usup_inputs(sizes, seed)
+    nodes = [x.requires_grad_() for x in nodes]
+    tr = {}
+    loss = og.u_sup_forward(p, nodes, labels, forced_target=torch.from_numpy(gold[f"usup_{name}_target"]), trace=tr)
+    loss.backward()
+    close(tr["N"], gold[f"usup_{name}_N"], 1e-5)
+    close(tr["Us"], gold[f"usup_{name}_Us"], 1e-6)
+    close(loss, gold[f"usup_{name}_loss"], 1e-7)
+    for g, x in enumerate(nodes):
+        close(x.grad, gold[f"usup_{name}_dnode{g}"], 1e-7)
+    close(p["U"].grad, gold[f"usup_{name}_d_U"], 1e-7)
+    for k in ("linear_k.weight", "linear_v.weight", "linear_q.weight", "linear_final.weight", "linear_final.bias", "layer_norm.weight"):
+        check_pgrad(gold, f"usup_{name}_d_Net_U.g_gene.{k}", p["Net_U.g_gene." + k].grad, 1e-6)
+    free = og.u_sup_forward(p, [x.detach() for x in nodes], labels)
+    assert torch.isfinite(free)

@@ -66,10 +66,11 @@ class _FeatGraphParams(nn.Module):
         self.wk = nn.Linear(d, d)
 
 
-class _UniverseNetParams(nn.Module):
-    """Parameter holder with the names of G_Universe (reference :77-88); training-time only."""
+class G_Universe(nn.Module):
+    """Universe network of the source-training matching loss (reference :77-117).  Parameter names are the checkpoint
+    contract (``f2g``, ``adapt`` and ``affinity_layer`` are declared by the reference but unused in its forward)."""
 
-    def __init__(self, dim, univ_size):
+    def __init__(self, dim=256, univ_size=256):
         super().__init__()
         self.f2g = _FeatGraphParams(dim)
         self.g_gene = MultiHeadAttention(dim, 1, dropout=0.1, version='v2')
@@ -77,24 +78,130 @@ class _UniverseNetParams(nn.Module):
         self.affinity_layer = Affinity(dim)
         self.univ_size = univ_size
 
+    def forward(self, nodes, U):
+        """nodes: list of (n_g, dim) -> (N = cat(node_g U^T) (M, univ), [edge_g / (D_g + 1e-8)]) as reference :90-112.
+        ``D = 1 - sum(x^2)/||x||^2`` (:114-117) is zero up to fp32 rounding, so the edge scale (~1e7) and sign follow the
+        rounding of whichever reduction computes it; only N carries gradient into the loss."""
+        N_list, E_list = [], []
+        for node in nodes:
+            node, edge = self.g_gene([node, node, node])
+            D = self.cos_similarity(node)
+            E_list.append(edge * (1 / (D + 1e-8)))
+            N_list.append(ops.LinearFn.apply(node.contiguous(), U, None))
+        return torch.cat(N_list, dim=0), E_list
+
+    def cos_similarity(self, nodes):
+        norms = torch.norm(nodes, p=2, dim=1, keepdim=True)
+        return 1 - torch.sum(nodes * nodes, dim=1, keepdim=True) / norms ** 2
+
+
+class HiPPI(nn.Module):
+    """Higher-order projected power iteration (reference :392-449): V = (W U) U^T (W U), per-graph Sinkhorn (dummy rows,
+    tau 1/200, 20 sweeps) or Hungarian projection, stop when ||U - lastU||_F < 1e-5.  Per iteration: three MFMA GEMMs
+    (the 32 x 32 middle product first, the association chain_matmul picks), ONE ragged batched Sinkhorn / LAP launch over
+    all graphs and one host read of the convergence norm, instead of a Python loop over graphs."""
+
+    def __init__(self, max_iter=50, sk_iter=20, sk_tau=1 / 200.):
+        super().__init__()
+        self.max_iter = max_iter
+        self.sinkhorn = Sinkhorn(max_iter=sk_iter, tau=sk_tau)
+        self.last_iters = None
+
+    def power_step(self, W, U):
+        """One V = (W U) U^T (W U) (:421-422)."""
+        M, d = U.shape
+        WU = torch.empty(M, d, device=U.device, dtype=torch.float32)
+        ops.gemm(W, W.stride(0), W.stride(1), U, 1, d, WU, d, 1, M, d, M)          # WU[m,n] = sum_k W[m,k] U[k,n]
+        T = torch.empty(d, d, device=U.device, dtype=torch.float32)
+        ops.gemm(U, 1, d, WU, 1, d, T, d, 1, d, d, M)                              # T = U^T WU
+        V = torch.empty(M, d, device=U.device, dtype=torch.float32)
+        ops.gemm(WU, d, 1, T, 1, d, V, d, 1, M, d, d)                              # V = WU T
+        return V
+
+    def forward(self, W, U0, ms, d, projector='sinkhorn'):
+        if projector not in ('sinkhorn', 'hungarian'):
+            raise NameError('Unknown projector {}.'.format(projector))
+        sizes = [int(m) for m in ms]
+        G, nmax, M = len(sizes), max(sizes), sum(sizes)
+        dev = U0.device
+        W = W.detach().float()
+        U = U0.detach().float().contiguous()
+        if U.shape != (M, d):
+            raise ValueError("U0 must be (sum(ms), d)")
+        # row m of graph g lives at padded slot g*nmax + (m - offset_g)
+        slot = torch.cat([torch.arange(n) + g * nmax for g, n in enumerate(sizes)]).to(dev)
+        n1 = torch.tensor(sizes, dtype=torch.int32, device=dev)
+        for i in range(self.max_iter):
+            lastU = U
+            V = self.power_step(W, U)
+            Vp = torch.zeros(G * nmax, d, device=dev, dtype=torch.float32)
+            Vp[slot] = V
+            Vp = Vp.view(G, nmax, d)
+            if projector == 'sinkhorn':
+                Up = ops.sinkhorn_batched(Vp, n1, None, True, self.sinkhorn.tau, self.sinkhorn.max_iter)
+                U = Up.view(G * nmax, d)[slot].contiguous()
+            else:
+                U = torch.cat([ops.lap_batched(Vp[g:g + 1, :n].contiguous())[0] for g, n in enumerate(sizes)], dim=0)
+            if float(torch.norm(U - lastU)) < 1e-5:
+                break
+        self.last_iters = i + 1
+        return U
+
 
 class U_sup(nn.Module):
-    """Holder of the learned universe ``U`` (reference :119-134).  The TTA path only READS ``.U``
-    (rcnn.py:353); the supervised HiPPI loss of ``forward`` belongs to source training.
-    All reference parameters are declared so that checkpoints load with strict=True."""
+    """Learned universe ``U`` and its source-training loss (reference :119-169).  The TTA path only READS ``.U``
+    (rcnn.py:353); ``forward`` is the supervised matching loss of source training (rcnn.py:262-266):
+    ``0.1 * mse(Sinkhorn(node U^T), HiPPI(...).detach()) + 1e-4 * ||U||_F``.  All reference parameters are declared so
+    that checkpoints load with strict=True."""
 
     def __init__(self, num_cls, univ_size, dim=256):
         super().__init__()
         self.univ_size = univ_size
         self.U = nn.Parameter(torch.randn(univ_size, dim) + 1 / self.univ_size)
         self.num_classes = num_cls
-        self.Net_U = _UniverseNetParams(dim, univ_size)
+        self.Net_U = G_Universe(dim, univ_size)
         self.node_affinity = Affinity(256)
         self.sinkhorn = Sinkhorn(max_iter=20, tau=0.05, epsilon=1e-10, batched_operation=False)
+        self.matching = HiPPI()
 
-    def forward(self, nodes, labels):
-        raise NotImplementedError("U_sup.forward is the source-training matching loss (SURVEY.md §8f N3); "
-                                  "test-time adaptation only reads U_sup.U")
+    def forward(self, nodes, labels, forced_target=None, trace=None):
+        """``forced_target`` (M, univ) replaces the HiPPI result, which the loss detaches (:156-158): the parity tests
+        use it to pin everything that carries gradient independently of the rounding-driven edge weights."""
+        ms = [len(label) for label in labels]
+        N, edges = self.Net_U(nodes, self.U)
+        U = self.sinkhorn(N)
+        if forced_target is None:
+            with torch.no_grad():
+                A = torch.block_diag(*[e.detach() for e in edges])
+                Wl = self.label_matrix(labels)
+                M = A.shape[0]
+                AW = torch.empty(M, M, device=A.device, dtype=torch.float32)
+                ops.gemm(A, M, 1, Wl, M, 1, AW, M, 1, M, M, M)                      # A W   (W symmetric: B(n,k) = W[n,k])
+                A_ = torch.empty(M, M, device=A.device, dtype=torch.float32)
+                ops.gemm(Wl, 1, M, AW, 1, M, A_, M, 1, M, M, M)                     # W^T (A W)
+                target = self.matching(A_, U, ms, self.univ_size)
+        else:
+            target = forced_target
+        if trace is not None:
+            trace.update(N=N.detach(), Us=U.detach(), target=target.detach())
+        return self.U_loss(U, target.detach(), self.U)
+
+    def label_matrix(self, labels):
+        """:146-152 with build_label_wise / one_hot (:161-166): W[a,b] = 1 iff nodes a and b carry the same label."""
+        idx = torch.cat([l.long() for l in labels]) - 1
+        idx = torch.where(idx < 0, idx + self.num_classes, idx)                      # eye[x - 1]: negative rows wrap (:166)
+        if bool(((idx < 0) | (idx >= self.num_classes)).any()):
+            raise IndexError("label out of range for {} classes".format(self.num_classes))
+        return (idx[:, None] == idx[None, :]).float().contiguous()
+
+    def build_label_wise(self, label1, label2):
+        return torch.mm(self.one_hot(label1), self.one_hot(label2).t())
+
+    def one_hot(self, x):
+        return torch.eye(self.num_classes, device=x.device)[x.long() - 1, :]
+
+    def U_loss(self, U, U_gt, Ue, w=0.1, lam=1e-4, epsilon=1e-5):
+        return w * torch.nn.functional.mse_loss(U, U_gt) + lam * torch.norm(Ue, p='fro')
 
 
 class MGM3_unsup(nn.Module):

@@ -1,10 +1,13 @@
 """MultiHeadAttention — mirror of reference utils/attentions.py:44-116 (version 'v2').
 
 Parameter names (linear_k/v/q/final, layer_norm) are the checkpoint contract.  The TTA path only consumes
-the attention map (multi_graph_matching.py:498); the (output, attention) pair is still returned for
-signature compatibility, the attention coming from csrc/mha.hip."""
+the attention map (multi_graph_matching.py:498), which comes from csrc/mha.hip without autograd; ``forward`` returns the
+(output, attention) pair and is differentiable when gradients are enabled (the source-training loss U_sup.forward
+back-propagates through ``output``, multi_graph_matching.py:100-106): the four projections run on the MFMA GEMM
+(ops.LinearFn), softmax / LayerNorm are torch glue."""
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from ... import ops
 
@@ -42,6 +45,15 @@ class MultiHeadAttention(nn.Module):
 
     def forward(self, key_value_query, attn_mask=None):
         key, value, query = key_value_query
+        if torch.is_grad_enabled() and (query.requires_grad or self.linear_q.weight.requires_grad):
+            if self.version != 'v2' or self.num_heads != 1:
+                raise NotImplementedError("only the 1-head 'v2' configuration used by the matching losses is implemented")
+            lin = lambda x, l: ops.LinearFn.apply(x.float().contiguous(), l.weight, l.bias)
+            k, v, q = lin(key, self.linear_k), lin(value, self.linear_v), lin(query, self.linear_q)
+            scale = (k.shape[-1] // self.num_heads) ** -0.5            # attentions.py:80
+            attention = self.dropout(torch.softmax((q @ k.t()) * scale, dim=1))   # attentions.py:31-42
+            out = self.dropout(lin(attention @ v, self.linear_final))
+            return self.layer_norm(query + out).squeeze(), attention.squeeze()
         attention = self.attention_only(query)
         with torch.no_grad():
             v = ops.linear_raw(value.detach().contiguous(), self.linear_v.weight, self.linear_v.bias)

@@ -109,8 +109,18 @@ class DAobjTwoStagePseudoLabGeneralizedRCNN(nn.Module):
                 torch.cuda.current_stream().wait_stream(side)      # join: backward / SGD start after the detector work
                 del side_out
             return loss, [], [], feats
-        raise NotImplementedError("branch {!r} is a source-training branch; only 'TTT' and eval inference are on the "
-                                  "test-time-adaptation path".format(branch))
+        if branch == "supervised":
+            # source-training matching term only (rcnn.py:262-266): graph nodes sampled inside the
+            # GROUND-TRUTH boxes, U_sup.forward -> loss_matching.  The detector's own RPN / ROI / mask losses of that
+            # branch (rcnn.py:236-249) belong to source training proper and are out of scope (SURVEY.md §2 OUT).
+            gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
+            feats = [features[k] for k in ("p2", "p3", "p4", "p5", "p6")]
+            nodes, labels = self.graph_generator(feats, gt_instances)
+            if nodes is None:
+                return {}, [], [], feats
+            return {"loss_matching": self.multi_matching_sup(nodes, labels)}, [], [], feats
+        raise NotImplementedError("branch {!r} is a source-training branch; only 'TTT', the matching term of 'supervised' and "
+                                  "eval inference are built".format(branch))
 
     def _forced(self, x, size):
         b = x["tf_boxes"].to(self.device).float()

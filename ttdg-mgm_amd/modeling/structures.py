@@ -61,6 +61,12 @@ class Instances:
             return len(v)
         return 0
 
+    def to(self, device):
+        out = Instances(self._image_size)
+        for k, v in self._fields.items():
+            out.set(k, Boxes(v.tensor.to(device)) if isinstance(v, Boxes) else (v.to(device) if hasattr(v, "to") else v))
+        return out
+
     def __getitem__(self, idx):
         out = Instances(self._image_size)
         for k, v in self._fields.items():

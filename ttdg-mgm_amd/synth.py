@@ -54,6 +54,34 @@ def mgm3_params(seed, std=0.05):
     return out
 
 
+def _affinity_shapes(prefix):
+    return ((prefix + "fc_M.0.weight", (HID, HID)), (prefix + "fc_M.0.bias", (HID,)), (prefix + "fc_M.2.weight", (1, HID)),
+            (prefix + "fc_M.2.bias", (1,)), (prefix + "project_sr.weight", (DIM, DIM)), (prefix + "project_tg.weight", (DIM, DIM)))
+
+
+# state dict of U_sup(num_cls, 32) (multi_graph_matching.py:77-88, 119-134; utils/graph_network.py:95-99)
+USUP_PARAM_SHAPES = (
+    (("Net_U.f2g.wq.weight", (DIM, DIM)), ("Net_U.f2g.wq.bias", (DIM,)), ("Net_U.f2g.wk.weight", (DIM, DIM)), ("Net_U.f2g.wk.bias", (DIM,)))
+    + tuple(("Net_U.g_gene.linear_%s.%s" % (n, w), (DIM, DIM) if w == "weight" else (DIM,))
+            for n in ("k", "v", "q", "final") for w in ("weight", "bias"))
+    + (("Net_U.g_gene.layer_norm.weight", (DIM,)), ("Net_U.g_gene.layer_norm.bias", (DIM,)),
+       ("Net_U.adapt.weight", (DIM, DIM)), ("Net_U.adapt.bias", (DIM,)))
+    + _affinity_shapes("Net_U.affinity_layer.") + _affinity_shapes("node_affinity."))
+
+
+def usup_params(seed, std=0.05):
+    """U_sup state dict: ``U`` as the reference initialises it (:124), every other weight at std 0.05."""
+    g = gen(seed)
+    out = {"U": normal(g, (UNIV, DIM), 1.0, 1.0 / UNIV)}
+    for name, shape in USUP_PARAM_SHAPES:
+        if name.endswith("layer_norm.weight"):
+            out[name] = torch.ones(shape)
+            g.standard_normal(shape)
+        else:
+            out[name] = normal(g, shape, std)
+    return out
+
+
 def universe(seed):
     """U_sup.U init: randn + 1/univ_size (multi_graph_matching.py:124)."""
     return normal(gen(seed), (UNIV, DIM), 1.0, 1.0 / UNIV)
