@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--bf16-backbone", action="store_true", help="cfg-5 style: bf16 autocast for the backbone only")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (validation on a 1-GPU box)")
     ap.add_argument("--share-device", action="store_true", help="validation only: every rank uses cuda:0")
+    ap.add_argument("--sync-universe", action="store_true",
+                    help="Mode S (SURVEY.md 8e): all ranks adapt on ONE multi-graph (RCCL all-gather of the node embeddings, gradient "
+                         "all-reduce) = the single-GPU algorithm at batch N*B; default is Mode R (independent shards, as the reference)")
     return ap.parse_args()
 
 
@@ -73,6 +76,16 @@ def build(cfg_id, n_images, args, device, rank, world):
     batches = list(loader)
     from ttdg_mgm_amd.modeling import calibrate_frozen_bn
     calibrate_frozen_bn(model, batches[0])
+    if args.sync_universe and world > 1:
+        model.sync_universe = True
+        with torch.no_grad():          # replicas must start identical: the calibration batch differs per rank
+            for t in list(model.parameters()) + list(model.buffers()):
+                if dist.get_backend() == "nccl":
+                    dist.broadcast(t, 0)
+                else:
+                    h = t.cpu()
+                    dist.broadcast(h, 0)
+                    t.copy_(h)
     return cfg, model, opt, batches, name, loader.dataset_dicts
 
 
@@ -195,6 +208,18 @@ def cpu_baseline(args):
                       % (args.cpu_steps, args.cpu_steps * args.batch, args.size, args.size, cores), "seconds": t}
 
 
+def _finite(x):
+    """NaN / inf -> null: the line must be strict JSON (the Dice means are NaN when no prediction of the random-init
+    detector clears the 0.9 score threshold)."""
+    if isinstance(x, float):
+        return x if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    return x
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -226,7 +251,8 @@ def main():
             "config": {"workload": "cfg-2: %d-image synthetic %dx%d 2-class fundus stream per GPU, TEST.BATCH=%d, "
                                    "ResNet-50-FPN stand-in (random init) + 20-sweep Sinkhorn, 1 TTA step per batch + Dice pass, %s detections"
                                    % (K * B, args.size, args.size, B, "free-running" if args.free_running else "teacher-forced"),
-                       "global_batch": world * B, "parallelism": "dp%d (independent shards, no data-path collective)" % world},
+                       "global_batch": world * B, "parallelism": ("dp%d (independent shards, no data-path collective)" % world) if not (args.sync_universe and world > 1)
+                       else "dp%d synchronous universe graph (all-gather of node embeddings + gradient all-reduce)" % world},
             "tta_only_images_per_s": images / run["tta"], "dice": run["dice"],
         }
         out["roofline"] = roofline_from_stamps(run, K)
@@ -247,7 +273,7 @@ def main():
                 out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
                 out["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(out))
+        print(json.dumps(_finite(out)))
     if world > 1:
         dist.destroy_process_group()
 

@@ -141,6 +141,9 @@ int ttdg_gagm_solve(const float* Apack, const float* W, const float* U0, ttdg_gr
 int ttdg_lap_batched(const float* s, int b, int r, int c, float* x, ttdg_stream_t stream);
 /* benchmarking aid: 0 = compiler-lowered fp64 arg-min (default), 1 = hand-scheduled inline asm; affects ttdg_lap_batched only */
 int ttdg_debug_set_lap_variant(int v);
+/* benchmarking aid: total node count from which ttdg_gagm_solve takes the multi-workgroup solver even though every graph
+ * fits the single-workgroup kernel (<= 0 restores the built-in default) */
+int ttdg_debug_set_gagm_large_from(int total_nodes);
 /* micro-benchmark hook: `reps` projections (mode 0 Sinkhorn, 1 LAP) of G graphs x n nodes from LDS, one wavefront per
  * graph, as inside ttdg_gagm_solve; ticks[0] receives the shader-cycle count. */
 int ttdg_debug_project(const float* V, int n, int G, float tau, int iters, int reps, int mode, float* U,

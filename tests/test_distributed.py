@@ -59,3 +59,78 @@ def test_single_process_loader_matches_reference_sampler():
     for r in range(4):
         seen.append([d["image_id"] for b in data.build_detection_test_loader(cfg, "dist_ds2", r, 4) for d in b])
     assert seen == [[0, 1, 2], [3, 4, 5], [6, 7, 8], []]
+
+
+# ----------------------------------------------------------------------------- Mode S (engine/sync_universe.py)
+def _toy_loss(nodes, w):
+    """Stand-in for the replicated matching loss: couples every pair of graphs, has its own (replicated) parameter."""
+    loss = 0
+    for i in range(len(nodes)):
+        for j in range(i + 1, len(nodes)):
+            loss = loss + (nodes[i].mean(0) * nodes[j].mean(0) * w).sum()
+    return loss
+
+
+def _graphs(seed, sizes):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(n, 8, generator=g) for n in sizes], [torch.randint(1, 3, (n,), generator=g) for n in sizes]
+
+
+def _sync_worker(rank, world, port, q, layout):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ttdg_mgm_amd.engine import sync_universe as su
+        torch.manual_seed(0)
+        backbone = torch.nn.Linear(8, 256)                     # "summed" parameters: see only the local graphs
+        unused = torch.nn.Parameter(torch.zeros(3))            # never receives a gradient on any rank
+        only0 = torch.nn.Parameter(torch.ones(256))            # receives a gradient on rank 0 only
+        w = torch.nn.Parameter(torch.full((256,), 0.5))        # "replicated" parameter
+        xs, labs = _graphs(100 + rank, layout[rank])
+        nodes = [backbone(x) * (only0 if rank == 0 else 1.0) for x in xs] if xs else None
+        all_nodes, all_labs = su.gather_graphs(nodes, labs if xs else None, torch.device("cpu"))
+        loss = _toy_loss(all_nodes, w)
+        loss.backward()
+        su.allreduce_grads([backbone.weight, backbone.bias, unused, only0], [w])
+        q.put((rank, float(loss), [tuple(t.shape) for t in all_nodes], [l.tolist() for l in all_labs], backbone.weight.grad.clone(),
+               backbone.bias.grad.clone(), w.grad.clone(), unused.grad is None, only0.grad.clone()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("layout", [((3, 5), (4,)), ((6, 2), ())])
+def test_sync_universe_gather_and_gradient_allreduce(layout):
+    """World-size-2 gloo: the gathered multi-graph is the rank-major concatenation, the loss is replicated, and after the
+    all-reduce every rank holds exactly the gradients of the single-process computation on all graphs (a rank with no
+    graph at all included); a parameter without gradient anywhere keeps grad None."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000 + len(layout[1])
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q, layout)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference on all graphs
+    torch.manual_seed(0)
+    backbone = torch.nn.Linear(8, 256)
+    only0 = torch.nn.Parameter(torch.ones(256))
+    w = torch.nn.Parameter(torch.full((256,), 0.5))
+    nodes, labs = [], []
+    for r in range(2):
+        xs, ls = _graphs(100 + r, layout[r])
+        nodes += [backbone(x) * (only0 if r == 0 else 1.0) for x in xs]
+        labs += [l.tolist() for l in ls]
+    loss = _toy_loss(nodes, w)
+    loss.backward()
+    for rank, l, shapes, glabs, gw, gb, gwr, unused_none, g0 in res:
+        assert shapes == [tuple(n.shape) for n in nodes] and glabs == labs
+        assert abs(l - float(loss.detach())) <= 1e-6 * max(1.0, abs(float(loss.detach())))
+        assert torch.allclose(gw, backbone.weight.grad, rtol=1e-5, atol=1e-7)
+        assert torch.allclose(gb, backbone.bias.grad, rtol=1e-5, atol=1e-7)
+        assert torch.allclose(gwr, w.grad, rtol=1e-5, atol=1e-7)          # replicated: averaged, not summed
+        assert torch.allclose(g0, only0.grad, rtol=1e-5, atol=1e-7)       # gradient on rank 0 only -> zeros from rank 1
+        assert unused_none
+    assert torch.equal(res[0][4], res[1][4]) and torch.equal(res[0][6], res[1][6])

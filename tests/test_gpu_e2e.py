@@ -254,3 +254,27 @@ def test_supervised_matching_branch(setup):
     assert got, "no backbone gradient from the supervised matching loss"
     with pytest.raises(NotImplementedError):
         m(inputs, branch="supervised_target")
+
+
+def test_sync_universe_step_equals_single_process_step():
+    """Mode S (engine/sync_universe.py): 2 ranks x 2 images, one all-gather of the node embeddings + gradient all-reduce,
+    against the single-process step on the same 4 images (tools/mode_s_check.py; two ranks share the GPU over gloo)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29600 + os.getpid() % 300
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "tools", "mode_s_check.py")],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    for name in ("split", "idle_rank"):
+        c = res[name]
+        assert c["replicas_identical"] and c["replicated_loss_identical"] and c["same_gradient_set"], c
+        assert abs(c["loss"] - c["loss_single_process"]) <= 1e-5 * max(1.0, abs(c["loss_single_process"])), c
+        assert c["max_param_update"] > 1e-6, c                                  # the step did move the weights
+        # split: the vendor's convolution backward on 2 + 2 images vs on 4 (different algorithm, ~1 % on single elements)
+        assert c["max_param_diff_vs_single_process"] <= (0.03 if name == "split" else 1e-3) * c["max_param_update"] + 2e-8, c

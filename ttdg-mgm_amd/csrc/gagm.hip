@@ -612,9 +612,16 @@ static size_t ga_fixed_lds_bytes(int cmaxp, int GA_WAVES, int cwmax, int M) {
 static inline int ga_mp(int M) { return (M + 31) & ~31; }
 
 // gagm_large.hip
+#define GAGM_LARGE_FROM_DEFAULT (1 << 30)
 size_t ttdg_gagm_large_ws_bound(int M);
 int ttdg_gagm_large_solve(const float* Apack, const float* W, const float* U0, ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg,
                           float* U, int32_t* info, void* ws, hipStream_t st);
+
+// total node count above which graphs that WOULD fit the single-workgroup kernel still take the multi-workgroup solver:
+// the single workgroup streams the M x M matrix W once per iteration, which stops paying once W has left LDS and the
+// per-iteration W U product outgrows one CU (Mode S: the gathered multi-graph of 8 ranks is ~1000 nodes)
+static int g_gagm_large_from = GAGM_LARGE_FROM_DEFAULT;
+extern "C" int ttdg_debug_set_gagm_large_from(int total_nodes) { g_gagm_large_from = total_nodes > 0 ? total_nodes : GAGM_LARGE_FROM_DEFAULT; return 0; }
 
 extern "C" size_t ttdg_gagm_workspace_bytes(int M) {
   const size_t small = ga_ws_hist_off(M) * sizeof(float) + (size_t)GA_HIST * M + 64;
@@ -634,7 +641,7 @@ extern "C" int ttdg_gagm_solve(const float* Apack, const float* W, const float* 
     cmax = n > cmax ? n : cmax;
     asz += n * n;
   }
-  if (cmax > 128)   // beyond one CU's LDS: the multi-workgroup solver (gagm_large.hip), same schedule and outputs
+  if (cmax > 128 || gr.off[gr.G] >= g_gagm_large_from)   // beyond one CU: the multi-workgroup solver (gagm_large.hip), same schedule and outputs
     return ttdg_gagm_large_solve(Apack, W, U0, gr, cfg, U, info, ws, (hipStream_t)stream);
   TTDG_LIMIT(gr.off[gr.G] <= 4096, "gagm: more than 4096 nodes in total");
   const int cmaxp = (cmax + 63) & ~63;

@@ -122,14 +122,38 @@ class BaselineTrainer:
 
     @classmethod
     def tta_step(cls, model, optimizer, inputs):
-        """One adaptation step (reference :476-482).  Returns the loss tensor or None when skipped."""
+        """One adaptation step (reference :476-482).  Returns the loss tensor or None when skipped.
+        With ``model.sync_universe`` (Mode S, engine/sync_universe.py) ``inputs`` may be None on a rank whose shard has
+        run out: the skip decision is then global (the gathered multi-graph is the same on every rank) and the gradients
+        are all-reduced before the step, so every replica takes the same step."""
         loss, _, _, _ = model(inputs, branch='TTT')
         if loss is None:
             return None
         optimizer.zero_grad(set_to_none=True)
         loss.backward()
+        if getattr(model, "sync_universe", False):
+            from . import sync_universe
+            sync_universe.allreduce_grads(*sync_universe.split_params(model))
         optimizer.step()
         return loss
+
+    @classmethod
+    def tta_batches(cls, model, data_loader, limit=None):
+        """The batches one rank adapts on.  Mode S keeps the ranks in lockstep: every rank takes max-over-ranks steps and
+        feeds None once its own shard is exhausted."""
+        batches = []
+        for bidx, inputs in enumerate(data_loader):
+            if limit is not None and bidx >= limit:
+                break
+            batches.append(inputs)
+        if getattr(model, "sync_universe", False):
+            import torch.distributed as dist
+            n = torch.tensor([len(batches)], dtype=torch.int64)
+            if dist.get_backend() == "nccl":
+                n = n.to(model.device)
+            dist.all_reduce(n, op=dist.ReduceOp.MAX)
+            batches += [None] * (int(n) - len(batches))
+        return batches
 
     @classmethod
     def test(cls, cfg, model, optimizer=None, evaluators=None, timers=None):
@@ -139,9 +163,7 @@ class BaselineTrainer:
             data_loader = cls.build_test_loader(cfg, dataset_name)
             t0 = time.perf_counter()
             if cfg.TEST.TTT:
-                for bidx, inputs in enumerate(data_loader):
-                    if cfg.TEST.MIN_BATCH_NUM is not None and bidx >= cfg.TEST.MIN_BATCH_NUM:
-                        break
+                for inputs in cls.tta_batches(model, data_loader, cfg.TEST.MIN_BATCH_NUM):
                     cls.tta_step(model, optimizer, inputs)
             if timers is not None:
                 torch.cuda.synchronize()

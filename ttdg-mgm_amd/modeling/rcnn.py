@@ -42,6 +42,7 @@ class DAobjTwoStagePseudoLabGeneralizedRCNN(nn.Module):
         self.graph_generator = PrototypeComputation(self.roi_heads.num_classes, sample_dist)
         self.multi_matching_sup = U_sup(self.roi_heads.num_classes, univ_size)
         self.multi_matching_unsup = MGM3_unsup(self.roi_heads.num_classes, univ_size)
+        self.sync_universe = False      # Mode S (engine/sync_universe.py): all ranks adapt on one gathered multi-graph
         self.teacher_forced = False     # synthetic runs: replace detections by the jittered GT boxes the inputs carry
         self.autocast_backbone = False  # cfg-5: bf16 autocast for the backbone only
 
@@ -69,6 +70,13 @@ class DAobjTwoStagePseudoLabGeneralizedRCNN(nn.Module):
     def forward(self, batched_inputs, branch=None, given_proposals=None, val_mode=False):
         if not self.training and not val_mode:
             return self.inference(batched_inputs)
+        if batched_inputs is None:
+            # Mode S only: this rank's shard has no batch left, but it still joins the all-gather and the replicated matching
+            if not (branch == "TTT" and self.sync_universe):
+                raise ValueError("batched_inputs=None is only meaningful for a synchronous-universe TTT step")
+            from ..engine import sync_universe
+            nodes, labels = sync_universe.gather_graphs(None, None, self.device)
+            return self.multi_matching_unsup(nodes, labels, self.multi_matching_sup.U), [], [], []
         images = self.preprocess_image(batched_inputs)
         features = self._backbone(images.tensor)
         if branch == "TTT":
@@ -104,6 +112,10 @@ class DAobjTwoStagePseudoLabGeneralizedRCNN(nn.Module):
                     proposals_roih = [self._forced(x, sz) for x, sz in zip(batched_inputs, images.image_sizes)]
             feats = [features[k] for k in ("p2", "p3", "p4", "p5", "p6")]
             nodes, labels = self.graph_generator(feats, proposals_roih)
+            if self.sync_universe:
+                # Mode S (engine/sync_universe.py): one all-gather turns the per-rank graphs into the global multi-graph
+                from ..engine import sync_universe
+                nodes, labels = sync_universe.gather_graphs(nodes, labels, self.device)
             loss = self.multi_matching_unsup(nodes, labels, self.multi_matching_sup.U)
             if DENSE_INFERENCE and side is not None:
                 torch.cuda.current_stream().wait_stream(side)      # join: backward / SGD start after the detector work
