@@ -612,7 +612,7 @@ static size_t ga_fixed_lds_bytes(int cmaxp, int GA_WAVES, int cwmax, int M) {
 static inline int ga_mp(int M) { return (M + 31) & ~31; }
 
 // gagm_large.hip
-#define GAGM_LARGE_FROM_DEFAULT (1 << 30)
+#define GAGM_LARGE_FROM_DEFAULT 320   // measured (tools/bench_gagm_scale.py): 140 vs 89 us per iteration at 451 nodes, 392 vs 95 at 892; 69 vs 69 at 221
 size_t ttdg_gagm_large_ws_bound(int M);
 int ttdg_gagm_large_solve(const float* Apack, const float* W, const float* U0, ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg,
                           float* U, int32_t* info, void* ws, hipStream_t st);
