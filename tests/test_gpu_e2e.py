@@ -278,3 +278,52 @@ def test_sync_universe_step_equals_single_process_step():
         assert c["max_param_update"] > 1e-6, c                                  # the step did move the weights
         # split: the vendor's convolution backward on 2 + 2 images vs on 4 (different algorithm, ~1 % on single elements)
         assert c["max_param_diff_vs_single_process"] <= (0.03 if name == "split" else 1e-3) * c["max_param_update"] + 2e-8, c
+
+
+def test_train_net_eval_only_on_coco_json(tmp_path):
+    """``train_net.py --eval-only`` end to end: COCO-json dataset written here (PNG images, polygon + RLE
+    ground truth), a checkpoint in detectron2's {"model": ...} layout, two test datasets -> TTA + Dice per dataset, the
+    family mean, and result_ap.txt in the reference's two-line format."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from PIL import Image
+    from ttdg_mgm_amd import synth
+    from ttdg_mgm_amd.config import get_cfg
+    from ttdg_mgm_amd.engine import BaselineTrainer
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    images, anns = [], []
+    for i in range(4):
+        img, boxes, classes, masks = synth.fundus_image(7000 + i, 192)
+        Image.fromarray(img.permute(1, 2, 0).numpy()).save(str(tmp_path / ("f%d.png" % i)))
+        images.append(dict(id=i + 1, file_name="f%d.png" % i, height=192, width=192))
+        for k in range(len(classes)):
+            m = masks[k].numpy().T.reshape(-1)                       # column-major runs
+            change = np.flatnonzero(np.diff(np.concatenate([[0], m.astype(np.int8), [0]])))
+            counts = np.diff(np.concatenate([[0], change, [m.size]])).tolist()
+            x0, y0, x1, y1 = [float(v) for v in boxes[k]]
+            anns.append(dict(id=len(anns) + 1, image_id=i + 1, category_id=int(classes[k]) + 1, iscrowd=0, bbox=[x0, y0, x1 - x0, y1 - y0],
+                             segmentation=dict(size=[192, 192], counts=counts)))
+    for name in ("fundusA_val", "fundusB_val"):
+        with open(str(tmp_path / (name + ".json")), "w") as f:
+            json.dump(dict(images=images, annotations=anns, categories=[dict(id=1, name="disc"), dict(id=2, name="cup")]), f)
+    cfg = get_cfg()
+    cfg.MODEL.DEVICE = "cpu"
+    torch.manual_seed(3)
+    ckpt = str(tmp_path / "model_final.pth")
+    torch.save({"model": BaselineTrainer.build_model(cfg).state_dict(), "iteration": 1}, ckpt)
+    out = str(tmp_path / "out")
+    cmd = [sys.executable, os.path.join(root, "train_net.py"), "--eval-only", "--config-file", os.path.join(root, "configs", "test_segment.yaml"),
+           "--register-coco", "fundusA_val", str(tmp_path / "fundusA_val.json"), str(tmp_path),
+           "--register-coco", "fundusB_val", str(tmp_path / "fundusB_val.json"), str(tmp_path),
+           "MODEL.WEIGHTS", ckpt, "DATASETS.TEST", "('fundusA_val','fundusB_val')", "TEST.BATCH", "2", "INPUT.MIN_SIZE_TEST", "256",
+           "OUTPUT_DIR", out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = open(os.path.join(out, "result_ap.txt")).read().splitlines()
+    assert lines[0] == "loading data from: " + ckpt
+    res = json.loads(lines[1])
+    assert set(res) == {"fundusA_val", "fundusB_val", "fundusA_mean", "fundusB_mean"}
+    for v in res.values():
+        assert set(v) == {"Dice Coefficient", "Enhanced Alignment Metric", "Structural Similarity Metric"}

@@ -39,7 +39,21 @@ class CfgNode(dict):
             parts = k.split(".")
             for p in parts[:-1]:
                 node = node[p]
-            node[parts[-1]] = yaml.safe_load(v) if isinstance(v, str) else v
+            node[parts[-1]] = _decode(v) if isinstance(v, str) else v
+
+
+def _decode(v):
+    """Command-line values as yacs reads them: a Python literal when it parses as one ("('a',)", "0.001", "True"), else
+    yaml scalars ("true", "null"), else the string itself."""
+    import ast
+    try:
+        out = ast.literal_eval(v)
+        return list(out) if isinstance(out, tuple) else out
+    except (ValueError, SyntaxError):
+        try:
+            return yaml.safe_load(v)
+        except yaml.YAMLError:
+            return v
 
 
 def _node(d):
