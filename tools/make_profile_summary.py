@@ -2,7 +2,8 @@
 whole-run stats of the hand-written kernels (from *_kernel_stats.csv) + steady-state breakdown (trace window)."""
 import csv, sys, subprocess, os
 stats, trace, warm, out = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
-OURS = ("gagm_kernel", "affinity_", "sinkhorn_", "mha_adj", "perm_loss", "node_", "sgd_multi", "gemm_f32", "colsum", "nms_", "roi_align", "lap_batched")
+OURS = ("gagm_", "affinity_", "sinkhorn_", "mha_adj", "perm_loss", "node_", "sgd_multi", "gemm_f32", "gemm_splitk", "colsum", "nms_", "roi_align",
+        "lap_batched", "rpn_decode", "box_inference", "paste_masks", "bias_act", "dice_", "emeasure", "smeasure")
 rows = list(csv.DictReader(open(stats)))
 with open(out, "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline  (MI355X, gfx950)\n")
