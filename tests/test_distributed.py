@@ -134,3 +134,46 @@ def test_sync_universe_gather_and_gradient_allreduce(layout):
         assert torch.allclose(g0, only0.grad, rtol=1e-5, atol=1e-7)       # gradient on rank 0 only -> zeros from rank 1
         assert unused_none
     assert torch.equal(res[0][4], res[1][4]) and torch.equal(res[0][6], res[1][6])
+
+
+def _lockstep_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ttdg_mgm_amd import data
+        from ttdg_mgm_amd.config import get_cfg
+        from ttdg_mgm_amd.engine import BaselineTrainer
+
+        class Model:
+            sync_universe = True
+            device = torch.device("cpu")
+
+        cfg = get_cfg()
+        cfg.TEST.BATCH = 2
+        data.register_synthetic("lock_ds", 5, size=64)                # shards: rank 0 -> 3 images (2 batches), rank 1 -> 2 images (1 batch)
+        loader = data.build_detection_test_loader(cfg, "lock_ds", rank, world)
+        steps = BaselineTrainer.tta_batches(Model(), loader)
+        capped = BaselineTrainer.tta_batches(Model(), loader, 1)
+        plain = Model()
+        plain.sync_universe = False
+        q.put((rank, [None if b is None else [d["image_id"] for d in b] for b in steps], len(capped), len(BaselineTrainer.tta_batches(plain, loader))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sync_universe_keeps_ranks_in_lockstep_on_uneven_shards():
+    """Mode S: every rank takes max-over-ranks adaptation steps and feeds None once its shard is exhausted (the collectives
+    inside a step must be entered by all ranks); Mode R keeps each rank's own count."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_lockstep_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [[0, 1], [2]] and res[1][1] == [[3, 4], None]
+    assert res[0][2] == 1 and res[1][2] == 1
+    assert res[0][3] == 2 and res[1][3] == 1
