@@ -75,9 +75,11 @@ def worker(rank, world, port, args):
     cfg.MODEL.DEVICE = "cuda:%d" % local
     from ttdg_mgm_amd.engine import BaselineTrainer
     from ttdg_mgm_amd.engine.checkpoint import load_weights
+    if cfg.SEMISUPNET.Trainer == "ateacher":
+        raise NotImplementedError("the mean-teacher trainer is source training (out of scope); its checkpoints are evaluated with "
+                                  "SEMISUPNET.Trainer baseline (the student / teacher half is picked by TEST.EVAL_STU)")
     if cfg.SEMISUPNET.Trainer != "baseline":
-        raise ValueError("Trainer Name is not found.") if cfg.SEMISUPNET.Trainer != "ateacher" else NotImplementedError(
-            "the mean-teacher trainer is source training (out of scope); evaluate its checkpoints with SEMISUPNET.Trainer baseline")
+        raise ValueError("Trainer Name is not found.")
     BaselineTrainer.rank, BaselineTrainer.world, BaselineTrainer.device = rank, world, torch.device("cuda", local)
     torch.manual_seed(0)
     model = BaselineTrainer.build_model(cfg)
