@@ -10,7 +10,8 @@ the eval-mode Dice pass over the same batches (reference order, engine/trainer.p
 head still run inside the timed region.  One "step" = one adapted batch (TTA step + its share of the eval pass).
 Each rank adapts its own shard (InferenceSampler semantics, no data-path collective): weak scaling; at N > 1 the one
 collective of the path is the all-gather of the per-rank Dice score lists at the end of the eval pass (RCCL).  The eval
-pass feeds its independent batches from two host threads on two HIP streams (--eval-streams).
+pass can feed its independent batches from several host threads on their own HIP streams (--eval-streams N; default 1:
+the pass is GPU-bound since the detection pipelines were fused).
 
 Prints ONE JSON line on rank 0 with the contract fields plus `roofline` (dominant hand-written kernel, timed live
 with HIP events on the launch stream) and, at N = 1, `cpu_baseline` (the oracle "port" on the host cores, bounded
@@ -39,7 +40,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=64)
-    ap.add_argument("--eval-streams", type=int, default=2, help="concurrent eval batches (HIP streams) in the Dice pass; 1 = sequential")
+    ap.add_argument("--eval-streams", type=int, default=1, help="concurrent eval batches (HIP streams) in the Dice pass; 1 = sequential")
     ap.add_argument("--no-overlap-detector", action="store_true", help="A/B: keep the teacher-forced RPN + box head on the main stream")
     ap.add_argument("--eval-coalesce", type=int, default=1, help="loader batches merged into one inference call in the Dice pass; 1 = none")
     ap.add_argument("--free-running", action="store_true", help="use the detector's own boxes instead of teacher forcing")

@@ -16,7 +16,10 @@ from ..modeling import build_model
 from ..optim import FusedSGD
 
 
-EVAL_STREAMS = 2      # concurrent eval batches per GPU (HIP streams, one host thread each); 1 = the plain loop
+EVAL_STREAMS = 1      # concurrent eval batches per GPU (HIP streams, one host thread each); 1 = the plain loop.  With the fused
+                      # detection pipelines an eval batch is ~5 ms of Python for ~19 ms of GPU work, so one stream is GPU-bound;
+                      # two threads only add GIL traffic (1 core: 62.2 vs 59.4 images/s, >= 2 cores: equal).  2 pays when the
+                      # host needs longer to issue a batch than the GPU to run it.
 EVAL_COALESCE = 1     # loader batches merged into one inference call in the Dice pass (eval-mode inference is per image:
                       # FrozenBN, no cross-image op, so the merge is invisible in the results).  Off by default: measured on
                       # MI355X the fp32 convolutions gain nothing at batch 16 (44.8 vs 49.3 images/s) and a batch size the
