@@ -42,6 +42,16 @@ def load():
     return mgm, bg
 
 
+def load_tree_sinkhorn():
+    """The reference tree's own log-Sinkhorn: ``GModule.sinkhorn_iter`` of the (otherwise dead) graph_matching.py:788-840.
+    It does not touch ``self``; returned as a plain function (log_alpha, n_iters, slack) -> log_alpha."""
+    load()
+    import importlib
+    gm = importlib.import_module("adapteacher.modeling.GModule.graph_matching")
+    fn = gm.GModule.sinkhorn_iter
+    return lambda log_alpha, n_iters, slack=False: fn(None, log_alpha, n_iters=n_iters, slack=slack)
+
+
 class FakeBoxes:
     def __init__(self, t):
         self.tensor = t

@@ -183,3 +183,44 @@ def hippi_inputs(sizes, seed):
 
 def usup_inputs(sizes, seed):
     return synth.node_sets(seed, sizes, scale=0.5)
+
+
+# ----------------------------------------------------------------------------- A5: the reference tree's own log-Sinkhorn
+# adapteacher/modeling/GModule/graph_matching.py:828-839 (``sinkhorn_iter(log_alpha, n_iters=K, slack=False)``: K full
+# row-then-column sweeps on a square batch, no dummy rows, no tau).  It is the only Sinkhorn arithmetic the reference
+# tree holds itself (pygmtools is an un-vendored dependency), so it pins the sweep order / logsumexp arithmetic of
+# oracle/sinkhorn_spec.py and of the HIP kernels:  spec(s, tau, max_iter=2K) == exp(sinkhorn_iter(s / tau, K)).
+# "dm_*" cases pin the dummy-row machinery the same way: the (c - r) dummy rows are written out as rows of the
+# constant -100 (Appendix B step 5) by THIS file, the reference function runs on the padded square matrix, and
+# spec(s, dummy_row=True)[real rows] must equal it.  What stays from memory of pygmtools is then only: the fill
+# constant, that it is applied after the tau scaling, and the orientation rule (rows <= cols).
+SKREF_SWEEPS = 10          # K full sweeps == max_iter 20 of the pygmtools call
+SKREF_CASES = (  # name, batch, rows, cols, tau, seed, input scale
+    ("sq_t10", 4, 32, 32, 0.1, 950, 1.0),
+    ("sq_t05", 3, 22, 22, 0.05, 951, 0.3),
+    ("sq_t006", 4, 32, 32, 0.00625, 952, 1.0),
+    ("sq40_t05", 2, 40, 40, 0.05, 953, 0.3),
+    ("sq64_t0125", 1, 64, 64, 0.0125, 954, 0.5),
+    ("dm_t05", 1, 18, 25, 0.05, 955, 0.3),
+    ("dm_t10", 4, 22, 32, 0.1, 956, 1.0),
+    ("dm_t006", 3, 30, 32, 0.00625, 957, 1.0),
+    ("dm_one", 2, 1, 5, 0.1, 958, 1.0),
+)
+SKREF_DUMMY_FILL = -100.0
+
+
+def skref_input(name):
+    for n, b, r, c, tau, seed, scale in SKREF_CASES:
+        if n == name:
+            return synth.normal(synth.gen(seed), (b, r, c), scale), tau
+    raise KeyError(name)
+
+
+def skref_log_alpha(name):
+    """The (b, c, c) log-domain matrix handed to the reference function: s / tau, dummy rows of -100 appended."""
+    s, tau = skref_input(name)
+    b, r, c = s.shape
+    la = s / tau
+    if r < c:
+        la = torch.cat([la, torch.full((b, c - r, c), SKREF_DUMMY_FILL)], dim=1)
+    return la

@@ -225,6 +225,15 @@ def gold_dice():
     np.savez_compressed(os.path.join(OUT, "dice.npz"), **out)
 
 
+def gold_sinkhorn_ref():
+    """Outputs of the reference tree's own log-Sinkhorn (graph_matching.py:828-839, slack=False) in the LOG domain."""
+    fn = ref_import.load_tree_sinkhorn()
+    out = {}
+    for name, b, r, c, tau, seed, scale in SKREF_CASES:
+        out[f"{name}_log"] = npy(fn(skref_log_alpha(name), SKREF_SWEEPS, slack=False))
+    np.savez_compressed(os.path.join(OUT, "sinkhorn_ref.npz"), **out)
+
+
 def gold_usup(mgm):
     """N3: HiPPI on planted similarities, and U_sup.forward with the HiPPI result captured so that everything carrying
     gradient can be pinned independently of the rounding-driven edge weights."""
@@ -278,6 +287,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "usup":
         gold_usup(mgm)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "sinkhorn_ref":
+        gold_sinkhorn_ref()
+        return
     gold_dice()
     gold_affinity(mgm)
     gold_mha(mgm)
@@ -287,6 +299,7 @@ def main():
     gold_mgm3(mgm)
     gold_proto(bg)
     gold_usup(mgm)
+    gold_sinkhorn_ref()
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

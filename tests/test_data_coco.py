@@ -144,12 +144,21 @@ def test_checkpoint_formats(tmp_path):
     ens = {"modelStudent." + k: v for k, v in sd.items()}
     ens.update({"modelTeacher." + k: v + 1 for k, v in sd.items()})
     torch.save({"model": ens}, p4)
-    for p in (p1, p2, p3, p4):
+    for p in (p1, p2):
         m = fresh()
         assert load_weights(m, p) == ([], []) and same(m)
+    with pytest.raises(ValueError):                 # a pickle executes code from the file: refused unless trusted
+        load_weights(fresh(), p3)
     m = fresh()
-    load_weights(m, p4, prefer_student=False)
+    assert load_weights(m, p3, trusted=True) == ([], []) and same(m)
+    m = fresh()                                      # reference default TEST.EVAL_STU = False: the teacher half (config.py:11)
+    load_weights(m, p4)
     assert torch.equal(m[0].weight, sd["0.weight"] + 1)
+    m = fresh()
+    assert load_weights(m, p4, prefer_student=True) == ([], []) and same(m)
+    torch.save({"model": {"wrong.prefix." + k: v for k, v in sd.items()}}, p2)
+    with pytest.raises(ValueError):                 # nothing matches: never a silent random-init run
+        load_weights(fresh(), p2)
     m = fresh()
     before = {k: v.clone() for k, v in m.state_dict().items()}
     assert load_weights(m, "") == ([], []) and all(torch.equal(v, before[k]) for k, v in m.state_dict().items())

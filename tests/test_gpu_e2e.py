@@ -86,6 +86,41 @@ def test_tta_step_updates_exactly_the_reference_parameter_set(setup):
     assert torch.isfinite(torch.stack([v.detach().abs().max() for v in gpu.parameters()])).all()
 
 
+def test_eval_after_tta_step_sees_the_adapted_weights(setup):
+    """Continual TTA (trainer.py:452-485): eval -> adaptation step -> eval.  The eval pass caches FrozenBN-folded filters
+    keyed on the weights' autograd version; the fused SGD kernel writes through raw pointers, so it must bump that version
+    or the second Dice pass runs on stale filters.  Checked against an uncached convolution with the live weights."""
+    import torch.nn.functional as F
+    from ttdg_mgm_amd.engine import BaselineTrainer
+    from ttdg_mgm_amd.modeling.backbone import ConvNorm
+    cfg, cpu, gpu, batch = setup
+    gpu = copy.deepcopy(gpu)
+    opt = BaselineTrainer.build_optimizer(cfg, gpu)
+    conv = gpu.backbone.bottom_up.res4[0].conv2
+    assert isinstance(conv, ConvNorm) and conv.weight.requires_grad
+    x = torch.randn(1, conv.in_channels, 12, 12, device="cuda:0")
+
+    def live(c):
+        scale, shift = c.norm.folded()
+        return F.conv2d(x, c.weight.detach() * scale, shift, c.stride, c.padding)
+
+    gpu.eval()
+    with torch.no_grad():
+        gpu(batch)                                   # fills the folded-filter caches
+        y0 = conv(x)
+    assert float((y0 - live(conv)).abs().max()) <= 1e-5
+    gpu.train()
+    v0 = conv.weight._version
+    w_before = conv.weight.detach().clone()
+    assert BaselineTrainer.tta_step(gpu, opt, batch) is not None
+    assert not torch.equal(conv.weight.detach(), w_before) and conv.weight._version > v0
+    gpu.eval()
+    with torch.no_grad():
+        y1 = conv(x)
+    assert float((y1 - live(conv)).abs().max()) <= 1e-5, "eval pass ran on filters folded before the adaptation step"
+    assert float((y1 - y0).abs().max()) > 0
+
+
 def test_eval_pass_and_dice_run_on_device(setup):
     from ttdg_mgm_amd.engine import inference_on_dataset
     from ttdg_mgm_amd.evaluation import DiceEvaluator

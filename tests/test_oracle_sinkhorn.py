@@ -1,5 +1,6 @@
-"""Property tests pinning oracle/sinkhorn_spec.py (the stand-in for the absent
-pygmtools==0.3.8; PARITY UNPINNED against the real package — SURVEY.md §8c)."""
+"""oracle/sinkhorn_spec.py (the stand-in for the absent pygmtools==0.3.8) against the reference tree's own
+log-Sinkhorn (fixture tests/golden/sinkhorn_ref.npz <- graph_matching.py:828-839) and against properties.
+What stays unpinned against the real package is listed in the spec's header."""
 import numpy as np
 import pytest
 import torch
@@ -7,6 +8,46 @@ import torch
 from oracle import gmodule as og
 from oracle.sinkhorn_spec import sinkhorn
 from ttdg_mgm_amd import synth
+
+
+import cases
+from oracle.sinkhorn_spec import log_sinkhorn
+
+
+@pytest.mark.parametrize("name", [c[0] for c in cases.SKREF_CASES])
+@pytest.mark.parametrize("batched", [False, True])
+def test_spec_matches_reference_tree_log_sinkhorn(golden, name, batched):
+    """Log domain, fp32, both code paths of the spec: <= 4 ulp of the largest log-domain magnitude (the reference function
+    and the spec run the same torch.logsumexp sequence; with dummy rows the spec's bookkeeping differs, the arithmetic not)."""
+    ref = torch.from_numpy(golden("sinkhorn_ref")[name + "_log"])
+    s, tau = cases.skref_input(name)
+    b, r, c = s.shape
+    got = log_sinkhorn(s, dummy_row=r < c, max_iter=2 * cases.SKREF_SWEEPS, tau=tau, batched_operation=batched)
+    assert got.shape == (b, r, c)
+    ulp = float((s / tau).abs().max()) * 2.0 ** -23
+    err = float((got - ref[:, :r]).abs().max())
+    print(name, "log-domain |d| = %.3e (ulp of max|s/tau| = %.3e)" % (err, ulp))
+    assert err <= max(4 * ulp, 1e-6)
+    assert float((got.exp() - ref[:, :r].exp()).abs().max()) <= 1e-6
+
+
+def test_ragged_batch_equals_reference_on_the_valid_blocks(golden):
+    """n1 masking (gagm's unequal-size branch): every matrix of a zero-padded batch equals the pinned stand-alone problem."""
+    ref = torch.from_numpy(golden("sinkhorn_ref")["dm_t10_log"])
+    s, tau = cases.skref_input("dm_t10")                      # (4, 22, 32)
+    pad = torch.zeros(4, 30, 32)
+    pad[:, :22] = s
+    sizes = torch.tensor([22, 22, 22, 22])
+    got = log_sinkhorn(pad, n1=sizes, dummy_row=True, max_iter=20, tau=tau, batched_operation=True)
+    assert float((got[:, :22] - ref[:, :22]).abs().max()) <= 1e-5 and bool(torch.isinf(got[:, 22:]).all())
+
+
+def test_transposed_problem_equals_reference(golden):
+    """rows > cols: the spec solves the transposed problem (Appendix B step 1) - pinned through the fixture's transpose."""
+    ref = torch.from_numpy(golden("sinkhorn_ref")["dm_t05_log"])          # (1, 25, 25), real rows 18
+    s, tau = cases.skref_input("dm_t05")                                   # (1, 18, 25)
+    got = log_sinkhorn(s.transpose(1, 2).contiguous(), dummy_row=True, max_iter=20, tau=tau)
+    assert float((got.transpose(1, 2) - ref[:, :18]).abs().max()) <= 1e-5
 
 
 def rnd(seed, shape, scale=1.0):

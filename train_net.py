@@ -83,7 +83,7 @@ def worker(rank, world, port, args):
     BaselineTrainer.rank, BaselineTrainer.world, BaselineTrainer.device = rank, world, torch.device("cuda", local)
     torch.manual_seed(0)
     model = BaselineTrainer.build_model(cfg)
-    load_weights(model, cfg.MODEL.WEIGHTS, prefer_student=bool(cfg.TEST.get("EVAL_STU", True)))
+    load_weights(model, cfg.MODEL.WEIGHTS, prefer_student=bool(cfg.TEST.get("EVAL_STU", False)))
     if not cfg.MODEL.WEIGHTS and cfg.DATASETS.TEST:
         # random initialisation only: give the frozen BatchNorm layers statistics, as bench.py does (a checkpoint carries its own)
         from ttdg_mgm_amd.modeling import calibrate_frozen_bn

@@ -31,6 +31,7 @@ class CfgNode(dict):
             d = yaml.safe_load(f) or {}
         d.pop("_BASE_", None)          # Base-RCNN-FPN.yaml values are the defaults below
         self.merge_from_dict(d)
+        check_supported(self)
 
     def merge_from_list(self, opts):
         assert len(opts) % 2 == 0
@@ -72,12 +73,61 @@ def get_cfg():
         "INPUT": {"FORMAT": "RGB", "MIN_SIZE_TEST": 800, "MAX_SIZE_TEST": 1333},
         "DATASETS": {"TEST": []},
         "DATALOADER": {"NUM_WORKERS": 4},
-        "SOLVER": {"BASE_LR": 0.005, "MOMENTUM": 0.9, "WEIGHT_DECAY": 1e-4, "WEIGHT_DECAY_NORM": 0.0, "IMG_PER_BATCH_LABEL": 8},
-        "TEST": {"TTT": True, "BATCH": 4, "DICE_THRES": 0.9, "MIN_BATCH_NUM": None, "DETECTIONS_PER_IMAGE": 100,
-                 "EVALUATOR": "COCOeval"},
-        "SEMISUPNET": {"Trainer": "baseline", "BBOX_THRESHOLD": 0.8, "DIS_TYPE": "p2"},
+        "SOLVER": {"BASE_LR": 0.005, "MOMENTUM": 0.9, "WEIGHT_DECAY": 1e-4, "WEIGHT_DECAY_NORM": 0.0, "IMG_PER_BATCH_LABEL": 1},
+        # add_ateacher_config defaults (reference config.py:10-17,35): the student half is NOT evaluated by default, one
+        # image per test batch unless the yaml says otherwise (test_segment.yaml:34 sets 4)
+        "TEST": {"TTT": True, "BATCH": 1, "DICE_THRES": 0.9, "MIN_BATCH_NUM": None, "DETECTIONS_PER_IMAGE": 100,
+                 "EVAL_STU": False, "EVALUATOR": "COCOeval"},
+        "SEMISUPNET": {"Trainer": "ateacher", "BBOX_THRESHOLD": 0.7, "DIS_TYPE": "res4"},
         "OUTPUT_DIR": "./output",
     })
+
+
+# keys of the reference yamls whose value the R50-FPN stand-in hard-codes (modeling/): a yaml that asks for something else
+# must not silently build the default network
+_HARD_CODED = {
+    "MODEL.META_ARCHITECTURE": "DAobjTwoStagePseudoLabGeneralizedRCNN",
+    "MODEL.MASK_ON": True,
+    "MODEL.BACKBONE.NAME": "build_resnet_fpn_backbone",
+    "MODEL.BACKBONE.FREEZE_AT": 2,
+    "MODEL.RESNETS.DEPTH": 50,
+    "MODEL.RESNETS.OUT_FEATURES": ["res2", "res3", "res4", "res5"],
+    "MODEL.RESNETS.NORM": "FrozenBN",
+    "MODEL.RESNETS.STRIDE_IN_1X1": True,
+    "MODEL.FPN.IN_FEATURES": ["res2", "res3", "res4", "res5"],
+    "MODEL.FPN.OUT_CHANNELS": 256,
+    "MODEL.ANCHOR_GENERATOR.SIZES": [[32], [64], [128], [256], [512]],
+    "MODEL.ANCHOR_GENERATOR.ASPECT_RATIOS": [[0.5, 1.0, 2.0]],
+    "MODEL.RPN.IN_FEATURES": ["p2", "p3", "p4", "p5", "p6"],
+    "MODEL.RPN.PRE_NMS_TOPK_TRAIN": 2000, "MODEL.RPN.PRE_NMS_TOPK_TEST": 1000,
+    "MODEL.RPN.POST_NMS_TOPK_TRAIN": 1000, "MODEL.RPN.POST_NMS_TOPK_TEST": 1000,
+    "MODEL.RPN.NMS_THRESH": 0.7,
+    "MODEL.PROPOSAL_GENERATOR.NAME": "PseudoLabRPN",
+    "MODEL.ROI_HEADS.NAME": "StandardROIHeadsPseudoLab",
+    "MODEL.ROI_HEADS.IN_FEATURES": ["p2", "p3", "p4", "p5"],
+    "MODEL.ROI_BOX_HEAD.NAME": "FastRCNNConvFCHead",
+    "MODEL.ROI_BOX_HEAD.NUM_FC": 2, "MODEL.ROI_BOX_HEAD.NUM_CONV": 0, "MODEL.ROI_BOX_HEAD.FC_DIM": 1024,
+    "MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION": 7,
+    "MODEL.ROI_MASK_HEAD.NAME": "MaskRCNNConvUpsampleHead",
+    "MODEL.ROI_MASK_HEAD.NUM_CONV": 4, "MODEL.ROI_MASK_HEAD.POOLER_RESOLUTION": 14,
+}
+
+
+def _canon(v):
+    return [_canon(x) for x in v] if isinstance(v, (list, tuple)) else v
+
+
+def check_supported(cfg):
+    """Raise on a config value the stand-in hard-codes differently (detectron2 would have built a different network)."""
+    for key, want in _HARD_CODED.items():
+        node = cfg
+        for part in key.split("."):
+            if not isinstance(node, dict) or part not in node:
+                node = None
+                break
+            node = node[part]
+        if node is not None and _canon(node) != _canon(want):
+            raise ValueError("%s = %r is not supported: the MI355X stand-in builds %r (ttdg-mgm_amd/modeling)" % (key, node, want))
 
 
 def add_ateacher_config(cfg):

@@ -192,7 +192,8 @@ def build_model(cfg):
     m = DAobjTwoStagePseudoLabGeneralizedRCNN(
         backbone=FPN(freeze_at=2),
         proposal_generator=PseudoLabRPN(),
-        roi_heads=StandardROIHeadsPseudoLab(cfg.MODEL.ROI_HEADS.NUM_CLASSES),
+        roi_heads=StandardROIHeadsPseudoLab(cfg.MODEL.ROI_HEADS.NUM_CLASSES, cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST,
+                                            cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST, cfg.TEST.DETECTIONS_PER_IMAGE),
         pixel_mean=cfg.MODEL.PIXEL_MEAN, pixel_std=cfg.MODEL.PIXEL_STD, input_format=cfg.INPUT.FORMAT,
         dis_type=cfg.SEMISUPNET.DIS_TYPE)
     return m.to(torch.device(cfg.MODEL.DEVICE))

@@ -86,6 +86,9 @@ class FusedSGD(torch.optim.Optimizer):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         call("ttdg_sgd_multi_tensor", base, base + t_off, base + o_off, nc, CHUNK, float(lr), float(mom), stream())
+        # the kernel writes through raw pointers: tell autograd (and every cache keyed on ``_version``, e.g. the folded
+        # FrozenBN filters of modeling/backbone.py that the Dice pass reuses) that the parameters changed
+        torch.autograd.graph.increment_version([t[0] for t in todo] + [t[2] for t in todo])
         if timers is not None:
             e1.record()
             nbytes = sum(p.numel() * 4 * (4 if first else 5) for p, _, _, _, first in todo)   # p r/w, g r, buf (r)/w
