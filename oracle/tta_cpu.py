@@ -106,7 +106,7 @@ class _CpuBackend:
         return paste_masks_in_image_torch(masks.reshape(masks.shape[0], 1, masks.shape[-2], masks.shape[-1]), boxes, (H, W), threshold)
 
 
-def _model_and_batches(n_steps, batch, size, teacher_forced):
+def _model_and_batches(n_steps, batch, size, teacher_forced, weights=None):
     from ttdg_mgm_amd import data
     from ttdg_mgm_amd.config import get_cfg
     from ttdg_mgm_amd.modeling import build_model, detector
@@ -114,13 +114,17 @@ def _model_and_batches(n_steps, batch, size, teacher_forced):
     cfg.MODEL.DEVICE = "cpu"
     cfg.TEST.BATCH = batch
     name = "synthfundus_cpu_baseline"
-    data.register_synthetic(name, n_steps * batch, size=size, cfg_id=2)
+    data.register_synthetic(name, n_steps * batch, size=size, cfg_id=2)        # the first images of bench.py's stream
     torch.manual_seed(0)
     model = build_model(cfg)
     model.teacher_forced = teacher_forced
     batches = list(data.build_detection_test_loader(cfg, name))
-    from ttdg_mgm_amd.modeling import calibrate_frozen_bn
-    calibrate_frozen_bn(model, batches[0])
+    if weights:
+        from ttdg_mgm_amd.engine.checkpoint import load_weights
+        load_weights(model, weights)
+    else:
+        from ttdg_mgm_amd.modeling import calibrate_frozen_bn
+        calibrate_frozen_bn(model, batches[0])
     return cfg, model, batches, detector, name
 
 
@@ -147,25 +151,46 @@ def tta_step(model, inputs, bufs, cfg):
     return loss
 
 
-def time_steps(n_steps, batch, size, teacher_forced=True):
-    """Seconds for n_steps adaptation steps followed by the eval pass over the same batches (no warm-up: the CPU
-    path has no autotuning; the first step is representative)."""
+def _one_rep(model, cfg, batches, name):
+    """n TTA steps, then the eval pass + Dice over the same batches (reference order); returns (seconds, Dice dict)."""
     from ttdg_mgm_amd.evaluation import DiceEvaluator
-    cfg, model, batches, detector, name = _model_and_batches(n_steps, batch, size, teacher_forced)
+    model.train()
+    bufs = [None] * len([q for q in model.parameters() if q.requires_grad])
+    t0 = time.perf_counter()
+    for b in batches:
+        tta_step(model, b, bufs, cfg)
+    model.eval()
+    dice = DiceEvaluator(name, cfg.TEST.DICE_THRES, dataset_dicts=[it["dataset_dict"] for b in batches for it in b])
+    with torch.no_grad():
+        for b in batches:
+            dice.process(b, model(b))
+    res = dice.evaluate()
+    dt = time.perf_counter() - t0
+    res["kept_masks"] = len(dice.dice_scores)
+    return dt, res
+
+
+def run(n_steps, batch, size, teacher_forced=True, weights=None, reps=3, warmup=1):
+    """``warmup`` untimed-for-the-median repetitions, then ``reps`` timed ones, every repetition from the same initial
+    weights (the state dict is restored outside the timed part).  Returns times, warm-up times and the Dice of the FIRST
+    repetition (checkpoint -> n TTA steps -> eval), which is what bench.py compares with the GPU."""
+    cfg, model, batches, detector, name = _model_and_batches(n_steps, batch, size, teacher_forced, weights)
+    init = {k: v.detach().clone() for k, v in model.state_dict().items()}
     saved = detector._backend
     detector._backend = _CpuBackend
     try:
-        model.train()
-        bufs = [None] * len([q for q in model.parameters() if q.requires_grad])
-        t0 = time.perf_counter()
-        for b in batches:
-            tta_step(model, b, bufs, cfg)
-        model.eval()
-        dice = DiceEvaluator(name, cfg.TEST.DICE_THRES, dataset_dicts=[it["dataset_dict"] for b in batches for it in b])
-        with torch.no_grad():
-            for b in batches:
-                dice.process(b, model(b))
-        dice.evaluate()
-        return time.perf_counter() - t0
+        times, wtimes, first = [], [], None
+        for r in range(warmup + reps):
+            model.load_state_dict(init)
+            dt, res = _one_rep(model, cfg, batches, name)
+            if first is None:
+                first = res
+            (wtimes if r < warmup else times).append(dt)
+        return dict(times=times, warmup_times=wtimes, dice=first)
     finally:
         detector._backend = saved
+
+
+def time_steps(n_steps, batch, size, teacher_forced=True):
+    """Round-1 entry: one cold repetition."""
+    return run(n_steps, batch, size, teacher_forced, reps=1, warmup=0)["times"][0]

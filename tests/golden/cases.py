@@ -82,6 +82,23 @@ PLANTED_CASES = (  # name, sizes, seed
 )
 
 
+# Planted cases where the kernels branch: graphs above the universe size (transposed Sinkhorn
+# orientation, wave projector with > 32 rows), 64 < n <= 128 (two LAP columns per lane, LDS cost matrix), the
+# multi-workgroup solver (a graph > 128 nodes, or >= 320 nodes in total), and G = 2 with n > 32.
+PLANTED_BIG_CASES = (  # name, sizes, seed
+    ("pb_n40", (40, 36, 45), 903),
+    ("pb_eq48", (48, 48, 48), 904),
+    ("pb_g2n40", (36, 44), 905),
+    ("pb_n100", (100, 70, 128), 906),
+    ("pb_n132", (132, 60, 48), 907),
+    ("pb_12x30", (30,) * 12, 908),
+)
+
+
+PLANTED_BIG_KW = dict(alpha=1.0, noise=0.006, uscale=1.0 / 16)
+PLANTED_BIG_C = 0.07
+
+
 def planted_params(seed, c=0.02, jitter=0.002):
     p = synth.mgm3_params(seed, std=jitter)
     eye = torch.eye(256)
@@ -94,14 +111,23 @@ def planted_params(seed, c=0.02, jitter=0.002):
     return p
 
 
-def planted_nodes(seed, sizes, alpha=0.2, noise=0.02):
+def planted_nodes(seed, sizes, alpha=0.2, noise=0.02, uscale=1.0):
+    """Graphs of up to 32 nodes: noisy copies of distinct universe rows.  Larger graphs (PLANTED_BIG_CASES): all 32
+    universe rows plus n - 32 nodes drawn from a pool of 'off-universe' points Z shared by all graphs (objects that
+    recur across images but are not in the learned universe), in random order: pairwise affinities stay sharp and
+    cycle-consistent, only 32 nodes of such a graph can be assigned."""
     g = synth.gen(seed)
-    U = synth.universe(seed + 70)
+    U = synth.universe(seed + 70) * uscale
+    extra = max(0, max(sizes) - 32)
+    Z = synth.normal(synth.gen(seed + 71), (extra, 256), uscale) if extra else None
     nodes, labels = [], []
     for n in sizes:
-        assert n <= 32
-        ids = torch.from_numpy(g.permutation(32)[:n])
-        nodes.append(alpha * U[ids] + synth.normal(g, (n, 256), noise))
+        if n <= 32:
+            ids = torch.from_numpy(g.permutation(32)[:n])
+            nodes.append(alpha * U[ids] + synth.normal(g, (n, 256), noise))
+        else:
+            base = torch.cat((U, Z[torch.from_numpy(g.permutation(extra)[:n - 32])]))
+            nodes.append(alpha * base[torch.from_numpy(g.permutation(n))] + synth.normal(g, (n, 256), noise))
         labels.append(torch.from_numpy(g.integers(1, 3, size=n).astype(np.int64)))
     return nodes, labels, U
 
@@ -116,6 +142,13 @@ def mgm_inputs(name):
         if n == name:
             nodes, labels, U = planted_nodes(seed, sizes)
             return planted_params(seed + 50), nodes, labels, U, sizes
+    for n, sizes, seed in PLANTED_BIG_CASES:
+        if n == name:
+            # unit-norm universe rows: U0 = x U^T is O(1), so the first projection is a soft one (with the O(50) scores of
+            # the small cases the first Sinkhorn at tau 0.1 is already a hard assignment decided by fp32 rounding once
+            # off-universe nodes compete for the 32 slots)
+            nodes, labels, U = planted_nodes(seed, sizes, **PLANTED_BIG_KW)
+            return planted_params(seed + 50, c=PLANTED_BIG_C), nodes, labels, U, sizes
     raise KeyError(name)
 
 

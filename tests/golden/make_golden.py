@@ -122,36 +122,10 @@ def gold_gagm(mgm):
     np.savez_compressed(os.path.join(OUT, "gagm.npz"), **out)
 
 
-def gold_mgm3(mgm):
-    out = {}
-    for name, sizes, seed in MGM_CASES:
-        params, nodes, labels, U, _ = mgm_inputs(name)
-        m = mgm.MGM3_unsup(2, 32)
-        m.load_state_dict(params, strict=True)
-        m.eval()
-        nodes = [x.requires_grad_() for x in nodes]
-        m.zero_grad()
-        cap = {}
-        orig = m.ga_mgmc.forward
-
-        def spy(*a, _o=orig, _c=cap, **k):
-            res = _o(*a, **k)
-            _c["U"] = res[0].detach().clone()
-            return res
-        m.ga_mgmc.forward = spy
-        loss = m(nodes, labels, U)
-        loss.backward()
-        out[f"{name}_loss"] = npy(loss)
-        out[f"{name}_U"] = npy(cap["U"])      # the pseudo-labels this (rounding-unstable) run happened to produce
-        for gi, x in enumerate(nodes):
-            out[f"{name}_dnode{gi}"] = npy(x.grad)
-        for k, p in m.named_parameters():
-            if p.grad is not None:
-                pgrad(out, f"{name}_d_{k}", p.grad)
-            else:
-                out[f"{name}_nograd_{k}"] = np.zeros(0, np.float32)
-    # planted (trained-like) cases: the solver converges, the reference is rounding-stable -> U is golden too
-    for name, sizes, seed in PLANTED_CASES:
+def planted_goldens(mgm, case_list, out):
+    """Free-running reference runs whose permutation matrices are golden: asserted rounding-stable (1 thread, 8 threads,
+    two 1e-7-relative input perturbations give the same U)."""
+    for name, sizes, seed in case_list:
         params, nodes, labels, U, _ = mgm_inputs(name)
         runs = []
         for trial in range(4):          # 1 thread, 8 threads, and two 1e-7-relative input perturbations
@@ -187,6 +161,45 @@ def gold_mgm3(mgm):
                 pgrad(out, f"{name}_d_{k}", p.grad)
             else:
                 out[f"{name}_nograd_{k}"] = np.zeros(0, np.float32)
+
+
+def gold_mgm3_big(mgm):
+    """Planted cases where the kernels branch: n_g > 32, 64 < n_g <= 128, the multi-workgroup solver, G = 2 with n > 32."""
+    out = {}
+    planted_goldens(mgm, PLANTED_BIG_CASES, out)
+    np.savez_compressed(os.path.join(OUT, "mgm3_big.npz"), **out)
+
+
+def gold_mgm3(mgm):
+    out = {}
+    for name, sizes, seed in MGM_CASES:
+        params, nodes, labels, U, _ = mgm_inputs(name)
+        m = mgm.MGM3_unsup(2, 32)
+        m.load_state_dict(params, strict=True)
+        m.eval()
+        nodes = [x.requires_grad_() for x in nodes]
+        m.zero_grad()
+        cap = {}
+        orig = m.ga_mgmc.forward
+
+        def spy(*a, _o=orig, _c=cap, **k):
+            res = _o(*a, **k)
+            _c["U"] = res[0].detach().clone()
+            return res
+        m.ga_mgmc.forward = spy
+        loss = m(nodes, labels, U)
+        loss.backward()
+        out[f"{name}_loss"] = npy(loss)
+        out[f"{name}_U"] = npy(cap["U"])      # the pseudo-labels this (rounding-unstable) run happened to produce
+        for gi, x in enumerate(nodes):
+            out[f"{name}_dnode{gi}"] = npy(x.grad)
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                pgrad(out, f"{name}_d_{k}", p.grad)
+            else:
+                out[f"{name}_nograd_{k}"] = np.zeros(0, np.float32)
+    # planted (trained-like) cases: the solver converges, the reference is rounding-stable -> U is golden too
+    planted_goldens(mgm, PLANTED_CASES, out)
     # single graph -> None (multi_graph_matching.py:489-490)
     m = ref_mgm3(mgm, 1)
     nodes, labels = synth.node_sets(1, (9,))
@@ -287,6 +300,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "usup":
         gold_usup(mgm)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "mgm3_big":
+        gold_mgm3_big(mgm)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "sinkhorn_ref":
         gold_sinkhorn_ref()
         return
@@ -297,6 +313,7 @@ def main():
     gold_loss(mgm)
     gold_gagm(mgm)
     gold_mgm3(mgm)
+    gold_mgm3_big(mgm)
     gold_proto(bg)
     gold_usup(mgm)
     gold_sinkhorn_ref()

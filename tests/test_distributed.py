@@ -156,7 +156,7 @@ def _lockstep_worker(rank, world, port, q):
         capped = BaselineTrainer.tta_batches(Model(), loader, 1)
         plain = Model()
         plain.sync_universe = False
-        q.put((rank, [None if b is None else [d["image_id"] for d in b] for b in steps], len(capped), len(BaselineTrainer.tta_batches(plain, loader))))
+        q.put((rank, [None if b is None else [d["image_id"] for d in b] for b in steps], len(capped), len(list(BaselineTrainer.tta_batches(plain, loader)))))
     finally:
         dist.destroy_process_group()
 
@@ -177,3 +177,28 @@ def test_sync_universe_keeps_ranks_in_lockstep_on_uneven_shards():
     assert res[0][1] == [[0, 1], [2]] and res[1][1] == [[3, 4], None]
     assert res[0][2] == 1 and res[1][2] == 1
     assert res[0][3] == 2 and res[1][3] == 1
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher: the script spawns one rank per GPU on 127.0.0.1 as
+    the reference's launch(main, num_gpus) does (train_net.py:94-101).  Here with gloo and --plumbing-only: rendezvous, shard
+    arithmetic, barrier, max-over-ranks timing and the Dice all-gather - everything of the N > 1 path that is not GPU work -
+    in the weak (--steps) and the strong (--images, cfg-4) scaling mode."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    for extra, want in ((["--steps", "3", "--warmup", "1"], dict(steps=3, scaling="weak", images_total=32)),
+                        (["--images", "64", "--warmup", "2"], dict(steps=8, scaling="strong"))):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--plumbing-only"] + extra,
+                           capture_output=True, text=True, timeout=300, env=env, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["backend"] == "gloo" and line["gathered_scores"] == 3
+        assert abs(line["max_time"] - 0.002) < 1e-9
+        for k, v in want.items():
+            assert line[k] == v, (k, line)
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--plumbing-only", "--images", "30"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert bad.returncode != 0                         # 30 images do not split into 2 ranks x batches of 4

@@ -59,9 +59,25 @@ def test_tta_forward_matches_host_pipeline(setup):
     assert float((tr["X"].cpu() - X).abs().max()) <= 2e-3 * max(1.0, float(X.abs().max()))
     otr = {}
     p = dict(cpu.multi_matching_unsup.named_parameters())
-    og.mgm3_unsup_forward(p, nodes, labels, cpu.multi_matching_sup.U, trace=otr)
-    assert float((tr["Wds"].cpu() - otr["Wds"]).abs().max()) <= 2e-2     # Sinkhorn at tau=.05 amplifies the feature noise 20x
+    ref_nodes = [x.detach().clone().requires_grad_() for x in nodes]
+    ref_loss = og.mgm3_unsup_forward(p, ref_nodes, labels, cpu.multi_matching_sup.U, trace=otr)
+    ref_loss.backward()
     assert torch.isfinite(loss) and float(loss) > 0
+    # the vendor convolutions differ from the host's by ~1e-3 (summation order), so the matching operators are compared on
+    # IDENTICAL inputs: the host's node features go through the device module -> Wds / U0 / V0 <= 1e-4, loss and gradients
+    # <= 1e-4 with the host run's pseudo-labels supplied
+    m = gpu.multi_matching_unsup
+    dn = [x.detach().to("cuda:0").requires_grad_() for x in nodes]
+    dl = [l.to("cuda:0") for l in labels]
+    tr2 = {}
+    l2 = m(dn, dl, gpu.multi_matching_sup.U, trace=tr2, forced_U=otr["Ub"].to("cuda:0"))
+    l2.backward()
+    m.zero_grad()
+    assert float((tr2["Wds"].cpu() - otr["Wds"]).abs().max()) <= 1e-4
+    assert float((tr2["U0"].cpu() - otr["U0"]).abs().max()) <= 1e-4 * max(1.0, float(otr["U0"].abs().max()))
+    assert abs(float(l2.detach()) - float(ref_loss.detach())) <= 1e-4
+    for a, b in zip(dn, ref_nodes):
+        assert float((a.grad.cpu() - b.grad).abs().max()) <= 1e-4
 
 
 def test_tta_step_updates_exactly_the_reference_parameter_set(setup):
@@ -312,7 +328,9 @@ def test_sync_universe_step_equals_single_process_step():
         assert abs(c["loss"] - c["loss_single_process"]) <= 1e-5 * max(1.0, abs(c["loss_single_process"])), c
         assert c["max_param_update"] > 1e-6, c                                  # the step did move the weights
         # split: the vendor's convolution backward on 2 + 2 images vs on 4 (different algorithm, ~1 % on single elements)
-        assert c["max_param_diff_vs_single_process"] <= (0.03 if name == "split" else 1e-3) * c["max_param_update"] + 2e-8, c
+        # + 2 ulp of an O(1) fp32 parameter (the vendor's convolution backward is not run-to-run deterministic: a 1-ulp
+        # difference in p - lr * buf is 6e-8 whatever the size of the update)
+        assert c["max_param_diff_vs_single_process"] <= (0.03 if name == "split" else 1e-3) * c["max_param_update"] + 1.2e-7, c
 
 
 def test_train_net_eval_only_on_coco_json(tmp_path):

@@ -29,7 +29,7 @@ def maxerr(a, b):
     return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64)))) if a.size else 0.0
 
 
-def derived_gate(what, dev_val, ref32, truth64, scale=1.0, factor=2.0):
+def derived_gate(what, dev_val, ref32, truth64, scale=1.0, factor=2.0, quiet=False):
     """Where the 1e-4 bar is below what fp32 arithmetic can deliver (log-domain magnitudes of 1/tau = 20..160 times the
     input, iterated maps), the gate is DERIVED, not chosen: `truth64` is the same oracle computation in float64 on the same
     fp32 inputs, e_ref = |fp32 oracle - truth| is what the reference's own fp32 path loses, and the device must stay within
@@ -38,9 +38,18 @@ def derived_gate(what, dev_val, ref32, truth64, scale=1.0, factor=2.0):
     e_ref = float((ref32.detach().cpu().double() - t).abs().max())
     e_dev = float((dev_val.detach().cpu().double() - t).abs().max())
     bound = max(TOL * scale, factor * e_ref)
-    print("%s: device vs fp64 truth %.3e, fp32 oracle vs fp64 truth %.3e, gate %.3e" % (what, e_dev, e_ref, bound))
+    if not quiet:
+        print("%s: device vs fp64 truth %.3e, fp32 oracle vs fp64 truth %.3e, gate %.3e" % (what, e_dev, e_ref, bound))
     assert e_dev <= bound, (what, e_dev, e_ref, bound)
     return e_dev, e_ref
+
+
+def planted_gold(golden, name):
+    """mgm3.npz holds the planted cases of up to 32 nodes per graph, mgm3_big.npz the ones where the kernels branch."""
+    return golden("mgm3_big" if name.startswith("pb_") else "mgm3")
+
+
+ALL_PLANTED = cases.PLANTED_CASES + cases.PLANTED_BIG_CASES
 
 
 def check_pgrad(gold, key, g, tol):
@@ -79,7 +88,8 @@ def test_linear_autograd(dev):
     y.square().sum().backward()
     xr, Wr, br = (t.detach().clone().requires_grad_() for t in (x, W, b))
     torch.nn.functional.linear(xr, Wr, br).square().sum().backward()
-    assert maxerr(x.grad, xr.grad) <= 5e-3 and maxerr(W.grad, Wr.grad) <= 5e-3 and maxerr(b.grad, br.grad) <= 5e-3
+    for got, ref in ((x.grad, xr.grad), (W.grad, Wr.grad), (b.grad, br.grad)):       # sums of 45..512 products of O(10) terms
+        assert maxerr(got, ref) <= 2e-5 * float(ref.abs().max())
 
 
 # ------------------------------------------------------------------------------------------- A4
@@ -217,7 +227,7 @@ def test_sinkhorn_differentiable_vs_autograd_through_the_oracle(dev, b, r, c, du
     if n1 is None:
         s64 = s.double().requires_grad_()
         (osk(s64, dummy_row=dummy, max_iter=20, tau=tau, batched_operation=True) * w.double()).sum().backward()
-        derived_gate("sinkhorn bwd (%d,%d,%d) tau %g" % (b, r, c, tau), sd.grad, sr.grad, s64.grad, scale=float(s64.grad.abs().max()))
+        derived_gate("sinkhorn bwd (%d,%d,%d) tau %g" % (b, r, c, tau), sd.grad, sr.grad, s64.grad)
     else:
         # autograd through the unrolled batched spec turns the -inf padding of a ragged batch into NaN gradients
         # (0 * inf in the logsumexp backward), so every matrix is checked against its own stand-alone problem instead
@@ -227,7 +237,7 @@ def test_sinkhorn_differentiable_vs_autograd_through_the_oracle(dev, b, r, c, du
             (osk(si, dummy_row=dummy, max_iter=20, tau=tau) * w[i, :n]).sum().backward()
             s64 = s[i, :n].double().requires_grad_()
             (osk(s64, dummy_row=dummy, max_iter=20, tau=tau) * w[i, :n].double()).sum().backward()
-            derived_gate("ragged sinkhorn bwd %d" % i, sd.grad[i, :n], si.grad, s64.grad, scale=float(s64.grad.abs().max()))
+            derived_gate("ragged sinkhorn bwd %d" % i, sd.grad[i, :n], si.grad, s64.grad)
             assert float(sd.grad[i, n:].abs().max()) == 0 if n < r else True
 
 
@@ -293,7 +303,7 @@ def test_pair_sinkhorn_forward_backward(dev, sizes, ks):
     for a in range(G):
         for b in range(a):
             low[off[a]:off[a + 1], off[b]:off[b + 1]] = 1
-    derived_gate("pair sinkhorn bwd %s" % (sizes,), dM.cpu() * low, Mr.grad * low, M64.grad * low, scale=float(M64.grad.abs().max()))
+    derived_gate("pair sinkhorn bwd %s" % (sizes,), dM.cpu() * low, Mr.grad * low, M64.grad * low)
 
 
 # ------------------------------------------------------------------------------------------- A7
@@ -397,7 +407,7 @@ def test_gagm_one_step_map_along_oracle_trajectory(dev, name, sizes, seed):
     from ttdg_mgm_amd import ops
     A, W, U0 = cases.gagm_inputs(sizes, seed)
     ap, Wd, gr = _pack(A, sizes).to(dev), W.to(dev), ops.graphs(sizes)
-    nh = 0
+    nh, worst = 0, (0.0, 0.0)
     for proj, tau, Ut, Unext, V in _oracle_trajectory(A, W, U0, sizes):
         Ug, Vg = ops.gagm_one_step(ap, Wd, Ut.to(dev), gr, list(sizes), None if proj == "hungarian" else tau)
         scale = max(1.0, float(V.abs().max()))
@@ -420,16 +430,20 @@ def test_gagm_one_step_map_along_oracle_trajectory(dev, name, sizes, seed):
             U64 = og._project_sinkhorn(V64, list(sizes), 32, tau, 20)
             if len(sizes) == 2:
                 U64[:sizes[0]] = torch.eye(sizes[0], 32, dtype=torch.float64)
-            derived_gate("%s one step tau %g" % (name, tau), Ug, Unext, U64)
+            worst = max(worst, derived_gate("%s one step tau %g" % (name, tau), Ug, Unext, U64, quiet=True))
+    print("%s: Sinkhorn-projector steps, worst (device vs fp64 truth, fp32 oracle vs fp64 truth) = (%.3e, %.3e), gate 1e-4" % ((name,) + worst))
     assert nh >= 1
 
 
-@pytest.mark.parametrize("name,sizes,seed", cases.PLANTED_CASES)
+@pytest.mark.parametrize("name,sizes,seed", ALL_PLANTED)
 def test_gagm_planted_identical_permutations(dev, golden, name, sizes, seed):
-    """Full solve on the solver inputs of a planted case (A, Wds, U0 from the oracle's front end)."""
+    """Full solve on the solver inputs of a planted case (A, Wds, U0 from the oracle's front end).  The pb_* cases cover
+    every solver branch against the REFERENCE's permutations: n_g > 32 (transposed Sinkhorn orientation), 64 < n_g <= 128
+    (two LAP columns per lane, LDS cost matrix), the multi-workgroup solver (a graph above 128 nodes; >= 320 nodes in
+    total), G = 2 with n > 32."""
     from oracle import gmodule as og
     from ttdg_mgm_amd.GModule.multi_graph_matching import GA_GM
-    gold = golden("mgm3")
+    gold = planted_gold(golden, name)
     params, nodes, labels, U, _ = cases.mgm_inputs(name)
     otr = {}
     og.mgm3_unsup_forward(params, nodes, labels, U, trace=otr)
@@ -534,10 +548,10 @@ def _check_against_gold(gold, name, m, dn, loss):
             check_pgrad(gold, f"{name}_d_{k}", p.grad, TOL)
 
 
-@pytest.mark.parametrize("name", [c[0] for c in cases.PLANTED_CASES])
+@pytest.mark.parametrize("name", [c[0] for c in ALL_PLANTED])
 def test_mgm3_end_to_end_planted_golden(dev, golden, name):
     """Free-running: node features -> loss, gradients and the permutation matrices, all against the reference."""
-    gold = golden("mgm3")
+    gold = planted_gold(golden, name)
     m, dn, loss, tr = _run_mgm3(dev, name)
     print(name, "gagm iterations", tr["info"].cpu().tolist()[:7], "loss", float(loss), "ref", float(gold[f"{name}_loss"]))
     assert np.array_equal(tr["Ub"].cpu().numpy(), gold[f"{name}_U"]), "permutation matrices differ from the reference"
@@ -553,7 +567,7 @@ def test_mgm3_end_to_end_random_teacher_forced(dev, golden, name):
     _check_against_gold(gold, name, m, dn, loss)
 
 
-@pytest.mark.parametrize("name", [c[0] for c in cases.MGM_CASES + cases.PLANTED_CASES])
+@pytest.mark.parametrize("name", [c[0] for c in cases.MGM_CASES + ALL_PLANTED])
 def test_mgm3_intermediates_vs_oracle(dev, name):
     from oracle import gmodule as og
     from ttdg_mgm_amd.GModule import MGM3_unsup
@@ -569,7 +583,7 @@ def test_mgm3_intermediates_vs_oracle(dev, name):
     assert maxerr(tr["U0"], otr["U0"]) <= TOL * max(1.0, float(otr["U0"].abs().max()))
     assert maxerr(tr["V0"], otr["V0"]) <= TOL * max(1.0, float(otr["V0"].abs().max()))
     assert maxerr(tr["apack"], _pack(otr["A"], sizes)) <= 1e-5
-    if name in [c[0] for c in cases.PLANTED_CASES]:
+    if name in [c[0] for c in ALL_PLANTED]:
         assert torch.equal(tr["Ub"].cpu(), otr["Ub"])
         it = tr["info"].cpu().tolist()
         assert it[:5] == otr["iters"][:5] and abs(it[5] - otr["iters"][5]) <= 1
@@ -706,7 +720,8 @@ def test_large_solver_matches_host_driven_statement(dev, sizes, seed):
     """Graphs above 128 nodes, or many small graphs with >= 320 nodes in total (the gathered multi-graph of Mode S): the native multi-workgroup solver (two launches per iteration, stage machine on the device)
     against the host-driven statement of the same schedule on the stand-alone operators (one host decision per
     iteration).  (1) from every state of the host-driven trajectory one native iteration gives the same V and the same
-    projection (Sinkhorn <= 1e-4 / 5e-3 below tau 0.05, Hungarian identical or equal LAP value); (2) free-running: same
+    projection (Sinkhorn projector: both statements within 1e-4 of the float64 statement of the step, Hungarian identical or
+    equal LAP value); (2) free-running: same
     iteration count for every stage up to the first one that hits the 200-iteration cap (a capped stage is the
     rounding-chaotic regime of DESIGN.md §4), and identical permutations when no stage is capped."""
     from ttdg_mgm_amd import ops
@@ -738,12 +753,22 @@ def test_large_solver_matches_host_driven_statement(dev, sizes, seed):
     # one native iteration from sampled states of the host-driven trajectory
     step = max(1, len(states) // 12)
     picked = states[::step] + [st for st in states if st[0]][:4]
+    from oracle import gmodule as og
+    Ad, Wdd, worst = A.double(), W.double(), (0.0, 0.0)
     for hung, tau, Ub, Ua, V in picked:
         Ug, Vg = ops.gagm_one_step(ap, Wd, Ub.contiguous(), gr, list(sizes), None if hung else tau)
         scale = max(1.0, float(V.abs().max()))
         assert maxerr(Vg, V) <= TOL * scale
         if not hung:
-            assert maxerr(Ug, Ua) <= (TOL if tau >= 0.05 else 5e-3), tau
+            # exact (float64) statement of the step from the same fp32 state; native and host-driven results both within 1e-4
+            Ud = Ub.double().cpu()
+            B64 = Ad @ Ud
+            V64 = (B64 @ (Ud.t() @ B64) + Wdd @ Ud) / len(sizes)
+            U64 = og._project_sinkhorn(V64, list(sizes), 32, tau, 20)
+            if len(sizes) == 2:
+                U64[:sizes[0]] = torch.eye(sizes[0], 32, dtype=torch.float64)
+            worst = max(worst, derived_gate("large one step tau %g" % tau, Ug, Ua, U64, quiet=True))
+            assert maxerr(Ua, U64.float()) <= TOL
         elif not torch.equal(Ug, Ua):
             o = 0
             for n in sizes:
@@ -752,6 +777,7 @@ def test_large_solver_matches_host_driven_statement(dev, sizes, seed):
                 r2, c2 = np.nonzero(Ug[o:o + n].cpu().numpy())
                 assert abs(v[r1, c1].sum() - v[r2, c2].sum()) <= 1e-5 * scale, "LAP value gap"
                 o += n
+    print(sizes, "Sinkhorn-projector steps: worst (native, host-driven) deviation from the fp64 statement = (%.3e, %.3e)" % worst)
 
 
 def test_cfg3_scale_front_end_and_large_solver(dev):
@@ -948,7 +974,13 @@ def test_hippi_golden(dev, golden, name, sizes, seed, proj):
     ref = gold[f"hippi_{name}_V0"]
     assert maxerr(V0, ref) <= 1e-5 * float(np.abs(ref).max())
     U = h(W.to(dev), U0.to(dev), torch.tensor(sizes), 32, projector=proj)
-    assert maxerr(U, gold[f"hippi_{name}_U"]) <= (0.0 if proj == "hungarian" else 2e-3), h.last_iters
+    if proj == "hungarian":
+        assert maxerr(U, gold[f"hippi_{name}_U"]) == 0.0, h.last_iters
+    else:
+        # up to 50 projected power iterations at tau = 1/200: gate derived from the float64 run of the same iteration
+        from oracle import gmodule as og
+        U64 = og.hippi(W.double(), U0.double(), sizes, 32, projector=proj)
+        derived_gate("HiPPI %s (%d iterations)" % (name, h.last_iters), U, torch.from_numpy(gold[f"hippi_{name}_U"]), U64)
 
 
 @pytest.mark.parametrize("sizes,seed", [((22, 30, 26, 19), 1), ((40, 12, 33), 2), ((32, 32), 3), ((5,), 4)])

@@ -139,3 +139,70 @@ def test_dense_and_list_inference_agree_on_the_host_backend():
         assert len(ia) == len(ib) > 0
         assert torch.equal(ia.pred_boxes.tensor, ib.pred_boxes.tensor) and torch.equal(ia.scores, ib.scores)
         assert torch.equal(ia.pred_classes, ib.pred_classes) and torch.equal(ia.pred_masks, ib.pred_masks)
+
+
+def test_synth_checkpoint_training_helpers():
+    """tools/synth_checkpoint.py (measurement infrastructure): the differentiable ROIAlign agrees with the oracle's ROIAlign
+    where the adaptive sampling ratio is 2, box deltas invert detectron2's apply_deltas, gradients reach the features."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import synth_checkpoint as sc
+    from oracle import detection as od
+    from ttdg_mgm_amd.modeling.detector import apply_deltas
+    g = synth.gen(5150)
+    f = synth.normal(g, (2, 6, 40, 40)).requires_grad_()
+    # 7 x 7 bins of 1 < size <= 2 feature pixels -> the adaptive sampling ratio of ROIAlign is 2
+    rois = torch.tensor([[0, 16.0, 20.0, 16 + 8 * 12.5, 20 + 8 * 9.0], [1, 40.0, 8.0, 40 + 8 * 10.0, 8 + 8 * 13.0]])
+    got = sc.roi_align_torch([f], rois, (8,), 7, sr=2, canonical_size=1e-3, min_level=2, canonical_level=2)
+    ref = od.roi_align(f.detach(), rois, 1.0 / 8, 7)
+    assert float((got - ref).abs().max()) <= 1e-5
+    got.square().sum().backward()
+    assert float(f.grad.abs().sum()) > 0
+    src = torch.tensor([[10.0, 12.0, 50.0, 70.0], [5.0, 5.0, 9.0, 30.0]])
+    tgt = torch.tensor([[12.0, 10.0, 55.0, 61.0], [4.0, 6.0, 12.0, 28.0]])
+    w = (10.0, 10.0, 5.0, 5.0)
+    assert float((apply_deltas(sc.get_deltas(src, tgt, w), src, w) - tgt).abs().max()) <= 1e-4
+    assert abs(float(sc.box_iou(src[:1], src[:1])) - 1.0) <= 1e-6
+
+
+def test_streaming_loader_equals_resident_loader():
+    """TestLoader(resident=False): batch-by-batch decode / resize with a bounded prefetch thread gives exactly the items of
+    the resident loader, on every pass, and the lazy DiceEvaluator reads the ground truth each item carries."""
+    cfg = get_cfg()
+    cfg.TEST.BATCH = 3
+    cfg.INPUT.MIN_SIZE_TEST = 96
+    data.register_synthetic("stream_ds", 7, size=64, id_offset=100)
+    res = data.build_detection_test_loader(cfg, "stream_ds", 0, 1, None, resident=True)
+    stm = data.build_detection_test_loader(cfg, "stream_ds", 0, 1, None, resident=False)
+    assert len(res) == len(stm) == 3 and stm.items is None
+    for _ in range(2):                                  # the reference iterates the loader twice per dataset
+        a, b = list(res), list(stm)
+        assert [len(x) for x in a] == [len(x) for x in b] == [3, 3, 1]
+        for ba, bb in zip(a, b):
+            for ia, ib in zip(ba, bb):
+                assert ia["image_id"] == ib["image_id"] >= 100 and torch.equal(ia["image"], ib["image"]) and torch.equal(ia["tf_boxes"], ib["tf_boxes"])
+    from ttdg_mgm_amd.modeling.structures import Boxes, Instances
+    ev = DiceEvaluator("stream_ds", 0.9, lazy=True)
+    assert ev.dataset_dicts is None
+    batch = next(iter(stm))
+    outs = []
+    for it in batch:
+        gm = torch.stack([a["mask"] for a in it["dataset_dict"]["annotations"]])
+        outs.append({"instances": Instances((64, 64), pred_boxes=Boxes(torch.zeros(2, 4)), scores=torch.tensor([0.95, 0.99]),
+                                            pred_classes=torch.tensor([0, 1]), pred_masks=gm)})
+    ev.process(batch, outs)
+    assert abs(ev.evaluate()["Dice Coefficient"] - 100.0) < 1e-3 and len(ev.dice_scores) == 6
+
+
+def test_config_rejects_unsupported_architecture_keys(tmp_path):
+    cfg = get_cfg()
+    p = tmp_path / "bad.yaml"
+    p.write_text("MODEL:\n  RESNETS:\n    DEPTH: 101\n")
+    with pytest.raises(ValueError):
+        cfg.merge_from_file(str(p))
+    good = tmp_path / "good.yaml"
+    good.write_text("MODEL:\n  RESNETS:\n    DEPTH: 50\n    OUT_FEATURES: [\"res2\", \"res3\", \"res4\", \"res5\"]\n  ROI_BOX_HEAD:\n    NUM_FC: 2\nTEST:\n  BATCH: 4\n")
+    cfg.merge_from_file(str(good))
+    assert cfg.TEST.BATCH == 4 and cfg.TEST.EVAL_STU is False          # add_ateacher_config default (reference config.py:11)
+    assert get_cfg().TEST.BATCH == 1                                    # reference default (config.py:16)

@@ -128,10 +128,10 @@ def test_prototype_computation(golden, ci):
         close(l, gold[f"{name}_labels{gi}"], 0)
 
 
-@pytest.mark.parametrize("name", [c[0] for c in cases.PLANTED_CASES])
+@pytest.mark.parametrize("name", [c[0] for c in cases.PLANTED_CASES + cases.PLANTED_BIG_CASES])
 def test_mgm3_planted_cases(golden, name):
     """Trained-like planted cases: the reference converges and is rounding-stable, so U itself is golden."""
-    gold = golden("mgm3")
+    gold = golden("mgm3_big" if name.startswith("pb_") else "mgm3")
     params, nodes, labels, U, sizes = cases.mgm_inputs(name)
     p = {k: v.clone().requires_grad_() for k, v in params.items()}
     nodes = [x.requires_grad_() for x in nodes]

@@ -1,0 +1,481 @@
+"""Deterministic "trained-regime" checkpoint for the synthetic benchmarks — MEASUREMENT INFRASTRUCTURE, not product.
+
+The reference is evaluated on trained checkpoints (README.md:92, configs/test_segment.yaml:7); none can be obtained
+offline, and with random weights nothing clears ``TEST.DICE_THRES`` 0.9 (Dice is NaN) and the matching solver sits in the
+rounding-chaotic regime of DESIGN.md §4.  This tool fits the Mask R-CNN stand-in on a synthetic fundus SOURCE stream
+(seeds disjoint from every test stream) so that bench.py / the e2e tests measure the path where the reference runs it:
+
+  stage 1  supervised source training (reference rcnn.py:229-268, the part its BaselineTrainer.run_step drives):
+           RPN + ROI box + mask losses written out in plain torch below (detectron2's formulation [3P]: IoU matcher
+           0.3 / 0.7 with low-quality matches, 256 anchors per image, 512 ROIs per image at 25 % foreground, L1 box loss,
+           per-class mask BCE) with a differentiable ROIAlign (grid_sample), plus the reference's own matching term
+           ``loss_matching = U_sup(nodes, labels)`` on nodes sampled inside the GT boxes (rcnn.py:262-266) - that is what
+           learns the universe ``U``;
+  stage 2  a short continual-TTA warm start on the source stream (the reference's own test loop, trainer.py:469-482):
+           ``multi_matching_unsup.node_affinity`` is never touched by source training in the reference (rcnn.py:264-266
+           only calls ``multi_matching_sup``), it is learned by the adaptation steps themselves; the warm start stands
+           for the datasets a continual run has already seen (model and optimizer state carry over, trainer.py:452).
+
+Everything is seeded; the result is cached by a hash of this file and its arguments (the GPU boxes are fresh, so
+bench.py usually rebuilds it: about a minute)."""
+import hashlib
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SOURCE_CFG_ID = 7            # seeds 7000 + i: disjoint from cfg-1..5 streams (1000 * cfg_id + i)
+
+
+# ------------------------------------------------------------------------------------------- box utilities
+def box_iou(a, b):
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    lt = torch.maximum(a[:, None, :2], b[None, :, :2])
+    rb = torch.minimum(a[:, None, 2:], b[None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    return inter / (area_a[:, None] + area_b[None, :] - inter).clamp(min=1e-9)
+
+
+def get_deltas(src, tgt, weights):
+    """detectron2 Box2BoxTransform.get_deltas [3P]."""
+    sw, sh = src[:, 2] - src[:, 0], src[:, 3] - src[:, 1]
+    sx, sy = src[:, 0] + 0.5 * sw, src[:, 1] + 0.5 * sh
+    tw, th = tgt[:, 2] - tgt[:, 0], tgt[:, 3] - tgt[:, 1]
+    tx, ty = tgt[:, 0] + 0.5 * tw, tgt[:, 1] + 0.5 * th
+    wx, wy, ww, wh = weights
+    return torch.stack((wx * (tx - sx) / sw, wy * (ty - sy) / sh, ww * torch.log(tw / sw), wh * torch.log(th / sh)), dim=1)
+
+
+def roi_align_torch(feats, rois, strides, P, sr=2, canonical_size=224, canonical_level=4, min_level=2):
+    """Differentiable ROIAlign (aligned=True) + ROIPooler level assignment in plain torch: every ROI samples P*sr x P*sr
+    bilinear points from its level (grid_sample), averaged over sr x sr.  Training-side only: the product path uses the
+    forward-only HIP kernel (csrc/detection.hip)."""
+    R = rois.shape[0]
+    C = feats[0].shape[1]
+    out = feats[0].new_zeros((R, C, P, P))
+    if R == 0:
+        return out
+    area = ((rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2])).clamp(min=0)
+    lvl = torch.floor(canonical_level + torch.log2(torch.sqrt(area) / canonical_size + 1e-8))
+    lvl = lvl.clamp(min_level, min_level + len(feats) - 1).long() - min_level
+    img = rois[:, 0].long()
+    S = P * sr
+    t = (torch.arange(S, device=rois.device, dtype=torch.float32) + 0.5) / S
+    for l, (f, stride) in enumerate(zip(feats, strides)):
+        H, W = f.shape[-2:]
+        for b in range(f.shape[0]):
+            idx = torch.nonzero((lvl == l) & (img == b)).squeeze(1)
+            if idx.numel() == 0:
+                continue
+            bx = rois[idx, 1:] / stride - 0.5
+            xs = bx[:, 0:1] + t[None, :] * (bx[:, 2:3] - bx[:, 0:1])            # (r, S) pixel-index coordinates
+            ys = bx[:, 1:2] + t[None, :] * (bx[:, 3:4] - bx[:, 1:2])
+            gx = (2 * xs + 1) / W - 1
+            gy = (2 * ys + 1) / H - 1
+            grid = torch.stack((gx[:, None, :].expand(-1, S, -1), gy[:, :, None].expand(-1, -1, S)), dim=-1)      # (r, S, S, 2)
+            smp = F.grid_sample(f[b:b + 1], grid.reshape(1, -1, S, 2), mode="bilinear", padding_mode="border", align_corners=False)
+            smp = smp.view(C, idx.numel(), P, sr, P, sr).mean(dim=(3, 5)).permute(1, 0, 2, 3)
+            out = out.index_put((idx,), smp)
+    return out
+
+
+def _sample(labels, num, pos_frac, gen):
+    pos = torch.nonzero(labels == 1).squeeze(1)
+    neg = torch.nonzero(labels == 0).squeeze(1)
+    npos = min(pos.numel(), int(num * pos_frac))
+    nneg = min(neg.numel(), num - npos)
+    pp = pos[torch.randperm(pos.numel(), generator=gen, device=labels.device)[:npos]]
+    nn_ = neg[torch.randperm(neg.numel(), generator=gen, device=labels.device)[:nneg]]
+    return pp, nn_
+
+
+# ------------------------------------------------------------------------------------------- detector losses
+def rpn_losses(rpn, features, gts, gen, batch_per_image=256, pos_frac=0.5):
+    """detectron2 RPN.losses [3P]: objectness BCE + L1 box regression on 256 sampled anchors per image."""
+    feats = [features[f] for f in rpn.in_features]
+    logits, deltas = rpn.rpn_head(feats)
+    dev = feats[0].device
+    anchors = torch.cat(rpn._anchors([f.shape[-2:] for f in feats], dev))
+    N = feats[0].shape[0]
+    lg = torch.cat([l.permute(0, 2, 3, 1).reshape(N, -1) for l in logits], dim=1)
+    dl = torch.cat([d.view(N, -1, 4, d.shape[-2], d.shape[-1]).permute(0, 3, 4, 1, 2).reshape(N, -1, 4) for d in deltas], dim=1)
+    loss_cls = lg.new_zeros(())
+    loss_loc = lg.new_zeros(())
+    for n, gt in enumerate(gts):
+        iou = box_iou(gt["boxes"], anchors)
+        mx, arg = iou.max(0)
+        lab = torch.full_like(mx, -1, dtype=torch.int64)
+        lab[mx < 0.3] = 0
+        lab[mx >= 0.7] = 1
+        lab[(iou == iou.max(1, keepdim=True).values).any(0)] = 1            # low-quality matches: every GT gets its best anchors
+        pos, neg = _sample(lab, batch_per_image, pos_frac, gen)
+        sel = torch.cat((pos, neg))
+        tgt = torch.cat((torch.ones(pos.numel(), device=dev), torch.zeros(neg.numel(), device=dev)))
+        loss_cls = loss_cls + F.binary_cross_entropy_with_logits(lg[n, sel], tgt, reduction="sum")
+        if pos.numel():
+            loss_loc = loss_loc + (dl[n, pos] - get_deltas(anchors[pos], gt["boxes"][arg[pos]], (1.0, 1.0, 1.0, 1.0))).abs().sum()
+    norm = N * batch_per_image
+    return loss_cls / norm, loss_loc / norm
+
+
+def roi_losses(roi, features, proposals, gts, gen, batch_per_image=512, pos_frac=0.25):
+    """detectron2 StandardROIHeads losses [3P] (box classification + class-specific L1 regression + mask BCE)."""
+    C = roi.num_classes
+    dev = proposals[0].device
+    rois, cls_t, box_t, fg_rows, gt_of = [], [], [], [], []
+    start = 0
+    for n, (pr, gt) in enumerate(zip(proposals, gts)):
+        pr = torch.cat((pr, gt["boxes"]))                                     # proposal_append_gt
+        iou = box_iou(gt["boxes"], pr)
+        mx, arg = iou.max(0)
+        lab = (mx >= 0.5).long()
+        pos, neg = _sample(lab, batch_per_image, pos_frac, gen)
+        sel = torch.cat((pos, neg))
+        c = torch.cat((gt["classes"][arg[pos]], torch.full((neg.numel(),), C, device=dev, dtype=torch.int64)))
+        rois.append(torch.cat((pr.new_full((sel.numel(), 1), float(n)), pr[sel]), 1))
+        cls_t.append(c)
+        box_t.append(gt["boxes"][arg[pos]])
+        fg_rows.append(torch.arange(pos.numel(), device=dev) + start)
+        gt_of.append((n, arg[pos]))
+        start += sel.numel()
+    rois, cls_t = torch.cat(rois), torch.cat(cls_t)
+    fg = torch.cat(fg_rows)
+    feats = [features[f] for f in roi.box_in_features]
+    logits, deltas = roi.box_predictor(roi.box_head(roi_align_torch(feats, rois, (4, 8, 16, 32), 7)))
+    loss_cls = F.cross_entropy(logits, cls_t)
+    tgt = get_deltas(rois[fg, 1:], torch.cat(box_t), roi.bbox_weights)
+    pred = deltas.view(-1, C, 4)[fg, cls_t[fg]]
+    loss_box = (pred - tgt).abs().sum() / max(1, cls_t.numel())
+    # mask head on the foreground ROIs; target = GT bitmap cropped to the ROI at 28 x 28 (bilinear, >= 0.5)
+    mlogits = roi.mask_head(roi_align_torch(feats, rois[fg], (4, 8, 16, 32), 14))
+    S = mlogits.shape[-1]
+    t = (torch.arange(S, device=dev, dtype=torch.float32) + 0.5) / S
+    targets = []
+    row = 0
+    for (n, gidx), gt in zip(gt_of, gts):
+        k = gidx.numel()
+        if k == 0:
+            continue
+        sx, sy = gt["scale"]
+        bx = rois[fg[row:row + k], 1:] / torch.tensor([sx, sy, sx, sy], device=dev)          # original-image coordinates
+        row += k
+        H, W = gt["masks"].shape[-2:]
+        xs = bx[:, 0:1] + t[None] * (bx[:, 2:3] - bx[:, 0:1]) - 0.5
+        ys = bx[:, 1:2] + t[None] * (bx[:, 3:4] - bx[:, 1:2]) - 0.5
+        grid = torch.stack((((2 * xs + 1) / W - 1)[:, None, :].expand(-1, S, -1), ((2 * ys + 1) / H - 1)[:, :, None].expand(-1, -1, S)), -1)
+        smp = F.grid_sample(gt["masks"][None], grid.reshape(1, -1, S, 2), mode="bilinear", padding_mode="zeros", align_corners=False)
+        smp = smp.view(gt["masks"].shape[0], k, S, S)
+        targets.append((smp[gidx, torch.arange(k, device=dev)] >= 0.5).float())
+    if targets:
+        loss_mask = F.binary_cross_entropy_with_logits(mlogits[torch.arange(fg.numel(), device=dev), cls_t[fg]], torch.cat(targets))
+    else:
+        loss_mask = mlogits.sum() * 0
+    return loss_cls, loss_box, loss_mask
+
+
+# ------------------------------------------------------------------------------------------- universe labels
+class UniverseLabels:
+    """Supervised multi-graph-matching labels for the synthetic source stream.  Every graph node is an FPN point inside a
+    ground-truth box (build_graph.py:160-250); its descriptor is (class, FPN level, position inside its box).  A 32-point
+    universe is fitted to the descriptors of the whole source stream (k-means, farthest-point start, fixed order), and the
+    nodes of every graph are assigned one-to-one to universe points (LAP on squared distance).  The assignment U_g plays
+    the role the reference gives to the pseudo-labels of its solver: pairwise ground truth U_a U_b^T
+    (multi_graph_matching.py:629) - cycle-consistent by construction - and the target of the universe loss (:156-158)."""
+
+    W_CLASS, W_LEVEL, W_POS = 4.0, 2.0, 1.5
+
+    def __init__(self, pc, shapes, device, univ=32):
+        from ttdg_mgm_amd import ops
+        self.pc, self.shapes, self.dev, self.univ = pc, shapes, device, univ
+        self.lv = ops.levels_desc(shapes, pc.strides[:len(shapes)], pc.object_sizes_of_interest[:len(shapes)])
+        self.npts = sum(h * w for h, w in shapes)
+        self.centres = None
+        self._cache = {}
+
+    def descriptors(self, gts):
+        """-> per image: (n, 4) float64 descriptors in the node order of PrototypeComputation."""
+        import numpy as np
+        from ttdg_mgm_amd import ops
+        pc = self.pc
+        B, kmax = len(gts), max(len(g["classes"]) for g in gts)
+        boxes = torch.zeros(B, kmax, 4, device=self.dev)
+        classes = torch.zeros(B, kmax, device=self.dev, dtype=torch.int32)
+        for k, g in enumerate(gts):
+            boxes[k, :len(g["classes"])] = g["boxes"]
+            classes[k, :len(g["classes"])] = g["classes"].to(torch.int32)
+        nbox = torch.tensor([len(g["classes"]) for g in gts], dtype=torch.int32, device=self.dev)
+        labels = ops.node_labels(boxes, classes, nbox, self.lv, self.npts)
+        cap = len(self.shapes) * (2 * pc.num_nodes_per_class - 1)
+        sel_idx, sel_lab, count = ops.node_select(labels, self.lv, pc.num_nodes_per_class, cap)
+        counts = count.tolist()
+        sel_idx, sel_lab = sel_idx.cpu().numpy(), sel_lab.cpu().numpy()
+        out = []
+        for k, g in enumerate(gts):
+            pid, lab = sel_idx[k, :counts[k]], sel_lab[k, :counts[k]]
+            lvl, loc = pid >> 28, pid & ((1 << 28) - 1)
+            w = np.array([self.shapes[l][1] for l in lvl])
+            st = np.array([pc.strides[l] for l in lvl])
+            x, y = (loc % w) * st + st // 2, (loc // w) * st + st // 2
+            bx = g["boxes"].cpu().numpy()
+            cls = g["classes"].cpu().numpy()
+            d = np.zeros((len(pid), 4))
+            for i in range(len(pid)):
+                cand = [j for j in range(len(cls)) if cls[j] + 1 == lab[i] and bx[j, 0] < x[i] < bx[j, 2] and bx[j, 1] < y[i] < bx[j, 3]]
+                j = min(cand, key=lambda j: (bx[j, 2] - bx[j, 0]) * (bx[j, 3] - bx[j, 1])) if cand else int(np.argmax(cls + 1 == lab[i]))
+                u, v = (x[i] - bx[j, 0]) / (bx[j, 2] - bx[j, 0]), (y[i] - bx[j, 1]) / (bx[j, 3] - bx[j, 1])
+                d[i] = (self.W_CLASS * lab[i], self.W_LEVEL * lvl[i], self.W_POS * u, self.W_POS * v)
+            out.append(d)
+        return out
+
+    def fit(self, all_gts, iters=25):
+        import numpy as np
+        D = np.concatenate([d for gts in all_gts for d in self.descriptors(gts)])
+        c = [D[0]]
+        for _ in range(self.univ - 1):                      # farthest-point start: deterministic, well spread
+            dist = np.min(((D[:, None, :] - np.array(c)[None]) ** 2).sum(-1), axis=1)
+            c.append(D[int(np.argmax(dist))])
+        c = np.array(c)
+        for _ in range(iters):
+            a = np.argmin(((D[:, None, :] - c[None]) ** 2).sum(-1), axis=1)
+            for k in range(self.univ):
+                if np.any(a == k):
+                    c[k] = D[a == k].mean(0)
+        self.centres = c
+        return self
+
+    def assign(self, key, gts):
+        """-> (U_gt (M, univ) on the device, sizes) for one batch; cached per batch key."""
+        import numpy as np
+        from scipy.optimize import linear_sum_assignment
+        if key not in self._cache:
+            rows, sizes = [], []
+            for d in self.descriptors(gts):
+                cost = ((d[:, None, :] - self.centres[None]) ** 2).sum(-1)
+                r, cidx = linear_sum_assignment(cost)
+                u = np.zeros((len(d), self.univ), np.float32)
+                u[r, cidx] = 1
+                rows.append(u)
+                sizes.append(len(d))
+            self._cache[key] = (torch.from_numpy(np.concatenate(rows)).to(self.dev), sizes)
+        return self._cache[key]
+
+
+# ------------------------------------------------------------------------------------------- training
+def _ground_truth(items, device):
+    out = []
+    for it in items:
+        d = it["dataset_dict"]
+        nh, nw = it["image"].shape[-2:]
+        sx, sy = nw / d["width"], nh / d["height"]
+        boxes = torch.stack([a["bbox"] for a in d["annotations"]]).float() * torch.tensor([sx, sy, sx, sy])
+        out.append(dict(boxes=boxes.to(device), classes=torch.tensor([a["category_id"] for a in d["annotations"]], dtype=torch.int64, device=device),
+                        masks=torch.stack([a["mask"] for a in d["annotations"]]).to(device).float(), scale=(sx, sy)))
+    return out
+
+
+def source_batches(cfg, n_images, size, device, name="synthfundus_source"):
+    from ttdg_mgm_amd import data
+    data.register_synthetic(name, n_images, size=size, cfg_id=SOURCE_CFG_ID)
+    return list(data.TestLoader(name, cfg.TEST.BATCH, 0, 1, device, cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST))
+
+
+def train_source(model, batches, steps, lr=0.01, warmup=50, matching_weight=1.0, seed=0, log=None, train_all=False,
+                 unsup_weight=10.0, rois_per_image=256):
+    """Stage 1.  SGD (momentum 0.9, wd 1e-4, linear warm-up, cosine decay), gradient-norm clip 10.
+    Matching terms on nodes sampled inside the GT boxes (rcnn.py:262-266): ``matching_weight`` x the universe loss of
+    ``multi_matching_sup`` (:136-169) and ``unsup_weight`` x the permutation loss of ``multi_matching_unsup`` (:560-564),
+    both against the universe labels of UniverseLabels instead of solver output."""
+    from ttdg_mgm_amd.modeling.structures import Boxes, Instances
+    dev = model.device
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    frozen = [p for p in model.parameters() if not p.requires_grad]
+    if train_all:
+        for p in frozen:
+            p.requires_grad_(True)
+    params = [p for n, p in model.named_parameters() if p.requires_grad and not n.startswith("D_img.")]
+    ulab = None
+    opt = torch.optim.SGD(params, lr=lr, momentum=0.9, weight_decay=1e-4)
+    model.train()
+    hist = []
+    t_start = time.perf_counter()
+    for step in range(steps):
+        items = batches[step % len(batches)]
+        gts = _ground_truth(items, dev)
+        f = min(1.0, (step + 1) / warmup) * 0.5 * (1 + math.cos(math.pi * step / steps))
+        for g in opt.param_groups:
+            g["lr"] = lr * f
+        images = model.preprocess_image(items)
+        features = model.backbone(images.tensor)
+        l_obj, l_loc = rpn_losses(model.proposal_generator, features, gts, gen)
+        with torch.no_grad():
+            boxes, scores, keep, counts = model.proposal_generator.forward_dense(features, images.image_sizes)
+            counts = counts.tolist()
+            props = [boxes[n, keep[n, :counts[n]]] for n in range(len(items))]
+        l_cls, l_box, l_mask = roi_losses(model.roi_heads, features, props, gts, gen, batch_per_image=rois_per_image)
+        loss = l_obj + l_loc + l_cls + l_box + l_mask
+        l_match = l_perm = None
+        if matching_weight > 0 or unsup_weight > 0:
+            feats = [features[k] for k in ("p2", "p3", "p4", "p5", "p6")]
+            if ulab is None:
+                ulab = UniverseLabels(model.graph_generator, [tuple(f.shape[-2:]) for f in feats], dev)
+                ulab.fit([_ground_truth(b, dev) for b in batches])
+            inst = [Instances(sz, gt_boxes=Boxes(g["boxes"]), gt_classes=g["classes"]) for g, sz in zip(gts, images.image_sizes)]
+            nodes, labels = model.graph_generator(feats, inst)
+            Ugt, sizes = ulab.assign(step % len(batches), gts)
+            assert sizes == [len(x) for x in nodes], (sizes, [len(x) for x in nodes])
+            if matching_weight > 0:
+                l_match = model.multi_matching_sup(nodes, labels, forced_target=Ugt)
+                loss = loss + matching_weight * l_match
+            if unsup_weight > 0:
+                l_perm = model.multi_matching_unsup(nodes, labels, model.multi_matching_sup.U, forced_U=Ugt)
+                loss = loss + unsup_weight * l_perm
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 10.0)
+        opt.step()
+        if log is not None and (step % 25 == 0 or step == steps - 1):
+            rec = dict(step=step, loss=float(loss.detach()), rpn_cls=float(l_obj.detach()), rpn_loc=float(l_loc.detach()), cls=float(l_cls.detach()), box=float(l_box.detach()),
+                       mask=float(l_mask.detach()), matching=None if l_match is None else float(l_match.detach()),
+                       perm=None if l_perm is None else float(l_perm.detach()))
+            hist.append(rec)
+            rec["t"] = round(time.perf_counter() - t_start, 1)
+            log("stage1 " + " ".join("%s=%s" % (k, ("%.4f" % v) if isinstance(v, float) else v) for k, v in rec.items()))
+    if train_all:
+        for p in frozen:
+            p.requires_grad_(False)
+    return hist
+
+
+def warm_tta(model, cfg, batches, steps, log=None):
+    """Stage 2: the reference's own adaptation loop on the source stream (free-running detections)."""
+    from ttdg_mgm_amd.engine import BaselineTrainer
+    opt = BaselineTrainer.build_optimizer(cfg, model)
+    model.train()
+    model.teacher_forced = False
+    stats = []
+    for step in range(steps):
+        tr = {}
+        model.multi_matching_unsup.keep_trace = True
+        loss = BaselineTrainer.tta_step(model, opt, batches[step % len(batches)])
+        info = model.multi_matching_unsup.last.get("info") if model.multi_matching_unsup.last else None
+        it = info.cpu().tolist()[:6] if info is not None else None
+        stats.append((None if loss is None else float(loss), it))
+        if log is not None and (step % 10 == 0 or step == steps - 1):
+            log("stage2 step %d loss %s solver iterations per stage %s" % (step, stats[-1][0], it))
+    model.multi_matching_unsup.keep_trace = False
+    model.multi_matching_unsup.last = None
+    return stats
+
+
+@torch.no_grad()
+def solver_regime(model, batches):
+    """Free-running TTT forwards (no step) on test batches: graph sizes and solver iterations per stage."""
+    model.train()
+    model.teacher_forced = False
+    m = model.multi_matching_unsup
+    m.keep_trace = True
+    out = []
+    for b in batches:
+        loss, _, _, _ = model(b, branch="TTT")
+        if loss is None:
+            out.append(None)
+            continue
+        out.append(dict(sizes=m.last["sizes"], iters=m.last["info"].cpu().tolist()[:6], loss=float(loss)))
+    m.keep_trace = False
+    m.last = None
+    return out
+
+
+def make(cfg, device, steps=400, tta_steps=32, n_images=64, size=512, lr=0.01, seed=0, log=print, train_all=False, matching_weight=1.0,
+         unsup_weight=10.0):
+    """Build, fit and return (model, report).  ``cfg`` is the test config (TEST.BATCH, INPUT sizes, NUM_CLASSES)."""
+    from ttdg_mgm_amd.engine import BaselineTrainer
+    from ttdg_mgm_amd.modeling import calibrate_frozen_bn
+    t0 = time.perf_counter()
+    torch.manual_seed(seed)
+    cfg = cfg.clone()
+    cfg.MODEL.DEVICE = str(device)
+    model = BaselineTrainer.build_model(cfg)
+    batches = source_batches(cfg, n_images, size, device)
+    calibrate_frozen_bn(model, batches[0])
+    hist = train_source(model, batches, steps, lr=lr, seed=seed, log=log, train_all=train_all, matching_weight=matching_weight,
+                        unsup_weight=unsup_weight)
+    stats = warm_tta(model, cfg, batches, tta_steps, log=log) if tta_steps else []
+    torch.cuda.synchronize()
+    report = dict(stage1_steps=steps, stage2_tta_steps=tta_steps, source_images=n_images, seconds=time.perf_counter() - t0,
+                  stage1_last=hist[-1] if hist else None, stage2_last=stats[-1] if stats else None)
+    return model, report
+
+
+def cache_key(**kw):
+    h = hashlib.sha256(open(os.path.abspath(__file__), "rb").read())
+    h.update(repr(sorted(kw.items())).encode())
+    return h.hexdigest()[:16]
+
+
+def get_or_make(cfg, device, cache_dir=None, log=print, **kw):
+    """-> (state_dict path, report).  The checkpoint is a plain ``{"model": state_dict}`` .pth the product loader reads."""
+    cache_dir = cache_dir or os.environ.get("TTDG_CKPT_CACHE", "/tmp/ttdg_synth_ckpt")
+    os.makedirs(cache_dir, exist_ok=True)
+    key = cache_key(batch=cfg.TEST.BATCH, min_size=cfg.INPUT.MIN_SIZE_TEST, classes=cfg.MODEL.ROI_HEADS.NUM_CLASSES, **kw)
+    path = os.path.join(cache_dir, "synth_%s.pth" % key)
+    if os.path.exists(path):
+        rep = torch.load(path + ".report", weights_only=True) if os.path.exists(path + ".report") else {}
+        rep["cached"] = True
+        return path, rep
+    model, rep = make(cfg, device, log=log, **kw)
+    torch.save({"model": {k: v.detach().cpu() for k, v in model.state_dict().items()}}, path)
+    torch.save(rep, path + ".report")
+    rep["cached"] = False
+    return path, rep
+
+
+def main():
+    import argparse
+    import json
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--tta-steps", type=int, default=32)
+    ap.add_argument("--images", type=int, default=64)
+    ap.add_argument("--lr", type=float, default=0.01)
+    ap.add_argument("--train-all", action="store_true")
+    ap.add_argument("--matching-weight", type=float, default=1.0)
+    ap.add_argument("--unsup-weight", type=float, default=10.0)
+    ap.add_argument("--eval-images", type=int, default=16)
+    ap.add_argument("--out", default="")
+    a = ap.parse_args()
+    from ttdg_mgm_amd.config import get_cfg
+    from ttdg_mgm_amd.engine import BaselineTrainer, inference_on_dataset
+    from ttdg_mgm_amd.evaluation import DiceEvaluator
+    from ttdg_mgm_amd import data
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "test_segment.yaml"))
+    dev = torch.device("cuda:0")
+    model, rep = make(cfg, dev, steps=a.steps, tta_steps=a.tta_steps, n_images=a.images, lr=a.lr, train_all=a.train_all,
+                      matching_weight=a.matching_weight, unsup_weight=a.unsup_weight)
+    # held-out check on a test-stream slice (cfg-2 seeds)
+    data.register_synthetic("ckpt_check", a.eval_images, size=512, cfg_id=2)
+    BaselineTrainer.rank, BaselineTrainer.world, BaselineTrainer.device = 0, 1, dev
+    loader = BaselineTrainer.build_test_loader(cfg, "ckpt_check")
+    ev = DiceEvaluator("ckpt_check", cfg.TEST.DICE_THRES, dataset_dicts=loader.dataset_dicts)
+    res, _ = inference_on_dataset(model, loader, ev, cfg)
+    rep["heldout"] = res
+    rep["heldout_kept_masks"] = len(ev.dice_scores)
+    rep["heldout_regime"] = solver_regime(model, list(loader)[:4])
+    print(json.dumps(rep, default=str))
+    if a.out:
+        torch.save({"model": {k: v.detach().cpu() for k, v in model.state_dict().items()}}, a.out)
+
+
+if __name__ == "__main__":
+    main()

@@ -81,6 +81,7 @@ def worker(rank, world, port, args):
     if cfg.SEMISUPNET.Trainer != "baseline":
         raise ValueError("Trainer Name is not found.")
     BaselineTrainer.rank, BaselineTrainer.world, BaselineTrainer.device = rank, world, torch.device("cuda", local)
+    BaselineTrainer.resident_inputs = False       # real datasets: stream every pass with a bounded prefetch (data/__init__.py)
     torch.manual_seed(0)
     model = BaselineTrainer.build_model(cfg)
     load_weights(model, cfg.MODEL.WEIGHTS, prefer_student=bool(cfg.TEST.get("EVAL_STU", False)))

@@ -9,8 +9,9 @@ from .. import synth
 _REGISTRY = {}
 
 
-def register_synthetic(name, num_images, size=512, cfg_id=2, kind="fundus", num_cls=2):
-    _REGISTRY[name] = dict(n=num_images, size=size, cfg_id=cfg_id, kind=kind, num_cls=num_cls)
+def register_synthetic(name, num_images, size=512, cfg_id=2, kind="fundus", num_cls=2, id_offset=0):
+    """``id_offset`` shifts the image ids (two streams evaluated by one DiceEvaluator must not share ids)."""
+    _REGISTRY[name] = dict(n=num_images, size=size, cfg_id=cfg_id, kind=kind, num_cls=num_cls, id_offset=id_offset)
 
 
 def register_coco_instances(name, metadata, json_file, image_root, input_format="RGB"):
@@ -41,7 +42,8 @@ def dataset_dicts(name, start=0, stop=None):
         gen = synth.fundus_image if spec["kind"] == "fundus" else synth.polyp_image
         img, boxes, classes, masks = gen(seed, spec["size"]) if spec["kind"] == "fundus" else gen(seed, spec["size"], spec["num_cls"])
         anns = [dict(bbox=boxes[k], category_id=int(classes[k]), mask=masks[k]) for k in range(len(classes))]
-        out.append(dict(image=img, height=int(img.shape[1]), width=int(img.shape[2]), image_id=i, annotations=anns, seed=seed))
+        out.append(dict(image=img, height=int(img.shape[1]), width=int(img.shape[2]), image_id=i + spec.get("id_offset", 0), annotations=anns,
+                        seed=seed))
     return out
 
 
@@ -51,7 +53,8 @@ def map_for_test(d, min_size=800, max_size=1333):
     h, w = d["height"], d["width"]
     s = min(min_size / min(h, w), max_size / max(h, w))
     nh, nw = int(round(h * s)), int(round(w * s))
-    img = F.interpolate(d["image"][None].float(), size=(nh, nw), mode="bilinear", align_corners=False)[0]
+    # bilinear; antialiased when shrinking, as the PIL resize of detectron2's ResizeShortestEdge is [3P] (no effect when enlarging)
+    img = F.interpolate(d["image"][None].float(), size=(nh, nw), mode="bilinear", align_corners=False, antialias=nh < h or nw < w)[0]
     boxes = torch.stack([a["bbox"] for a in d["annotations"]]) if d["annotations"] else torch.zeros(0, 4)
     # teacher-forced detections: jittered ground-truth boxes for the seeded synthetic images, the plain ground truth otherwise
     tf = (synth.jitter_boxes(d["seed"] + 500000, boxes) if "seed" in d else boxes) * torch.tensor([nw / w, nh / h, nw / w, nh / h])
@@ -61,26 +64,87 @@ def map_for_test(d, min_size=800, max_size=1333):
 
 
 class TestLoader:
-    """Iterable over lists of mapped dicts; rank r sees the contiguous shard detectron2's InferenceSampler gives it."""
+    """Iterable over lists of mapped dicts; rank r sees the contiguous shard detectron2's InferenceSampler gives it.
 
-    def __init__(self, name, batch, rank=0, world=1, device=None, min_size=800, max_size=1333):
+    Two modes.  ``resident=True`` (bench.py, the parity tests): the shard is decoded, mapped and - with ``device`` -
+    uploaded once, and every pass iterates over the resident items (the timed region starts with its inputs in HBM).
+    ``resident=False`` (train_net.py, large COCO-json datasets): nothing is held; every pass decodes / synthesises,
+    resizes and uploads batch by batch on a background thread, ``prefetch`` batches ahead, from pinned memory on a side
+    stream - the loader the reference iterates twice per dataset (data/build.py:122-154, trainer.py:470,485).  Each item
+    carries its ``dataset_dict`` (ground truth), so the evaluator never needs the whole dataset in memory."""
+
+    def __init__(self, name, batch, rank=0, world=1, device=None, min_size=800, max_size=1333, resident=True, prefetch=2):
         n = dataset_size(name)
         shard = (n - 1) // world + 1 if n else 0           # detectron2 InferenceSampler [3P]: contiguous, unpadded
-        self.dataset_dicts = dataset_dicts(name, shard * rank, min(shard * (rank + 1), n))
-        self.items = [map_for_test(d, min_size, max_size) for d in self.dataset_dicts]
-        if device is not None:                                   # keep inputs resident in HBM (bench)
-            for it in self.items:
-                it["image"] = it["image"].to(device)
-        self.batch = batch
+        self.name, self.batch, self.device = name, batch, device
+        self.start, self.stop = min(shard * rank, n), min(shard * (rank + 1), n)
+        self.min_size, self.max_size, self.resident, self.prefetch = min_size, max_size, resident, max(1, int(prefetch))
+        self._dicts = self.items = None
+        if resident:
+            self._dicts = dataset_dicts(name, self.start, self.stop)
+            self.items = [map_for_test(d, min_size, max_size) for d in self._dicts]
+            if device is not None:                                   # keep inputs resident in HBM (bench)
+                for it in self.items:
+                    it["image"] = it["image"].to(device)
+
+    @property
+    def dataset_dicts(self):
+        """Ground truth of the shard (materialised on first use in the streaming mode; the evaluator does not need it
+        there: it reads the ``dataset_dict`` every item carries)."""
+        if self._dicts is None:
+            self._dicts = dataset_dicts(self.name, self.start, self.stop)
+        return self._dicts
 
     def __len__(self):
-        return (len(self.items) + self.batch - 1) // self.batch
+        return (self.stop - self.start + self.batch - 1) // self.batch
+
+    def _load_batch(self, lo, hi, stream):
+        items = [map_for_test(d, self.min_size, self.max_size) for d in dataset_dicts(self.name, lo, hi)]
+        ev = None
+        if self.device is not None and torch.device(self.device).type == "cuda":
+            with torch.cuda.stream(stream):
+                for it in items:
+                    it["image"] = it["image"].pin_memory().to(self.device, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+        return items, ev
 
     def __iter__(self):
-        for i in range(0, len(self.items), self.batch):
-            yield self.items[i:i + self.batch]
+        if self.resident:
+            for i in range(0, len(self.items), self.batch):
+                yield self.items[i:i + self.batch]
+            return
+        import queue
+        import threading
+        q = queue.Queue(maxsize=self.prefetch)
+        cuda = self.device is not None and torch.device(self.device).type == "cuda"
+        stream = torch.cuda.Stream(device=self.device) if cuda else None
+
+        def produce():
+            try:
+                if cuda:
+                    torch.cuda.set_device(self.device)
+                for lo in range(self.start, self.stop, self.batch):
+                    q.put(self._load_batch(lo, min(lo + self.batch, self.stop), stream))
+                q.put(None)
+            except BaseException as e:          # surfaced on the consumer's thread
+                q.put(e)
+
+        t = threading.Thread(target=produce, daemon=True)
+        t.start()
+        while True:
+            got = q.get()
+            if got is None:
+                break
+            if isinstance(got, BaseException):
+                raise got
+            items, ev = got
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)       # the upload ran on the side stream
+            yield items
+        t.join()
 
 
-def build_detection_test_loader(cfg, dataset_name, rank=0, world=1, device=None):
+def build_detection_test_loader(cfg, dataset_name, rank=0, world=1, device=None, resident=True):
     return TestLoader(dataset_name, cfg.TEST.BATCH, rank, world, device,
-                      cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST)
+                      cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST, resident=resident)

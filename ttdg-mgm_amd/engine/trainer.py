@@ -102,7 +102,9 @@ def inference_on_dataset(model, data_loader, evaluator, cfg=None):
 
 class BaselineTrainer:
     rank, world = 0, 1            # set by the launcher (one process per GPU)
-    device = None                 # inputs are kept resident on this device when set
+    device = None                 # inputs are uploaded to this device when set
+    resident_inputs = True        # True: a shard is decoded / resized / uploaded once and stays in HBM (bench, tests);
+                                  # False: streamed batch by batch with a bounded prefetch on every pass (train_net.py)
 
     @classmethod
     def build_model(cls, cfg):
@@ -121,7 +123,7 @@ class BaselineTrainer:
 
     @classmethod
     def build_test_loader(cls, cfg, dataset_name):
-        return build_detection_test_loader(cfg, dataset_name, cls.rank, cls.world, cls.device)
+        return build_detection_test_loader(cfg, dataset_name, cls.rank, cls.world, cls.device, resident=cls.resident_inputs)
 
     @classmethod
     def tta_step(cls, model, optimizer, inputs):
@@ -144,6 +146,13 @@ class BaselineTrainer:
     def tta_batches(cls, model, data_loader, limit=None):
         """The batches one rank adapts on.  Mode S keeps the ranks in lockstep: every rank takes max-over-ranks steps and
         feeds None once its own shard is exhausted."""
+        if not getattr(model, "sync_universe", False):
+            def stream():           # nothing is held: the loader decides whether the shard is resident or streamed
+                for bidx, inputs in enumerate(data_loader):
+                    if limit is not None and bidx >= limit:
+                        break
+                    yield inputs
+            return stream()
         batches = []
         for bidx, inputs in enumerate(data_loader):
             if limit is not None and bidx >= limit:
@@ -173,8 +182,12 @@ class BaselineTrainer:
                 timers.setdefault("tta_s", 0.0)
                 timers["tta_s"] += time.perf_counter() - t0
             t1 = time.perf_counter()
-            dice = evaluators[idx] if evaluators is not None else DiceEvaluator(
-                dataset_name, cfg.TEST.DICE_THRES, dataset_dicts=data_loader.dataset_dicts)   # ground truth of the local shard
+            if evaluators is not None:
+                dice = evaluators[idx]
+            elif cls.resident_inputs:
+                dice = DiceEvaluator(dataset_name, cfg.TEST.DICE_THRES, dataset_dicts=data_loader.dataset_dicts)   # ground truth of the local shard
+            else:
+                dice = DiceEvaluator(dataset_name, cfg.TEST.DICE_THRES, lazy=True)      # ground truth travels with every streamed item
             results_i, _ = inference_on_dataset(model, data_loader, dice, cfg)
             if timers is not None:
                 torch.cuda.synchronize()

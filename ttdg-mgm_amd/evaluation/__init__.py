@@ -84,11 +84,18 @@ def structure_measure(pred, gt, alpha=0.5):
 
 
 class DiceEvaluator:
-    def __init__(self, dataset_name, thres, dataset_dicts=None):
+    GT_CACHE_IMAGES = 256        # device copies of the ground-truth masks kept between passes (bounded: oldest dropped)
+
+    def __init__(self, dataset_name, thres, dataset_dicts=None, lazy=False):
+        """``dataset_dicts``: ground truth of the local shard.  ``lazy=True``: hold none - every input of ``process`` carries
+        its own ``dataset_dict`` (the streaming TestLoader), so a large dataset is never resident."""
         from ..data import dataset_dicts as _dd
         self.dataset_name = dataset_name
-        self.dataset_dicts = dataset_dicts if dataset_dicts is not None else _dd(dataset_name)
-        self._by_id = {d["image_id"]: d for d in self.dataset_dicts}
+        if lazy:
+            self.dataset_dicts, self._by_id = None, {}
+        else:
+            self.dataset_dicts = dataset_dicts if dataset_dicts is not None else _dd(dataset_name)
+            self._by_id = {d["image_id"]: d for d in self.dataset_dicts}
         self.score_threshold = thres
         self._gt_cache = {}
         self.reset()
@@ -97,11 +104,15 @@ class DiceEvaluator:
         self.dice_scores, self.ea_scores, self.sm_scores = [], [], []
         self._pending = []
 
-    def _gt(self, image_id, dev):
+    def _gt(self, image_id, dev, record=None):
         key = (image_id, str(dev))
         if key not in self._gt_cache:
             out = []
-            for a in self._by_id[image_id]["annotations"]:
+            if record is None:
+                record = self._by_id[image_id]
+            while len(self._gt_cache) >= self.GT_CACHE_IMAGES:
+                self._gt_cache.pop(next(iter(self._gt_cache)))
+            for a in record["annotations"]:
                 m = a["mask"]
                 ys, xs = torch.nonzero(m, as_tuple=True)
                 cen = (ys.double().mean().item(), xs.double().mean().item()) if ys.numel() else (float("nan"), float("nan"))
@@ -126,7 +137,7 @@ class DiceEvaluator:
             kept = [k for k, c in enumerate(mine) if c >= 0]
             if not kept:
                 continue
-            gts = self._gt(inp["image_id"], inst.pred_masks.device)
+            gts = self._gt(inp["image_id"], inst.pred_masks.device, inp.get("dataset_dict"))
             zero = torch.zeros((), dtype=torch.float64, device=inst.pred_masks.device)
             for k in kept:
                 pc, pm = mine[k], inst.pred_masks[k]

@@ -16,6 +16,25 @@ DIM, HID, UNIV = 256, 512, 32
 KERNEL_TIMERS = None
 
 
+class _timed:
+    """Records (name, start_event, end_event, meta, None) into KERNEL_TIMERS around a launch when bench.py asks for it."""
+
+    def __init__(self, name, meta):
+        self.name, self.meta, self.on = name, meta, KERNEL_TIMERS is not None
+
+    def __enter__(self):
+        if self.on:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record()
+            KERNEL_TIMERS.append((self.name, self.e0, self.e1, self.meta, None))
+        return False
+
+
 # ------------------------------------------------------------------------------------------- GEMM
 def gemm(A, sam, sak, B, sbn, sbk, Cout, scm, scn, M, N, K, bias=None, alpha=1.0, beta=0.0,
          a_off=0, b_off=0, c_off=0):
@@ -327,9 +346,11 @@ class MatchingLossFn(torch.autograd.Function):
         Q = linear_raw(Xt, W1, b1, DIM, HID)
         w2f = w2.reshape(-1)
         ks = opts.get("ksplit") or pick_ksplit(M, HID, max(sizes))
-        part = affinity_pairwise_fwd(P, Q, w2f, gr, ks)
+        with _timed("affinity_fwd", sizes):
+            part = affinity_pairwise_fwd(P, Q, w2f, gr, ks)
         tau, iters = opts.get("pair_tau", 0.05), opts.get("pair_iters", 20)
-        Wds, pot = sinkhorn_pairs_fwd(part, b2, gr, sizes, tau, iters)
+        with _timed("sinkhorn_pairs_fwd", sizes):
+            Wds, pot = sinkhorn_pairs_fwd(part, b2, gr, sizes, tau, iters)
         q = linear_raw(X, Wq, bq)
         k = linear_raw(X, Wk, bk)
         apack = mha_adjacency(q, k, gr, sizes, DIM ** -0.5, opts.get("drop_p", 0.0), opts.get("seed", 0))
@@ -354,8 +375,10 @@ class MatchingLossFn(torch.autograd.Function):
         gr = graphs(sizes)
         M = X.shape[0]
         # everything downstream is linear in dWds: apply the incoming loss scale (normally 1.0) once, here
-        dM = sinkhorn_pairs_bwd(part, b2, pot, dWds * gloss, gr, tau, iters)
-        dP, dQ, dw2, db2 = affinity_pairwise_bwd(P, Q, w2f, dM, gr)
+        with _timed("sinkhorn_pairs_bwd", sizes):
+            dM = sinkhorn_pairs_bwd(part, b2, pot, dWds * gloss, gr, tau, iters)
+        with _timed("affinity_bwd", sizes):
+            dP, dQ, dw2, db2 = affinity_pairwise_bwd(P, Q, w2f, dM, gr)
         dW1 = torch.empty_like(W1)
         gemm(dP, 1, HID, Xs, 1, DIM, dW1, HID, 1, HID, DIM, M)                    # dW1[:, :256] = dP^T Xs
         gemm(dQ, 1, HID, Xt, 1, DIM, dW1, HID, 1, HID, DIM, M, c_off=DIM)         # dW1[:, 256:] = dQ^T Xt
