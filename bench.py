@@ -55,7 +55,7 @@ def parse(argv=None):
     ap.add_argument("--ckpt-tta-steps", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=3, help="timed CPU repetitions after 1 warm-up (median reported)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = os.cpu_count()")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(os.cpu_count(), 64)")
     ap.add_argument("--cpu-1thread", action="store_true", help="also time ONE repetition with 1 thread (minutes)")
     ap.add_argument("--eval-streams", type=int, default=1, help="concurrent eval batches (HIP streams) in the Dice pass; 1 = sequential")
     ap.add_argument("--no-overlap-detector", action="store_true", help="A/B: keep the teacher-forced RPN + box head on the main stream")
@@ -282,13 +282,23 @@ def cpu_model_string():
 
 
 def cpu_baseline(args, weights, teacher_forced):
-    """SURVEY.md §8d protocol: all host cores (torch intra-op threads = os.cpu_count() unless --cpu-threads), 1 warm-up +
-    median of --cpu-reps repetitions of (one TTA step + eval pass on 4 images), each from the same checkpoint; the warm-up
-    repetition's Dice is the CPU side of `dice_parity`."""
-    from oracle import tta_cpu
-    cores = args.cpu_threads or (os.cpu_count() or 1)
-    torch.set_num_threads(cores)
-    r = tta_cpu.run(1, args.batch, args.size, teacher_forced=teacher_forced, weights=weights, reps=args.cpu_reps, warmup=1)
+    """SURVEY.md §8d protocol: 1 warm-up + median of --cpu-reps repetitions of (one TTA step + eval pass on 4 images), each
+    from the same checkpoint; the warm-up repetition's Dice is the CPU side of `dice_parity`.  Runs in a CHILD process with
+    a time limit (the oracle port must never be able to hang the bench) and its own thread count: min(os.cpu_count(), 64)
+    unless --cpu-threads - beyond 64 intra-op threads torch's CPU kernels stop scaling on these tensor sizes, and on a
+    cgroup-limited box oversubscribed spin-waits stall them altogether (measured: > 30 min at 256 threads)."""
+    import subprocess
+    cores = args.cpu_threads or min(os.cpu_count() or 1, 64)
+    spec = dict(batch=args.batch, size=args.size, teacher_forced=teacher_forced, weights=weights, reps=args.cpu_reps, warmup=1, threads=cores)
+    code = ("import json, sys, torch; sys.path.insert(0, %r); spec = json.loads(sys.argv[1]); torch.set_num_threads(spec['threads']); "
+            "from oracle import tta_cpu; r = tta_cpu.run(1, spec['batch'], spec['size'], teacher_forced=spec['teacher_forced'], "
+            "weights=spec['weights'], reps=spec['reps'], warmup=spec['warmup']); print('CPUJSON' + json.dumps(r))" % ROOT)
+    env = dict(os.environ, OMP_NUM_THREADS=str(cores), MKL_NUM_THREADS=str(cores), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    limit = 120 + 90 * (1 + args.cpu_reps)
+    p = subprocess.run([sys.executable, "-c", code, json.dumps(spec)], capture_output=True, text=True, timeout=limit, env=env, cwd=ROOT)
+    if p.returncode != 0:
+        raise RuntimeError("CPU port failed: " + p.stderr[-800:])
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("CPUJSON")][-1][7:])
     med = statistics.median(r["times"])
     out = {"value": args.batch / med, "unit": "adapted images/s", "cores": cores, "host_cores": os.cpu_count(), "cpu_model": cpu_model_string(),
            "kind": "port", "protocol": "1 warm-up + median of %d" % len(r["times"]), "seconds_median": med, "seconds_all": r["times"],
@@ -297,10 +307,11 @@ def cpu_baseline(args, weights, teacher_forced):
                      % (args.batch, args.size, args.size, cores, "trained-regime checkpoint" if weights else "random-init",
                         "teacher-forced" if teacher_forced else "free-running")}
     if args.cpu_1thread:
-        torch.set_num_threads(1)
-        r1 = tta_cpu.run(1, args.batch, args.size, teacher_forced=teacher_forced, weights=weights, reps=1, warmup=0)
+        spec1 = dict(spec, reps=1, warmup=0, threads=1)
+        env1 = dict(env, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+        p1 = subprocess.run([sys.executable, "-c", code, json.dumps(spec1)], capture_output=True, text=True, timeout=3600, env=env1, cwd=ROOT)
+        r1 = json.loads([l for l in p1.stdout.splitlines() if l.startswith("CPUJSON")][-1][7:])
         out["one_thread"] = {"value": args.batch / r1["times"][0], "seconds": r1["times"][0]}
-        torch.set_num_threads(cores)
     return out, r["dice"]
 
 
@@ -320,6 +331,14 @@ def gpu_dice_parity_leg(cfg, model, init_state, batch, dicts, name, teacher_forc
     res = ev.evaluate()
     res["kept_masks"] = len(ev.dice_scores)
     return res
+
+
+_T0 = time.perf_counter()
+
+
+def note(msg):
+    """Progress on stderr (the one JSON line stays alone on stdout)."""
+    print("[bench %6.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
 
 
 def _finite(x):
@@ -395,6 +414,9 @@ def gpu_main(args, rank, world, local):
         dist.barrier()
     K, W, B = steps_per_rank(args, world), args.warmup, args.batch
     cfg = base_cfg(args, device)
+    from ttdg_mgm_amd import ops as _ops
+    from ttdg_mgm_amd.modeling import detector as _det
+    assert _det._backend is _ops, "the GPU legs must run on the HIP operators (detector._backend was re-pointed)"
     if args.images:
         # strong scaling: the FIXED stream is sharded; warm-up batches come from another stream so that the timed work is
         # exactly args.images images whatever the rank count
@@ -409,10 +431,12 @@ def gpu_main(args, rank, world, local):
     weights, ckpt_report = (None, None)
     if args.weights == "trained":
         weights, ckpt_report = trained_checkpoint(cfg, args, device, rank, world)
+    note("inputs staged, weights: %s" % (weights or "random init"))
     model = build_model(cfg, args, device, weights, batches[0], world)
     init_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
     tf = bool(args.teacher_forced)
     main = timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, world, device, tf)
+    note("headline pass done: %.1f images/s" % (world * K * B / main["elapsed"]))
 
     ab = {}
     parity = None
@@ -424,15 +448,18 @@ def gpu_main(args, rank, world, local):
                     "kept_masks": r["kept_masks"], "gagm_avg_launch_ms": g and g["avg_launch_ms"],
                     "gagm_avg_iterations_per_stage": g and g["avg_iterations_per_stage"]}
         if args.weights == "trained":
+            note("A/B: other detection mode")
             ab["teacher_forced" if not tf else "free_running"] = short(
                 timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, world, device, not tf),
                 "same checkpoint, %s detections" % ("teacher-forced" if not tf else "free-running"))
+            note("A/B: random init")
             rmodel = build_model(cfg, args, device, None, batches[0], world)
             rstate = {k: v.detach().clone() for k, v in rmodel.state_dict().items()}
             ab["random_init"] = short(timed_pass(cfg, rmodel, rstate, batches, local_dicts, name, K, W, args, world, device, True),
                                       "random-init weights, teacher-forced detections (the round-1 configuration: worst-case solver regime, Dice undefined)")
             del rmodel, rstate
         # inputs through the streaming loader inside the timed region (synthesise + resize + pinned H2D, 2-deep prefetch)
+        note("A/B: loader-inclusive")
         from ttdg_mgm_amd import data
         data.register_synthetic("synthfundus_stream", K * B, size=args.size, cfg_id=4, id_offset=2 * 10 ** 6)
 
@@ -443,6 +470,7 @@ def gpu_main(args, rank, world, local):
             timed_pass(cfg, model, init_state, batches, local_dicts + sd, name, K, W, args, world, device, tf, loader_factory=stream),
             "timed batches stream through the test loader (image synthesis standing for decode, resize 512->800, pinned H2D; 2-deep prefetch) in both passes")
     if world == 1 and args.weights == "trained":
+        note("Dice parity leg (GPU)")
         parity = {"gpu": gpu_dice_parity_leg(cfg, model, init_state, batches[0], local_dicts, name, tf)}
 
     if rank != 0:
@@ -475,7 +503,9 @@ def gpu_main(args, rank, world, local):
         out["ab"] = ab
     if world == 1 and not args.no_cpu_baseline:
         try:
+            note("CPU baseline (1 warm-up + %d repetitions)" % args.cpu_reps)
             out["cpu_baseline"], cpu_dice = cpu_baseline(args, weights, tf)
+            note("CPU baseline done: %s s per repetition" % out["cpu_baseline"]["seconds_all"])
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             if parity is not None:
                 parity["cpu_port"] = cpu_dice

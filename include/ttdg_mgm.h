@@ -252,6 +252,16 @@ int ttdg_bias_act(float* y, const float* bias, const float* residual, const floa
 int ttdg_roi_align_multilevel(ttdg_fpn_t fp, ttdg_levels_t lv, const float* rois, int R, int P, float canonical_size,
                               int canonical_level, int min_level, float* out, ttdg_stream_t stream);
 
+/* DiceEvaluator reductions (reference evaluation/dice_metric.py:25-92 with enhanced_align :110-143 and
+ * Structure_measure :147-240): for `npairs` (predicted mask, same-class ground-truth mask) pairs of H x W byte maps (0/1,
+ * rows contiguous; pred[i] / gt[i] are DEVICE ADDRESSES), the counts n(p AND g), n(p), n(g) in the four quadrants of
+ * the image split at row cy[i] / column cx[i] (the S-measure's centroid split, :196-214):
+ *   counts[i][(2*(row >= cy) + (col >= cx)) * 3 + {0, 1, 2}].
+ * Dice, E-measure and S-measure of boolean maps are closed forms of these twelve integers (the host mirror evaluates them
+ * in float64); one launch covers every kept prediction of an eval batch.  Zeroes `counts` itself. */
+int ttdg_mask_pair_counts(const unsigned long long* pred, const unsigned long long* gt, const int32_t* cy, const int32_t* cx,
+                          int npairs, int H, int W, int32_t* counts, ttdg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

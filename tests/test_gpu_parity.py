@@ -322,10 +322,14 @@ def test_hungarian_ties_and_errors(dev, golden):
         hungarian(torch.zeros(3, device=dev))
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(6, 6), (12, 32), (40, 32), (32, 95), (64, 64), (256, 32), (20, 33), (32, 129), (200, 32), (60, 250), (100, 128)])
-def test_lap_batched_vs_scipy_incl_ties(dev, shape):
+def test_lap_batched_vs_scipy_incl_ties(dev, shape, variant):
+    """All three settings of the register-resident solver (0: cost column in registers + compiler-lowered fp64 DPP minimum,
+    1: hand-scheduled minimum, 2: costs read per step); other shapes take the same code under every setting."""
     import scipy.optimize
-    from ttdg_mgm_amd import ops
+    from ttdg_mgm_amd import _lib, ops
+    _lib.load().ttdg_debug_set_lap_variant(variant)
     mats = []
     for seed in range(24):
         g = synth.gen(9300 + seed)
@@ -337,7 +341,10 @@ def test_lap_batched_vs_scipy_incl_ties(dev, shape):
             m = g.standard_normal(shape).astype(np.float32)
         mats.append(m)
     s = torch.from_numpy(np.stack(mats))
-    x = ops.lap_batched(s.to(dev)).cpu().numpy()
+    try:
+        x = ops.lap_batched(s.to(dev)).cpu().numpy()
+    finally:
+        _lib.load().ttdg_debug_set_lap_variant(0)
     for i, m in enumerate(mats):
         r, c = scipy.optimize.linear_sum_assignment(m.astype(np.float64) * -1)
         ref = np.zeros(shape, np.float32)
@@ -1078,3 +1085,20 @@ def test_dice_evaluator_on_device_vs_reference_golden(dev, golden):
     for k, key in (("dice", "Dice Coefficient"), ("ea", "Enhanced Alignment Metric"), ("sm", "Structural Similarity Metric")):
         want = 100.0 * float(np.mean([float(gold[f"c{i}_{k}"]) for i in range(len(pairs))]))
         assert abs(res[key] - want) <= 1e-4, (key, res[key], want)
+
+
+@pytest.mark.parametrize("H,W", [(96, 80), (33, 17), (64, 61), (512, 512), (1, 7)])
+def test_mask_pair_counts_kernel_exact(dev, H, W):
+    """ttdg_mask_pair_counts against the same twelve counts in plain torch: vectorised (W % 4 == 0) and byte paths, cuts at
+    the borders, on a word boundary and inside a word, pairs that share a prediction."""
+    from ttdg_mgm_amd import ops
+    from ttdg_mgm_amd.evaluation import quadrant_counts
+    g = synth.gen(H * 1000 + W)
+    P = torch.from_numpy(g.uniform(size=(5, H, W)) < 0.4)
+    G = torch.from_numpy(g.uniform(size=(3, H, W)) < 0.6)
+    Pd, Gd = P.to(dev).contiguous(), G.to(dev).contiguous()
+    pairs = [(0, 0, 0, 0), (1, 1, H, W), (2, 2, H // 2, W // 2), (3, 0, min(H, 5), min(W, 3)), (4, 1, 1, 4 if W >= 4 else 1), (0, 2, H - 1, W - 1)]
+    cnt = ops.mask_pair_counts([Pd[a].data_ptr() for a, _, _, _ in pairs], [Gd[b].data_ptr() for _, b, _, _ in pairs],
+                               [c for _, _, c, _ in pairs], [c for _, _, _, c in pairs], H, W, dev).cpu().tolist()
+    for row, (a, b, cy, cx) in zip(cnt, pairs):
+        assert row == quadrant_counts(P[a], G[b], cy, cx), (a, b, cy, cx)

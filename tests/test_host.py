@@ -206,3 +206,27 @@ def test_config_rejects_unsupported_architecture_keys(tmp_path):
     cfg.merge_from_file(str(good))
     assert cfg.TEST.BATCH == 4 and cfg.TEST.EVAL_STU is False          # add_ateacher_config default (reference config.py:11)
     assert get_cfg().TEST.BATCH == 1                                    # reference default (config.py:16)
+
+
+def test_measures_from_quadrant_counts_equal_the_elementwise_measures(golden):
+    """The closed forms the device evaluator uses (twelve quadrant counts per mask pair) against the element-by-element
+    measures pinned to the reference's numpy functions: the six golden pairs and random / degenerate masks."""
+    from ttdg_mgm_amd.evaluation import (centroid_cuts, dice_tensor, enhanced_align_tensor, measures_from_counts, quadrant_counts,
+                                         structure_measure_tensor)
+    gold = golden("dice")
+    pairs = [(torch.from_numpy(p), torch.from_numpy(g)) for p, g in cases.dice_mask_pairs()]
+    g = synth.gen(77)
+    for shape, dens in (((40, 56), (0.3, 0.5)), ((33, 17), (0.05, 0.9)), ((8, 8), (0.5, 0.5)), ((64, 64), (0.0, 0.4)), ((21, 30), (1.0, 0.2))):
+        pairs.append((torch.from_numpy(g.uniform(size=shape) < dens[0]), torch.from_numpy(g.uniform(size=shape) < dens[1])))
+    for i, (p, gt) in enumerate(pairs):
+        ys, xs = torch.nonzero(gt, as_tuple=True)
+        cen = (ys.double().mean().item(), xs.double().mean().item()) if ys.numel() else (float("nan"), float("nan"))
+        cy, cx = centroid_cuts(cen)
+        H, W = p.shape
+        cnt = torch.tensor([quadrant_counts(p, gt, cy, cx)], dtype=torch.int32)
+        d, e, s = measures_from_counts(cnt, H, W, [cy], [cx])[0].tolist()
+        want = (float(dice_tensor(p, gt)), float(enhanced_align_tensor(p, gt)), float(structure_measure_tensor(p, gt, centroid=cen)))
+        for got, ref in zip((d, e, s), want):
+            assert (math.isnan(got) and math.isnan(ref)) or abs(got - ref) <= 1e-10, (i, (d, e, s), want)
+        if i < 6:
+            assert abs(d - float(gold[f"c{i}_dice"])) <= 1e-9 and abs(e - float(gold[f"c{i}_ea"])) <= 1e-9 and abs(s - float(gold[f"c{i}_sm"])) <= 1e-6

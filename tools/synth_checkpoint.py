@@ -127,7 +127,17 @@ def rpn_losses(rpn, features, gts, gen, batch_per_image=256, pos_frac=0.5):
     return loss_cls / norm, loss_loc / norm
 
 
-def roi_losses(roi, features, proposals, gts, gen, batch_per_image=512, pos_frac=0.25):
+def _pool(feats, rois, P, roi_grad):
+    """ROIAlign for the training heads: the differentiable torch formulation, or (default) the product's forward-only HIP
+    ROIPooler on detached features - the backbone then learns from the RPN and matching losses only, and a training step
+    costs a third (the scatter-add backward of grid_sample over ~1000 ROIs x 256 channels dominated it)."""
+    if roi_grad:
+        return roi_align_torch(feats, rois, (4, 8, 16, 32), P)
+    from ttdg_mgm_amd import ops
+    return ops.roi_align_multilevel([f.detach() for f in feats], rois, [4, 8, 16, 32], P)
+
+
+def roi_losses(roi, features, proposals, gts, gen, batch_per_image=512, pos_frac=0.25, roi_grad=False):
     """detectron2 StandardROIHeads losses [3P] (box classification + class-specific L1 regression + mask BCE)."""
     C = roi.num_classes
     dev = proposals[0].device
@@ -150,13 +160,18 @@ def roi_losses(roi, features, proposals, gts, gen, batch_per_image=512, pos_frac
     rois, cls_t = torch.cat(rois), torch.cat(cls_t)
     fg = torch.cat(fg_rows)
     feats = [features[f] for f in roi.box_in_features]
-    logits, deltas = roi.box_predictor(roi.box_head(roi_align_torch(feats, rois, (4, 8, 16, 32), 7)))
+    logits, deltas = roi.box_predictor(roi.box_head(_pool(feats, rois, 7, roi_grad)))
     loss_cls = F.cross_entropy(logits, cls_t)
     tgt = get_deltas(rois[fg, 1:], torch.cat(box_t), roi.bbox_weights)
     pred = deltas.view(-1, C, 4)[fg, cls_t[fg]]
     loss_box = (pred - tgt).abs().sum() / max(1, cls_t.numel())
-    # mask head on the foreground ROIs; target = GT bitmap cropped to the ROI at 28 x 28 (bilinear, >= 0.5)
-    mlogits = roi.mask_head(roi_align_torch(feats, rois[fg], (4, 8, 16, 32), 14))
+    # mask head on the foreground ROIs; target = GT bitmap cropped to the ROI at 28 x 28 (bilinear, >= 0.5).  The ROI set is
+    # padded (by repetition, zero loss weight) to a FIXED size: every new batch size of the mask head's convolutions would
+    # cost a MIOpen solver search / kernel build of about a second
+    nfg = fg.numel()
+    kfix = len(proposals) * int(batch_per_image * pos_frac)
+    fgp = fg[torch.arange(kfix, device=dev) % nfg]
+    mlogits = roi.mask_head(_pool(feats, rois[fgp], 14, roi_grad))[:nfg]
     S = mlogits.shape[-1]
     t = (torch.arange(S, device=dev, dtype=torch.float32) + 0.5) / S
     targets = []
@@ -289,7 +304,7 @@ def source_batches(cfg, n_images, size, device, name="synthfundus_source"):
 
 
 def train_source(model, batches, steps, lr=0.01, warmup=50, matching_weight=1.0, seed=0, log=None, train_all=False,
-                 unsup_weight=10.0, rois_per_image=256):
+                 unsup_weight=20.0, rois_per_image=256, matching_lr=1e-3, probe=None, probe_every=0, profile=False, roi_grad=False):
     """Stage 1.  SGD (momentum 0.9, wd 1e-4, linear warm-up, cosine decay), gradient-norm clip 10.
     Matching terms on nodes sampled inside the GT boxes (rcnn.py:262-266): ``matching_weight`` x the universe loss of
     ``multi_matching_sup`` (:136-169) and ``unsup_weight`` x the permutation loss of ``multi_matching_unsup`` (:560-564),
@@ -302,9 +317,21 @@ def train_source(model, batches, steps, lr=0.01, warmup=50, matching_weight=1.0,
     if train_all:
         for p in frozen:
             p.requires_grad_(True)
-    params = [p for n, p in model.named_parameters() if p.requires_grad and not n.startswith("D_img.")]
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and not n.startswith("D_img.")]
+    params = [p for n, p in named if not n.startswith("multi_matching_")]
+    mparams = [p for n, p in named if n.startswith("multi_matching_")]
     ulab = None
     opt = torch.optim.SGD(params, lr=lr, momentum=0.9, weight_decay=1e-4)
+    # the matching modules start from N(0, 0.01) weights (utils/affinity.py:33-41): plain SGD at the detector's rate barely
+    # moves them in a few hundred steps, so they get their own Adam
+    mopt = torch.optim.Adam(mparams, lr=matching_lr)
+    tprof = {}
+
+    def tick(name, t0):
+        if profile:
+            torch.cuda.synchronize()
+            tprof[name] = tprof.get(name, 0.0) + time.perf_counter() - t0
+        return time.perf_counter()
     model.train()
     hist = []
     t_start = time.perf_counter()
@@ -314,14 +341,21 @@ def train_source(model, batches, steps, lr=0.01, warmup=50, matching_weight=1.0,
         f = min(1.0, (step + 1) / warmup) * 0.5 * (1 + math.cos(math.pi * step / steps))
         for g in opt.param_groups:
             g["lr"] = lr * f
+        for g in mopt.param_groups:
+            g["lr"] = matching_lr * f
+        tt = time.perf_counter()
         images = model.preprocess_image(items)
         features = model.backbone(images.tensor)
+        tt = tick("backbone_fwd", tt)
         l_obj, l_loc = rpn_losses(model.proposal_generator, features, gts, gen)
+        tt = tick("rpn_loss", tt)
         with torch.no_grad():
             boxes, scores, keep, counts = model.proposal_generator.forward_dense(features, images.image_sizes)
             counts = counts.tolist()
             props = [boxes[n, keep[n, :counts[n]]] for n in range(len(items))]
-        l_cls, l_box, l_mask = roi_losses(model.roi_heads, features, props, gts, gen, batch_per_image=rois_per_image)
+        tt = tick("proposals", tt)
+        l_cls, l_box, l_mask = roi_losses(model.roi_heads, features, props, gts, gen, batch_per_image=rois_per_image, roi_grad=roi_grad)
+        tt = tick("roi_losses", tt)
         loss = l_obj + l_loc + l_cls + l_box + l_mask
         l_match = l_perm = None
         if matching_weight > 0 or unsup_weight > 0:
@@ -339,10 +373,18 @@ def train_source(model, batches, steps, lr=0.01, warmup=50, matching_weight=1.0,
             if unsup_weight > 0:
                 l_perm = model.multi_matching_unsup(nodes, labels, model.multi_matching_sup.U, forced_U=Ugt)
                 loss = loss + unsup_weight * l_perm
+        tt = tick("matching_fwd", tt)
         opt.zero_grad(set_to_none=True)
+        mopt.zero_grad(set_to_none=True)
         loss.backward()
+        tt = tick("backward", tt)
         torch.nn.utils.clip_grad_norm_(params, 10.0)
         opt.step()
+        mopt.step()
+        tt = tick("optimizer", tt)
+        if probe is not None and probe_every and (step + 1) % probe_every == 0 and log is not None:
+            log("probe after %d steps: %s" % (step + 1, probe(model)))
+            model.train()
         if log is not None and (step % 25 == 0 or step == steps - 1):
             rec = dict(step=step, loss=float(loss.detach()), rpn_cls=float(l_obj.detach()), rpn_loc=float(l_loc.detach()), cls=float(l_cls.detach()), box=float(l_box.detach()),
                        mask=float(l_mask.detach()), matching=None if l_match is None else float(l_match.detach()),
@@ -353,6 +395,8 @@ def train_source(model, batches, steps, lr=0.01, warmup=50, matching_weight=1.0,
     if train_all:
         for p in frozen:
             p.requires_grad_(False)
+    if profile and log is not None:
+        log("stage1 seconds per phase over %d steps: %s" % (steps, {k: round(v, 2) for k, v in tprof.items()}))
     return hist
 
 
@@ -369,7 +413,7 @@ def warm_tta(model, cfg, batches, steps, log=None):
         loss = BaselineTrainer.tta_step(model, opt, batches[step % len(batches)])
         info = model.multi_matching_unsup.last.get("info") if model.multi_matching_unsup.last else None
         it = info.cpu().tolist()[:6] if info is not None else None
-        stats.append((None if loss is None else float(loss), it))
+        stats.append((None if loss is None else float(loss.detach()), it))
         if log is not None and (step % 10 == 0 or step == steps - 1):
             log("stage2 step %d loss %s solver iterations per stage %s" % (step, stats[-1][0], it))
     model.multi_matching_unsup.keep_trace = False
@@ -396,8 +440,8 @@ def solver_regime(model, batches):
     return out
 
 
-def make(cfg, device, steps=400, tta_steps=32, n_images=64, size=512, lr=0.01, seed=0, log=print, train_all=False, matching_weight=1.0,
-         unsup_weight=10.0):
+def make(cfg, device, steps=600, tta_steps=16, n_images=64, size=512, lr=0.01, seed=0, log=print, train_all=False, matching_weight=1.0,
+         unsup_weight=20.0, matching_lr=1e-3, probe=None, probe_every=0, profile=False, roi_grad=False):
     """Build, fit and return (model, report).  ``cfg`` is the test config (TEST.BATCH, INPUT sizes, NUM_CLASSES)."""
     from ttdg_mgm_amd.engine import BaselineTrainer
     from ttdg_mgm_amd.modeling import calibrate_frozen_bn
@@ -409,7 +453,8 @@ def make(cfg, device, steps=400, tta_steps=32, n_images=64, size=512, lr=0.01, s
     batches = source_batches(cfg, n_images, size, device)
     calibrate_frozen_bn(model, batches[0])
     hist = train_source(model, batches, steps, lr=lr, seed=seed, log=log, train_all=train_all, matching_weight=matching_weight,
-                        unsup_weight=unsup_weight)
+                        unsup_weight=unsup_weight, matching_lr=matching_lr, probe=probe, probe_every=probe_every, profile=profile,
+                        roi_grad=roi_grad)
     stats = warm_tta(model, cfg, batches, tta_steps, log=log) if tta_steps else []
     torch.cuda.synchronize()
     report = dict(stage1_steps=steps, stage2_tta_steps=tta_steps, source_images=n_images, seconds=time.perf_counter() - t0,
@@ -444,13 +489,17 @@ def main():
     import argparse
     import json
     ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--tta-steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=600)
+    ap.add_argument("--tta-steps", type=int, default=16)
     ap.add_argument("--images", type=int, default=64)
+    ap.add_argument("--roi-grad", action="store_true")
     ap.add_argument("--lr", type=float, default=0.01)
     ap.add_argument("--train-all", action="store_true")
     ap.add_argument("--matching-weight", type=float, default=1.0)
-    ap.add_argument("--unsup-weight", type=float, default=10.0)
+    ap.add_argument("--unsup-weight", type=float, default=20.0)
+    ap.add_argument("--matching-lr", type=float, default=1e-3)
+    ap.add_argument("--probe-every", type=int, default=0)
+    ap.add_argument("--profile", action="store_true")
     ap.add_argument("--eval-images", type=int, default=16)
     ap.add_argument("--out", default="")
     a = ap.parse_args()
@@ -461,12 +510,14 @@ def main():
     cfg = get_cfg()
     cfg.merge_from_file(os.path.join(ROOT, "configs", "test_segment.yaml"))
     dev = torch.device("cuda:0")
-    model, rep = make(cfg, dev, steps=a.steps, tta_steps=a.tta_steps, n_images=a.images, lr=a.lr, train_all=a.train_all,
-                      matching_weight=a.matching_weight, unsup_weight=a.unsup_weight)
     # held-out check on a test-stream slice (cfg-2 seeds)
     data.register_synthetic("ckpt_check", a.eval_images, size=512, cfg_id=2)
     BaselineTrainer.rank, BaselineTrainer.world, BaselineTrainer.device = 0, 1, dev
     loader = BaselineTrainer.build_test_loader(cfg, "ckpt_check")
+    probe_batches = list(loader)[:3]
+    model, rep = make(cfg, dev, steps=a.steps, tta_steps=a.tta_steps, n_images=a.images, lr=a.lr, train_all=a.train_all,
+                      matching_weight=a.matching_weight, unsup_weight=a.unsup_weight, matching_lr=a.matching_lr, roi_grad=a.roi_grad,
+                      probe=lambda m: [r and r["iters"] for r in solver_regime(m, probe_batches)], probe_every=a.probe_every, profile=a.profile)
     ev = DiceEvaluator("ckpt_check", cfg.TEST.DICE_THRES, dataset_dicts=loader.dataset_dicts)
     res, _ = inference_on_dataset(model, loader, ev, cfg)
     rep["heldout"] = res

@@ -82,6 +82,9 @@ def worker(rank, world, port, args):
         raise ValueError("Trainer Name is not found.")
     BaselineTrainer.rank, BaselineTrainer.world, BaselineTrainer.device = rank, world, torch.device("cuda", local)
     BaselineTrainer.resident_inputs = False       # real datasets: stream every pass with a bounded prefetch (data/__init__.py)
+    from ttdg_mgm_amd import ops as _ops
+    from ttdg_mgm_amd.modeling import detector as _det
+    assert _det._backend is _ops, "train_net.py runs on the HIP operators only"
     torch.manual_seed(0)
     model = BaselineTrainer.build_model(cfg)
     load_weights(model, cfg.MODEL.WEIGHTS, prefer_student=bool(cfg.TEST.get("EVAL_STU", False)))

@@ -223,7 +223,11 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 
 // returns this lane's assigned column (valid for lanes < nr)
 // kMinImpl: 0 = compiler-lowered fp64 DPP min (default: measured 6 % faster on MI355X, tools/bench_lap.py),
-//           1 = hand-scheduled inline-asm stages (kept for A/B runs)
+//           1 = hand-scheduled inline-asm stages (kept for A/B runs).
+//           (Tried in round 2 and dropped: the minimum over order-preserving 64-bit integer keys as two rounds of
+//           single-instruction v_min_u32_dpp stages - 10 DPP instructions instead of ~30 - was 7-9 % SLOWER (41.8 vs 38.9 us
+//           per 30x32 LAP): the second round depends on a readlane of the first, which lengthens the per-step chain more
+//           than the shorter stages save.  The chain, not the instruction count, bounds this solver.)
 // kRegCost: the lane's column of the cost matrix (nr <= 32 rows) is preloaded into 32 registers and read back with a
 //           wavefront-uniform dynamic index (s_set_gpr_idx / v_movrel): the cost read leaves the per-step dependency chain
 //           (an LDS or L2 round trip per step otherwise)

@@ -71,6 +71,66 @@ def structure_measure_tensor(pred, gt, alpha=0.5, centroid=None):
     return torch.where(y == 0, 1 - p.mean(), torch.where(y == 1, p.mean(), general))
 
 
+def centroid_cuts(centroid):
+    """(row cut, column cut) of the S-measure's quadrant split (dice_metric.py:196-214) from the GT centroid (cy, cx)."""
+    if centroid[0] != centroid[0]:            # NaN centroid of an empty GT: the general branch is never selected
+        return 1, 1
+    return int(round(centroid[0])) + 1, int(round(centroid[1])) + 1
+
+
+def measures_from_counts(counts, H, W, cy, cx, alpha=0.5):
+    """Dice / E-measure / S-measure of BOOLEAN maps from the twelve quadrant counts ``ttdg_mask_pair_counts`` produces
+    (``counts[i][q*3 + {0,1,2}] = n(p&g), n(p), n(g)`` in quadrant q = 2*(row >= cy) + (col >= cx)); float64, vectorised
+    over pairs.  Same arithmetic as dice_tensor / enhanced_align_tensor / structure_measure_tensor above (which follow
+    dice_metric.py:54-66, 110-143, 147-240 element by element): every sum over pixels of a function of two booleans is
+    sum over the four (p, g) combinations of count x value.  -> (n, 3)."""
+    c = counts.to(torch.float64).view(-1, 4, 3)
+    N = float(H * W)
+    n11, npd, ng = c[:, :, 0].sum(1), c[:, :, 1].sum(1), c[:, :, 2].sum(1)
+    one, zero = torch.ones_like(n11), torch.zeros_like(n11)
+    dice = 2 * n11 / (npd + ng + 1e-6)
+    # ---- E-measure: fm = p, or all ones when the prediction is empty (threshold 2 * mean = 0)
+    nf = torch.where(npd == 0, one * N, npd)
+    n11f = torch.where(npd == 0, ng, n11)
+    mf, mg = nf / N, ng / N
+
+    def val(f, g):
+        af, ag = f - mf, g - mg
+        return ((2.0 * (ag * af) / (ag * ag + af * af + 1e-8)) + 1) ** 2 / 4
+    general = n11f * val(1.0, 1.0) + (nf - n11f) * val(1.0, 0.0) + (ng - n11f) * val(0.0, 1.0) + (N - nf - ng + n11f) * val(0.0, 0.0)
+    em = torch.where(ng == 0, N - nf, torch.where(ng == N, nf, general)) / (N - 1 + 1e-8)
+    # ---- S-measure: object term from the totals, region term from the quadrants
+    y = ng / N
+
+    def s_object(hit, cnt):                   # boolean values over `cnt` pixels, `hit` of them 1
+        x = hit / cnt
+        sig = torch.sqrt((hit * (1 - x) ** 2 + (cnt - hit) * x * x) / cnt)
+        return 2 * x / (x * x + 1 + sig + 1e-8)
+    obj = y * s_object(n11, ng) + (1 - y) * s_object(N - npd - ng + n11, N - ng)
+    cy = torch.as_tensor(cy, dtype=torch.float64, device=c.device).clamp(0, H)
+    cx = torch.as_tensor(cx, dtype=torch.float64, device=c.device).clamp(0, W)
+    areas = torch.stack((cy * cx, cy * (W - cx), (H - cy) * cx, (H - cy) * (W - cx)), 1)          # (n, 4), quadrant order of the kernel
+    a = areas.clamp(min=1.0)
+    x, yq = c[:, :, 1] / a, c[:, :, 2] / a
+    sx, sy = x * (1 - x), yq * (1 - yq)                                                               # population variance of a boolean map
+    sxy = torch.where(areas > 1, (c[:, :, 0] - a * x * yq) / (a - 1).clamp(min=1.0), torch.full_like(a, float("nan")))
+    al, be = 4 * x * yq * sxy, (x * x + yq * yq) * (sx + sy)
+    ssim = torch.where(al != 0, al / (be + 1e-8), torch.where(be == 0, torch.ones_like(al), torch.zeros_like(al)))
+    reg = torch.where(areas > 0, areas / N * ssim, torch.zeros_like(ssim)).sum(1)
+    sm = torch.where(y == 0, 1 - npd / N, torch.where(y == 1, npd / N, alpha * obj + (1 - alpha) * reg))
+    return torch.stack((dice, em, sm), 1)
+
+
+def quadrant_counts(p, g, cy, cx):
+    """The twelve counts of ``ttdg_mask_pair_counts`` for one pair, in plain torch (host-side reference of the kernel)."""
+    out = []
+    for rs in (slice(0, cy), slice(cy, None)):
+        for cs in (slice(0, cx), slice(cx, None)):
+            pq, gq = p[rs, cs].bool(), g[rs, cs].bool()
+            out += [int((pq & gq).sum()), int(pq.sum()), int(gq.sum())]
+    return out
+
+
 def dice_coefficient(p, g):
     return dice_tensor(p, g).item()
 
@@ -130,6 +190,8 @@ class DiceEvaluator:
         scores = torch.cat([i.scores for i in insts])
         classes = torch.cat([i.pred_classes for i in insts])
         sel = torch.where(scores >= self.score_threshold, classes, torch.full_like(classes, -1)).tolist()      # the one read
+        if scores.is_cuda:
+            return self._process_device(inputs, insts, lens, sel)
         start = 0
         for inp, inst, n in zip(inputs, insts, lens):
             mine = sel[start:start + n]
@@ -149,9 +211,57 @@ class DiceEvaluator:
                         bs = torch.maximum(bs, structure_measure_tensor(pm, gm, centroid=cen))
                 self._pending.append(torch.stack((bd, be, bs)) * 100)
 
+    def _process_device(self, inputs, insts, lens, sel):
+        """GPU path: ONE ``ttdg_mask_pair_counts`` launch per mask size for every (kept prediction, same-class GT) pair of
+        the batch, then the closed forms on an (npairs, 12) tensor - instead of ~100 small reductions per mask."""
+        from .. import ops
+        groups = {}                              # (H, W) -> pair lists
+        npred, start = 0, 0
+        for inp, inst, n in zip(inputs, insts, lens):
+            mine = sel[start:start + n]
+            start += n
+            kept = [k for k, c in enumerate(mine) if c >= 0]
+            if not kept:
+                continue
+            masks = inst.pred_masks
+            if masks.dtype != torch.bool or not masks[0].is_contiguous():
+                masks = masks.bool().contiguous()
+            H, W = int(masks.shape[-2]), int(masks.shape[-1])
+            gts = self._gt(inp["image_id"], masks.device, inp.get("dataset_dict"))
+            grp = groups.setdefault((H, W), dict(pp=[], gp=[], cy=[], cx=[], owner=[], rank=[], keep=[]))
+            base, stride = masks.data_ptr(), masks.stride(0)
+            for k in kept:
+                r = 0
+                for gc, gm, cen in gts:
+                    if mine[k] == gc:
+                        if tuple(gm.shape) != (H, W):
+                            raise ValueError("prediction %s and ground truth %s differ in size" % ((H, W), tuple(gm.shape)))
+                        cy, cx = centroid_cuts(cen)
+                        grp["pp"].append(base + k * stride), grp["gp"].append(gm.data_ptr())
+                        grp["cy"].append(cy), grp["cx"].append(cx), grp["owner"].append(npred), grp["rank"].append(r)
+                        r += 1
+                npred += 1
+            grp["keep"].append(masks)            # alive until the launch below is enqueued
+        if npred == 0:
+            return
+        dev = insts[0].scores.device
+        best = torch.zeros(npred, 3, dtype=torch.float64, device=dev)        # a prediction without a same-class GT scores 0
+        for (H, W), grp in groups.items():
+            if not grp["pp"]:
+                continue
+            counts = ops.mask_pair_counts(grp["pp"], grp["gp"], grp["cy"], grp["cx"], H, W, dev)
+            vals = measures_from_counts(counts, H, W, grp["cy"], grp["cx"])
+            owner = torch.tensor(grp["owner"], dtype=torch.int64).to(dev, non_blocking=True)
+            for r in range(max(grp["rank"]) + 1):                              # usually one GT per class: a single pass
+                idx = [i for i, x in enumerate(grp["rank"]) if x == r]
+                it = owner if len(idx) == len(grp["rank"]) else owner[torch.tensor(idx, dtype=torch.int64).to(dev, non_blocking=True)]
+                vr = vals if len(idx) == len(grp["rank"]) else vals[torch.tensor(idx, dtype=torch.int64).to(dev, non_blocking=True)]
+                best[it] = torch.maximum(best[it], vr)
+        self._pending.append(best * 100)
+
     def _flush(self):
         if self._pending:
-            vals = torch.stack(self._pending).cpu().tolist()
+            vals = torch.cat([v.reshape(-1, 3) for v in self._pending]).cpu().tolist()
             self._pending = []
             for d, e, s in vals:
                 self.dice_scores.append(d), self.ea_scores.append(e), self.sm_scores.append(s)

@@ -256,15 +256,19 @@ class StandardROIHeadsPseudoLab(nn.Module):
         return c
 
     @torch.no_grad()
-    def box_dense(self, features, boxes, scores, keep, image_sizes):
-        """Box head on the RPN's dense output (boxes (B, K, 4), scores (B, K), keep (B, post) by descending score; slots
-        beyond an image's proposal count carry score -inf and yield no detection).  Returns the detections padded to
-        ``topk`` per image: boxes (B, topk, 4), scores (B, topk) (-inf = empty slot), classes (B, topk), counts (B,) device."""
+    def box_dense(self, features, boxes, scores, keep, image_sizes, counts=None):
+        """Box head on the RPN's dense output (boxes (B, K, 4), scores (B, K), keep (B, post) by descending score, counts (B,)
+        = proposals per image: the slots of ``keep`` beyond an image's count are padding - they point at candidates the NMS
+        suppressed - and yield no detection).  Returns the detections padded to ``topk`` per image: boxes (B, topk, 4),
+        scores (B, topk) (-inf = empty slot), classes (B, topk), counts (B,) device."""
         C, dev = self.num_classes, boxes.device
         B, post = keep.shape
         feats = [features[f].detach() for f in self.box_in_features]
         pb = boxes.gather(1, keep[..., None].expand(-1, -1, 4))
         ps = scores.gather(1, keep)
+        if counts is not None:
+            slot = self._const(("slot", post, str(dev)), lambda: torch.arange(post, device=dev))
+            ps = torch.where(slot[None, :] < counts[:, None].to(dev), ps, ps.new_full((), float("-inf")))
         img = self._const(("img", B, post, str(dev)), lambda: torch.arange(B, device=dev, dtype=torch.float32).repeat_interleave(post)[:, None])
         rois = torch.cat((img, pb.reshape(-1, 4)), 1)
         logits, deltas = self.box_predictor(self.box_head(self.box_pooler(feats, None, rois)))
@@ -274,17 +278,20 @@ class StandardROIHeadsPseudoLab(nn.Module):
         col_cls = self._const(("cls", post, C, str(dev)), lambda: torch.arange(post * C, device=dev, dtype=torch.int64) % C)
         cbv, csv = cb.view(B, post * C, 4), cs.view(B, post * C)
         didx, dcounts = _backend.nms_batched(cbv, csv, col_cls, C, self.nms_thresh, post, self.topk, device_counts=True)
-        dscores = csv.gather(1, didx)
-        live = dscores > float("-inf")
+        # slots beyond an image's detection count are padding (they point at suppressed candidates): liveness comes from the
+        # count, never from the gathered score
+        tslot = self._const(("slot", didx.shape[1], str(dev)), lambda: torch.arange(didx.shape[1], device=dev))
+        live = tslot[None, :] < dcounts[:, None].to(dev)
+        dscores = torch.where(live, csv.gather(1, didx), csv.new_full((), float("-inf")))
         dboxes = torch.where(live[..., None], cbv.gather(1, didx[..., None].expand(-1, -1, 4)), cbv.new_zeros(()))
         return dboxes, dscores, didx % C, dcounts
 
     @torch.no_grad()
-    def inference_dense(self, features, boxes, scores, keep, image_sizes, out_size, mask_threshold=0.5):
+    def inference_dense(self, features, boxes, scores, keep, image_sizes, out_size, mask_threshold=0.5, counts=None):
         """Whole eval-mode ROI stage + detector_postprocess on padded tensors, ONE host read at the end.  All images share
         the output size `out_size` (H, W).  Returns the per-image Instances of detector_postprocess."""
         dev = boxes.device
-        dboxes, dscores, dcls, _ = self.box_dense(features, boxes, scores, keep, image_sizes)
+        dboxes, dscores, dcls, _ = self.box_dense(features, boxes, scores, keep, image_sizes, counts)
         B, T = dscores.shape
         feats = [features[f].detach() for f in self.mask_in_features]
         img = self._const(("img", B, T, str(dev)), lambda: torch.arange(B, device=dev, dtype=torch.float32).repeat_interleave(T)[:, None])

@@ -95,11 +95,11 @@ class DAobjTwoStagePseudoLabGeneralizedRCNN(nn.Module):
                         side = _SIDE_STREAMS[images.tensor.device] = torch.cuda.Stream(device=images.tensor.device)
                     side.wait_stream(cur)
                     with torch.cuda.stream(side):
-                        boxes, scores, keep, _ = self.proposal_generator.forward_dense(features, images.image_sizes)
-                        side_out = self.roi_heads.box_dense(features, boxes, scores, keep, images.image_sizes)      # alive until the join
+                        boxes, scores, keep, pcounts = self.proposal_generator.forward_dense(features, images.image_sizes)
+                        side_out = self.roi_heads.box_dense(features, boxes, scores, keep, images.image_sizes, pcounts)      # alive until the join
                 else:
-                    boxes, scores, keep, _ = self.proposal_generator.forward_dense(features, images.image_sizes)
-                    dboxes, dscores, dcls, dcounts = self.roi_heads.box_dense(features, boxes, scores, keep, images.image_sizes)
+                    boxes, scores, keep, pcounts = self.proposal_generator.forward_dense(features, images.image_sizes)
+                    dboxes, dscores, dcls, dcounts = self.roi_heads.box_dense(features, boxes, scores, keep, images.image_sizes, pcounts)
                 if self.teacher_forced:
                     proposals_roih = [self._forced(x, sz) for x, sz in zip(batched_inputs, images.image_sizes)]
                 else:
@@ -146,8 +146,8 @@ class DAobjTwoStagePseudoLabGeneralizedRCNN(nn.Module):
         out_sizes = [(x.get("height", sz[0]), x.get("width", sz[1])) for x, sz in zip(batched_inputs, images.image_sizes)]
         if do_postprocess and DENSE_INFERENCE and len(set(out_sizes)) == 1:
             # padded tensors from the RPN to the pasted masks: one host read per batch instead of four
-            boxes, scores, keep, _ = self.proposal_generator.forward_dense(features, images.image_sizes)
-            res = self.roi_heads.inference_dense(features, boxes, scores, keep, images.image_sizes, out_sizes[0])
+            boxes, scores, keep, pcounts = self.proposal_generator.forward_dense(features, images.image_sizes)
+            res = self.roi_heads.inference_dense(features, boxes, scores, keep, images.image_sizes, out_sizes[0], counts=pcounts)
             return [{"instances": r} for r in res]
         proposals, _ = self.proposal_generator(images, features, None, compute_loss=False)
         results, _ = self.roi_heads(images, features, proposals, None, compute_loss=False, branch="")

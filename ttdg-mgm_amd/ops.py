@@ -662,6 +662,20 @@ def paste_masks(masks, boxes, H, W, threshold=0.5):
     return out.view(torch.bool)
 
 
+def mask_pair_counts(pred_ptrs, gt_ptrs, cy, cx, H, W, device):
+    """(npairs, 12) int32 quadrant counts {n(p&g), n(p), n(g)} x 4 for pairs of H x W byte masks given by device address
+    (DiceEvaluator; dice_metric.py:25-92).  ``pred_ptrs`` / ``gt_ptrs`` / ``cy`` / ``cx``: python int lists, uploaded as one
+    small table.  The caller keeps the mask tensors alive until the stream has consumed them."""
+    n = len(pred_ptrs)
+    counts = torch.empty(n, 12, device=device, dtype=torch.int32)
+    if n == 0:
+        return counts
+    table = torch.tensor([pred_ptrs, gt_ptrs], dtype=torch.int64).to(device, non_blocking=True)
+    cuts = torch.tensor([cy, cx], dtype=torch.int32).to(device, non_blocking=True)
+    call("ttdg_mask_pair_counts", ptr(table), ptr(table) + 8 * n, ptr(cuts), ptr(cuts) + 4 * n, n, int(H), int(W), ptr(counts), stream())
+    return counts
+
+
 def nms(boxes, scores, thr, group=None):
     """Greedy NMS; returns kept indices (into the input order) sorted by descending score."""
     ng = None if group is None else int(group.max().item()) + 1 if group.numel() else 1
