@@ -155,6 +155,7 @@ def timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, w
     model.teacher_forced = teacher_forced
     opt = BaselineTrainer.build_optimizer(cfg, model)
     dice = DiceEvaluator(name, cfg.TEST.DICE_THRES, dataset_dicts=local_dicts)
+    dice.prestage(device)              # the evaluator's inputs (ground-truth masks) are resident in HBM like the images
 
     def adapt(bs):
         n = 0
@@ -469,7 +470,7 @@ def gpu_main(args, rank, world, local):
         ab["loader_inclusive"] = short(
             timed_pass(cfg, model, init_state, batches, local_dicts + sd, name, K, W, args, world, device, tf, loader_factory=stream),
             "timed batches stream through the test loader (image synthesis standing for decode, resize 512->800, pinned H2D; 2-deep prefetch) in both passes")
-    if world == 1 and args.weights == "trained":
+    if world == 1 and args.weights == "trained" and not args.no_cpu_baseline:
         note("Dice parity leg (GPU)")
         parity = {"gpu": gpu_dice_parity_leg(cfg, model, init_state, batches[0], local_dicts, name, tf)}
 

@@ -304,11 +304,20 @@ def source_batches(cfg, n_images, size, device, name="synthfundus_source"):
 
 
 def train_source(model, batches, steps, lr=0.01, warmup=50, matching_weight=1.0, seed=0, log=None, train_all=False,
-                 unsup_weight=20.0, rois_per_image=256, matching_lr=1e-3, probe=None, probe_every=0, profile=False, roi_grad=False):
+                 unsup_weight=20.0, rois_per_image=256, matching_lr=1e-3, probe=None, probe_every=0, profile=False, roi_grad=False,
+                 feat_reg=0.02, ttt_weight=1.0, ttt_from=0.5):
     """Stage 1.  SGD (momentum 0.9, wd 1e-4, linear warm-up, cosine decay), gradient-norm clip 10.
     Matching terms on nodes sampled inside the GT boxes (rcnn.py:262-266): ``matching_weight`` x the universe loss of
     ``multi_matching_sup`` (:136-169) and ``unsup_weight`` x the permutation loss of ``multi_matching_unsup`` (:560-564),
-    both against the universe labels of UniverseLabels instead of solver output."""
+    both against the universe labels of UniverseLabels instead of solver output.
+    ``feat_reg`` x mean(node feature^2): a from-scratch FPN on un-normalised inputs produces node features of norm ~100, so
+    that U0 = X U^T is O(10^2..10^3), the solver's first V (cubic in U0) O(10^9) and its first projection a hard assignment
+    decided by fp32 rounding - in the reference as much as here.  The regulariser (and the unit-norm universe rows set in
+    ``make``) keep the synthetic model where the solve is well conditioned.
+    ``ttt_weight`` x the FREE-RUNNING adaptation loss itself (solver pseudo-labels, exactly what a TTA step minimises) from
+    fraction ``ttt_from`` of the schedule on: the detector heads are fitted on features that already sit near a stationary
+    point of the adaptation loss, so that later TTA steps (which move the backbone but not the heads) do
+    not push the detections under the 0.9 score threshold of the Dice evaluator."""
     from ttdg_mgm_amd.modeling.structures import Boxes, Instances
     dev = model.device
     gen = torch.Generator(device=dev)
@@ -373,6 +382,10 @@ def train_source(model, batches, steps, lr=0.01, warmup=50, matching_weight=1.0,
             if unsup_weight > 0:
                 l_perm = model.multi_matching_unsup(nodes, labels, model.multi_matching_sup.U, forced_U=Ugt)
                 loss = loss + unsup_weight * l_perm
+            if feat_reg > 0:
+                loss = loss + feat_reg * torch.cat(nodes).square().mean()
+            if ttt_weight > 0 and step >= ttt_from * steps:
+                loss = loss + ttt_weight * model.multi_matching_unsup(nodes, labels, model.multi_matching_sup.U)
         tt = tick("matching_fwd", tt)
         opt.zero_grad(set_to_none=True)
         mopt.zero_grad(set_to_none=True)
@@ -386,7 +399,8 @@ def train_source(model, batches, steps, lr=0.01, warmup=50, matching_weight=1.0,
             log("probe after %d steps: %s" % (step + 1, probe(model)))
             model.train()
         if log is not None and (step % 25 == 0 or step == steps - 1):
-            rec = dict(step=step, loss=float(loss.detach()), rpn_cls=float(l_obj.detach()), rpn_loc=float(l_loc.detach()), cls=float(l_cls.detach()), box=float(l_box.detach()),
+            xn = float(torch.cat(nodes).detach().norm(dim=1).mean()) if (matching_weight > 0 or unsup_weight > 0) else None
+            rec = dict(step=step, node_norm=xn, loss=float(loss.detach()), rpn_cls=float(l_obj.detach()), rpn_loc=float(l_loc.detach()), cls=float(l_cls.detach()), box=float(l_box.detach()),
                        mask=float(l_mask.detach()), matching=None if l_match is None else float(l_match.detach()),
                        perm=None if l_perm is None else float(l_perm.detach()))
             hist.append(rec)
@@ -452,6 +466,8 @@ def make(cfg, device, steps=600, tta_steps=16, n_images=64, size=512, lr=0.01, s
     model = BaselineTrainer.build_model(cfg)
     batches = source_batches(cfg, n_images, size, device)
     calibrate_frozen_bn(model, batches[0])
+    with torch.no_grad():       # unit-norm universe rows (the reference's init, randn + 1/32 over 256 dims, has norm 16): see train_source
+        model.multi_matching_sup.U.div_(model.multi_matching_sup.U.norm(dim=1, keepdim=True))
     hist = train_source(model, batches, steps, lr=lr, seed=seed, log=log, train_all=train_all, matching_weight=matching_weight,
                         unsup_weight=unsup_weight, matching_lr=matching_lr, probe=probe, probe_every=probe_every, profile=profile,
                         roi_grad=roi_grad)

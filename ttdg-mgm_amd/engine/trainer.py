@@ -186,6 +186,8 @@ class BaselineTrainer:
                 dice = evaluators[idx]
             elif cls.resident_inputs:
                 dice = DiceEvaluator(dataset_name, cfg.TEST.DICE_THRES, dataset_dicts=data_loader.dataset_dicts)   # ground truth of the local shard
+                if cls.device is not None and torch.device(cls.device).type == "cuda":
+                    dice.prestage(cls.device)
             else:
                 dice = DiceEvaluator(dataset_name, cfg.TEST.DICE_THRES, lazy=True)      # ground truth travels with every streamed item
             results_i, _ = inference_on_dataset(model, data_loader, dice, cfg)

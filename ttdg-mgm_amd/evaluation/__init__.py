@@ -164,21 +164,52 @@ class DiceEvaluator:
         self.dice_scores, self.ea_scores, self.sm_scores = [], [], []
         self._pending = []
 
+    @staticmethod
+    def _centroid(m):
+        """(mean row, mean column) of the set pixels of a boolean map - what dice_metric.py:196-200 derives from the GT -
+        from the row / column histograms (exact: integer sums), NaN for an empty map."""
+        rows, cols = m.sum(1, dtype=torch.int64), m.sum(0, dtype=torch.int64)
+        cnt = int(rows.sum())
+        if cnt == 0:
+            return float("nan"), float("nan")
+        return (float((rows * torch.arange(m.shape[0])).sum()) / cnt, float((cols * torch.arange(m.shape[1])).sum()) / cnt)
+
     def _gt(self, image_id, dev, record=None):
         key = (image_id, str(dev))
         if key not in self._gt_cache:
-            out = []
             if record is None:
                 record = self._by_id[image_id]
             while len(self._gt_cache) >= self.GT_CACHE_IMAGES:
                 self._gt_cache.pop(next(iter(self._gt_cache)))
-            for a in record["annotations"]:
-                m = a["mask"]
-                ys, xs = torch.nonzero(m, as_tuple=True)
-                cen = (ys.double().mean().item(), xs.double().mean().item()) if ys.numel() else (float("nan"), float("nan"))
-                out.append((a["category_id"], m.to(dev), cen))
-            self._gt_cache[key] = out
+            anns = record["annotations"]
+            cens = [self._centroid(a["mask"]) for a in anns]
+            dm = torch.stack([a["mask"] for a in anns]).to(dev, non_blocking=True) if anns else None      # one upload per image
+            self._gt_cache[key] = [(a["category_id"], dm[k], cens[k]) for k, a in enumerate(anns)]
         return self._gt_cache[key]
+
+    def prestage(self, device):
+        """Upload the ground truth of the whole (resident) shard in ONE copy and cache centroids: the evaluator's inputs are
+        then resident in HBM like the images (bench.py, BaselineTrainer.test with resident inputs).  A shard larger than
+        the cache bound raises the bound: resident means resident."""
+        if not self.dataset_dicts:
+            return
+        recs = [d for d in self.dataset_dicts if d["annotations"]]
+        self.GT_CACHE_IMAGES = max(self.GT_CACHE_IMAGES, len(self.dataset_dicts) + 1)
+        by_shape = {}
+        for d in recs:
+            by_shape.setdefault(tuple(d["annotations"][0]["mask"].shape), []).append(d)
+        for shape, ds in by_shape.items():
+            flat = [a["mask"] for d in ds for a in d["annotations"]]
+            if any(tuple(m.shape) != shape for m in flat):
+                continue                                     # mixed sizes inside an image: staged lazily
+            dm = torch.stack(flat).to(device)
+            k = 0
+            for d in ds:
+                out = []
+                for a in d["annotations"]:
+                    out.append((a["category_id"], dm[k], self._centroid(a["mask"])))
+                    k += 1
+                self._gt_cache[(d["image_id"], str(torch.device(device)))] = out
 
     def process(self, inputs, outputs):
         """Enqueues everything on the device; ONE host read per batch (which predictions pass the score threshold and their
