@@ -66,6 +66,7 @@ def parse(argv=None):
     ap.add_argument("--sync-universe", action="store_true",
                     help="Mode S (SURVEY.md 8e): all ranks adapt on ONE multi-graph (RCCL all-gather of the node embeddings, gradient "
                          "all-reduce) = the single-GPU algorithm at batch N*B; default is Mode R (independent shards, as the reference)")
+    ap.add_argument("--gagm-threads", type=int, default=0, help="A/B: workgroup size of the single-workgroup solver (256 / 512; 0 = automatic)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch, rendezvous, sharding and the collectives of the bench without any GPU work (CPU test of --gpus N)")
     a = ap.parse_args(argv)
@@ -418,6 +419,9 @@ def gpu_main(args, rank, world, local):
     from ttdg_mgm_amd import ops as _ops
     from ttdg_mgm_amd.modeling import detector as _det
     assert _det._backend is _ops, "the GPU legs must run on the HIP operators (detector._backend was re-pointed)"
+    if args.gagm_threads:
+        from ttdg_mgm_amd import _lib
+        _lib.load().ttdg_debug_set_gagm_threads(args.gagm_threads)
     if args.images:
         # strong scaling: the FIXED stream is sharded; warm-up batches come from another stream so that the timed work is
         # exactly args.images images whatever the rank count

@@ -3,10 +3,10 @@ whole-run stats of the hand-written kernels (from *_kernel_stats.csv) + steady-s
 import csv, sys, subprocess, os
 stats, trace, warm, out = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
 OURS = ("gagm_", "affinity_", "sinkhorn_", "mha_adj", "perm_loss", "node_", "sgd_multi", "gemm_f32", "gemm_splitk", "colsum", "nms_", "roi_align",
-        "lap_batched", "rpn_decode", "box_inference", "paste_masks", "bias_act", "dice_", "emeasure", "smeasure")
+        "lap_batched", "rpn_decode", "box_inference", "paste_masks", "bias_act", "mask_pair_counts")
 rows = list(csv.DictReader(open(stats)))
 with open(out, "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline  (MI355X, gfx950)\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 4 --warmup 2 --no-ab --no-cpu-baseline  (MI355X, gfx950; trained-regime checkpoint, free-running)\n")
     f.write("# hand-written kernels (libttdg_mgm.so), whole run incl. warm-up; durations in ns\n")
     f.write("%-64s %7s %14s %12s\n" % ("kernel", "calls", "total_ns", "avg_ns"))
     for r in rows:

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
   float* X = base + SB;
   float* V = base + 2 * SB;
   float* Uprev_g = base + 3 * SB;             // used only when !kLds
-  constexpr int UPK = 16;
+  constexpr int UPK = 8192 / GA_THREADS;     // lastU2 values per thread: covers M * 32 <= 8192
   float uprev[UPK];
 #pragma unroll
   for (int k = 0; k < UPK; ++k) uprev[k] = 0.f;
@@ -621,6 +621,8 @@ int ttdg_gagm_large_solve(const float* Apack, const float* W, const float* U0, t
 // the single workgroup streams the M x M matrix W once per iteration, which stops paying once W has left LDS and the
 // per-iteration W U product outgrows one CU (Mode S: the gathered multi-graph of 8 ranks is ~1000 nodes)
 static int g_gagm_large_from = GAGM_LARGE_FROM_DEFAULT;
+static int g_gagm_threads = 0;   // 0 = automatic (256 threads for <= 4 graphs, else 512); 256 / 512 force a size (A/B runs)
+extern "C" int ttdg_debug_set_gagm_threads(int threads) { g_gagm_threads = (threads == 256 || threads == 512) ? threads : 0; return 0; }
 extern "C" int ttdg_debug_set_gagm_large_from(int total_nodes) { g_gagm_large_from = total_nodes > 0 ? total_nodes : GAGM_LARGE_FROM_DEFAULT; return 0; }
 
 extern "C" size_t ttdg_gagm_workspace_bytes(int M) {
@@ -646,21 +648,30 @@ extern "C" int ttdg_gagm_solve(const float* Apack, const float* W, const float* 
   TTDG_LIMIT(gr.off[gr.G] <= 4096, "gagm: more than 4096 nodes in total");
   const int cmaxp = (cmax + 63) & ~63;
   const int M = gr.off[gr.G], Mp = ga_mp(M);
-  const int waves = 8;
+  // 256 threads (one wavefront per SIMD, the whole 512-VGPR file each) when there are at most four graphs to project:
+  // with 512 threads the 256-VGPR cap makes the kernel spill ~100 VGPRs at its phase boundaries
+  // (graphs of 65..128 nodes, CWMAX 2, keep 512 threads: their two-columns-per-lane projector does not fit either way)
+  const int threads = (cmax <= 64 && (g_gagm_threads == 256 || (g_gagm_threads == 0 && gr.G <= 4))) ? 256 : 512;
+  const int waves = threads / 64;
   const int cw = cmax <= 64 ? 1 : 2;
   const size_t fixed = ga_fixed_lds_bytes(cmaxp, waves, cw, M);
   const size_t state = (size_t)3 * NU * (Mp + 1) * sizeof(float);
   const size_t wb = (size_t)M * Mp * sizeof(float), ab = (size_t)((asz + 3) & ~3) * sizeof(float);
   const size_t cap = 158 * 1024;
   // what fits decides what is staged: state, then W^T (largest per-iteration reader), then the A blocks
-  const bool regs_ok = (size_t)M * NU <= (size_t)16 * 512;   // lastU2 in registers: 16 values per thread
+  const bool regs_ok = (size_t)M * NU <= (size_t)8192;   // lastU2 in registers: 8192 / threads values per thread
   const int mode = !regs_ok ? 0 : (fixed + state + wb + ab <= cap) ? 3 : (fixed + state + wb <= cap) ? 2 : (fixed + state <= cap) ? 1 : 0;
   const size_t bytes = fixed + (mode >= 1 ? state : 0) + (mode >= 2 ? wb : 0) + (mode >= 3 ? ab : 0);
   hipStream_t st = (hipStream_t)stream;
-#define GA_LAUNCH(L, WL, AL, C)                                                                                      \
+#define GA_LAUNCH_T(L, WL, AL, C, T)                                                                                 \
   do {                                                                                                               \
-    TTDG_ALLOW_LDS((gagm_kernel<L, WL, AL, 512, C>), bytes);                                                         \
-    hipLaunchKernelGGL((gagm_kernel<L, WL, AL, 512, C>), dim3(1), dim3(512), bytes, st, Apack, W, U0, gr, cfg, U, info, (float*)ws, cmaxp); \
+    TTDG_ALLOW_LDS((gagm_kernel<L, WL, AL, T, C>), bytes);                                                           \
+    hipLaunchKernelGGL((gagm_kernel<L, WL, AL, T, C>), dim3(1), dim3(T), bytes, st, Apack, W, U0, gr, cfg, U, info, (float*)ws, cmaxp); \
+  } while (0)
+#define GA_LAUNCH(L, WL, AL, C)                                          \
+  do {                                                                   \
+    if (C == 1 && threads == 256) GA_LAUNCH_T(L, WL, AL, 1, 256);        \
+    else GA_LAUNCH_T(L, WL, AL, C, 512);                                 \
   } while (0)
 #define GA_MODES(C)                                             \
   do {                                                          \
@@ -672,6 +683,7 @@ extern "C" int ttdg_gagm_solve(const float* Apack, const float* W, const float* 
   if (cw == 1) GA_MODES(1); else GA_MODES(2);
 #undef GA_MODES
 #undef GA_LAUNCH
+#undef GA_LAUNCH_T
   return ttdg_launch_status("gagm");
 }
 

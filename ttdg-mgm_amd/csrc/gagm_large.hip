@@ -371,11 +371,71 @@ __device__ __forceinline__ void gl_project_cols(const float* vl, int n, float sc
   }
 }
 
-__global__ __launch_bounds__(GL_PTHREADS) void gagm_large_project_kernel(ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg, GlWs w, int t) {
+// After the projection of graph g: the G == 2 identity pin (:358-359), the graph's two squared norms for the stage
+// machine (:361) and - Hungarian stage - its state code + hash for the cycle shortcut (gl_control).
+template <int THREADS>
+__device__ __forceinline__ void gl_finish_projection(const ttdg_graphs_t& gr, const ttdg_gagm_cfg_t& cfg, const GlWs& w, const GlCtl& s_c,
+                                                     int g, float* Unew, const float* Ucur, const float* Uprev, bool hung) {
+  __shared__ float s_red[2 * (THREADS / 64)];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, G = gr.G, M = w.M;
+  const int o = gr.off[g], n = gr.off[g + 1] - o;
+  const int total = s_c.total;
+  if (G == 2 && g == 0) {   // :358-359
+    for (int e = tid; e < n * NU; e += THREADS) Unew[e] = ((e >> 5) == (e & 31)) ? 1.f : 0.f;
+    __syncthreads();
+  }
+  float d1 = 0.f, d2 = 0.f;
+  for (int e = tid; e < n * NU; e += THREADS) {
+    const float un = Unew[e], a = un - Ucur[e], b = un - Uprev[e];
+    d1 = fmaf(a, a, d1);
+    d2 = fmaf(b, b, d2);
+    if (total == 0) w.U1[(size_t)o * NU + e] = un;
+  }
+  d1 = wave_sum(d1); d2 = wave_sum(d2);
+  if (lane == 0) { s_red[2 * wave] = d1; s_red[2 * wave + 1] = d2; }
+  __syncthreads();
+  if (tid == 0) {
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < THREADS / 64; ++k) { a += s_red[2 * k]; b += s_red[2 * k + 1]; }
+    w.dn[2 * g] = a;
+    w.dn[2 * g + 1] = b;
+  }
+  if (hung && !cfg.no_cycle_skip && s_c.it < GL_HIST) {   // state code + hash for the cycle shortcut (gl_control)
+    __shared__ unsigned long long s_h[THREADS / 64];
+    unsigned long long hx = 0ull;
+    for (int r = tid; r < n; r += THREADS) {
+      int code = 255;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) if (Unew[r * NU + u] != 0.f) code = u;
+      w.hist[(size_t)s_c.it * M + o + r] = (unsigned char)code;
+      unsigned long long z = (unsigned long long)((o + r) * 256 + code) + 0x9E3779B97F4A7C15ull;     // splitmix64
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      hx ^= z ^ (z >> 31);
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) {
+      const unsigned lo = __shfl_xor((unsigned)hx, sft, 64), hi = __shfl_xor((unsigned)(hx >> 32), sft, 64);
+      hx ^= ((unsigned long long)hi << 32) | lo;
+    }
+    if (lane == 0) s_h[wave] = hx;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long h = 0ull;
+      for (int k = 0; k < THREADS / 64; ++k) h ^= s_h[k];
+      w.hg[g] = h;
+    }
+  }
+}
+
+// PT threads: 512 when every graph has <= 512 nodes (2 wavefronts per SIMD: a 256-VGPR budget - with 1024 threads the
+// 128-VGPR cap made the register-resident Sinkhorn column + its 33 partial lines spill into scratch inside the sweep
+// loop), 1024 for graphs of 513..768 nodes (one column per thread).
+template <int PT>
+__global__ __launch_bounds__(PT) void gagm_large_project_kernel(ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg, GlWs w, int t) {
   extern __shared__ __attribute__((aligned(16))) float gl_smem[];
   __shared__ __attribute__((aligned(16))) float s_S[NU * NU];
-  __shared__ __attribute__((aligned(16))) float s_brow[(GL_PTHREADS / 64) * 64];
-  __shared__ float s_red[2 * (GL_PTHREADS / 64)];
+  __shared__ __attribute__((aligned(16))) float s_brow[(PT / 64) * 64];
   __shared__ GlCtl s_c;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, G = gr.G, M = w.M;
   const size_t MU = (size_t)M * NU;
@@ -391,12 +451,13 @@ __global__ __launch_bounds__(GL_PTHREADS) void gagm_large_project_kernel(ttdg_gr
   const float* Uprev = w.ring + (size_t)((total + 2) % 3) * MU + (size_t)o * NU;
 
   const int li = lane & 31, kh = lane >> 5;
-  constexpr int CHUNK = 2 * GL_PWAVES * 8;          // rows per pass of the V loop (256): a wavefront takes two rows at a time
+  constexpr int PW = PT / 64;
+  constexpr int CHUNK = 2 * PW * 8;          // rows per pass of the V loop (256): a wavefront takes two rows at a time
   float bv[8], wu[8];
   // operands of the first V chunk: issued before the S reduction so that both sets of L2 round trips overlap
 #define GL_LOAD_V_OPERANDS(base)                                                                        \
   _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                       \
-    const int i = (base) + j * 2 * GL_PWAVES + wave * 2 + kh;                                            \
+    const int i = (base) + j * 2 * PW + wave * 2 + kh;                                            \
     const bool ok = i < n;                                                                               \
     const size_t idx = (size_t)(o + (ok ? i : 0)) * NU + li;                                             \
     bv[j] = ok ? w.B[idx] : 0.f;                                                                         \
@@ -407,8 +468,7 @@ __global__ __launch_bounds__(GL_PTHREADS) void gagm_large_project_kernel(ttdg_gr
   GL_LOAD_V_OPERANDS(0)
   // S = sum of the tile shares: one element per thread, 16 independent loads in flight per round (the plain
   // accumulate-as-you-go loop pays one L2 round trip per tile)
-  {
-    const int e = tid;      // GL_PTHREADS == NU * NU
+  for (int e = tid; e < NU * NU; e += PT) {
     float acc[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) acc[k] = 0.f;
@@ -433,7 +493,7 @@ __global__ __launch_bounds__(GL_PTHREADS) void gagm_large_project_kernel(ttdg_gr
       if (base > 0) { GL_LOAD_V_OPERANDS(base) }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const int i = base + j * 2 * GL_PWAVES + wave * 2 + kh;
+        const int i = base + j * 2 * PW + wave * 2 + kh;
         br[lane] = bv[j];
         wave_sync();
         float a0 = 0.f, a1 = 0.f;
@@ -474,77 +534,56 @@ __global__ __launch_bounds__(GL_PTHREADS) void gagm_large_project_kernel(ttdg_gr
       gl_project_cols(vl, n, pb.scale, cfg.sk_iter, Unew, gl_smem);
     }
   } else {
-    const bool tr = n > NU;
-    const int nr = tr ? NU : n, nc = tr ? n : NU;
-    for (int e = tid; e < n * NU; e += GL_PTHREADS) Unew[e] = 0.f;       // (V_g is already in the LDS tile)
-    __syncthreads();                                                     // zeros land before wavefront 0 writes the ones
-    if (wave == 0) {
-      if (nc <= 64) {
-        const int b = lap_wave_solve_reg<0, true>(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1);
-        wave_sync();
-        if (lane < nr) { if (tr) Unew[b * NU + lane] = 1.f; else Unew[lane * NU + b] = 1.f; }
-      } else if (nc <= 256) {   // 2 or 4 columns per lane, still register-resident
-        const int b = nc <= 128 ? lap_wave_solve_regw<2>(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1) : lap_wave_solve_regw<4>(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1);
-        wave_sync();
-        if (lane < nr) { if (tr) Unew[b * NU + lane] = 1.f; else Unew[lane * NU + b] = 1.f; }
-      } else {
-        LapScratch sc = lap_carve(vl + ((n * 33 + 3) & ~3), nr, nc);      // behind the V_g tile
-        lap_wave_solve(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1, sc);
-        wave_sync();
-        for (int a = lane; a < nr; a += 64) {
-          const int b = sc.col4row[a];
-          if (tr) Unew[b * NU + a] = 1.f; else Unew[a * NU + b] = 1.f;
-        }
-      }
-    }
+    // Hungarian stage: V_g is in the workspace; the LAP, the norms and the state hash belong to gagm_large_lap_kernel.
+    // (A 1024-thread kernel is limited to 128 VGPRs: compiled in here, the register-resident LAP spilled 44 VGPRs to
+    // scratch inside its per-step chain - 88 us per 32 x 256 LAP.)
+    return;
   }
   __syncthreads();
-  if (G == 2 && g == 0) {   // :358-359
-    for (int e = tid; e < n * NU; e += GL_PTHREADS) Unew[e] = ((e >> 5) == (e & 31)) ? 1.f : 0.f;
-    __syncthreads();
-  }
-  float d1 = 0.f, d2 = 0.f;
-  for (int e = tid; e < n * NU; e += GL_PTHREADS) {
-    const float un = Unew[e], a = un - Ucur[e], b = un - Uprev[e];
-    d1 = fmaf(a, a, d1);
-    d2 = fmaf(b, b, d2);
-    if (total == 0) w.U1[(size_t)o * NU + e] = un;
-  }
-  d1 = wave_sum(d1); d2 = wave_sum(d2);
-  if (lane == 0) { s_red[2 * wave] = d1; s_red[2 * wave + 1] = d2; }
+  gl_finish_projection<PT>(gr, cfg, w, s_c, g, Unew, Ucur, Uprev, false);
+}
+
+// One wavefront per graph, 64 threads = the whole 512-VGPR file: the scipy-exact LAP of the Hungarian stage
+// (utils/hungarian.py:8-66 inside multi_graph_matching.py:324-328), then the graph's norms and state hash.
+__global__ __launch_bounds__(64) void gagm_large_lap_kernel(ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg, GlWs w, int t) {
+  extern __shared__ __attribute__((aligned(16))) float gl_lap_smem[];
+  __shared__ GlCtl s_c;
+  const int lane = threadIdx.x, M = w.M;
+  const size_t MU = (size_t)M * NU;
+  if (lane == 0) s_c = w.ctl[(t + 1) & 1];
   __syncthreads();
-  if (tid == 0) {
-    float a = 0.f, b = 0.f;
-    for (int k = 0; k < GL_PTHREADS / 64; ++k) { a += s_red[2 * k]; b += s_red[2 * k + 1]; }
-    w.dn[2 * g] = a;
-    w.dn[2 * g + 1] = b;
-  }
-  if (hung && !cfg.no_cycle_skip && s_c.it < GL_HIST) {   // state code + hash for the cycle shortcut (gl_control)
-    __shared__ unsigned long long s_h[GL_PTHREADS / 64];
-    unsigned long long hx = 0ull;
-    for (int r = tid; r < n; r += GL_PTHREADS) {
-      int code = 255;
-#pragma unroll
-      for (int u = 0; u < NU; ++u) if (Unew[r * NU + u] != 0.f) code = u;
-      w.hist[(size_t)s_c.it * M + o + r] = (unsigned char)code;
-      unsigned long long z = (unsigned long long)((o + r) * 256 + code) + 0x9E3779B97F4A7C15ull;     // splitmix64
-      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-      hx ^= z ^ (z >> 31);
-    }
-#pragma unroll
-    for (int sft = 32; sft > 0; sft >>= 1) {
-      const unsigned lo = __shfl_xor((unsigned)hx, sft, 64), hi = __shfl_xor((unsigned)(hx >> 32), sft, 64);
-      hx ^= ((unsigned long long)hi << 32) | lo;
-    }
-    if (lane == 0) s_h[wave] = hx;
-    __syncthreads();
-    if (tid == 0) {
-      unsigned long long h = 0ull;
-      for (int k = 0; k < GL_PTHREADS / 64; ++k) h ^= s_h[k];
-      w.hg[g] = h;
+  if (s_c.done || !s_c.hung) return;
+  const int total = s_c.total;
+  const int g = blockIdx.x, o = gr.off[g], n = gr.off[g + 1] - o;
+  const float* Ucur = w.ring + (size_t)(total % 3) * MU + (size_t)o * NU;
+  float* Unew = w.ring + (size_t)((total + 1) % 3) * MU + (size_t)o * NU;
+  const float* Uprev = w.ring + (size_t)((total + 2) % 3) * MU + (size_t)o * NU;
+  const float* Vg = w.V + (size_t)o * NU;
+  float* vl = gl_lap_smem;                      // V_g tile, row stride 33: row and column walks are both conflict-free
+  for (int e = lane; e < n * NU; e += 64) { vl[(e >> 5) * 33 + (e & 31)] = Vg[e]; Unew[e] = 0.f; }
+  __syncthreads();
+  const bool tr = n > NU;
+  const int nr = tr ? NU : n, nc = tr ? n : NU;
+  if (nc <= 64) {
+    const int b = lap_wave_solve_reg<0, true>(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1);
+    wave_sync();
+    if (lane < nr) { if (tr) Unew[b * NU + lane] = 1.f; else Unew[lane * NU + b] = 1.f; }
+  } else if (nc <= 256) {   // 2 or 4 columns per lane, register-resident
+    const int b = nc <= 128 ? lap_wave_solve_regw<2>(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1) : lap_wave_solve_regw<4>(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1);
+    wave_sync();
+    if (lane < nr) { if (tr) Unew[b * NU + lane] = 1.f; else Unew[lane * NU + b] = 1.f; }
+  } else {
+    LapScratch sc = lap_carve(vl + ((n * 33 + 3) & ~3), nr, nc);      // behind the V_g tile
+    lap_wave_solve(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1, sc);
+    wave_sync();
+    for (int a = lane; a < nr; a += 64) {
+      const int b = sc.col4row[a];
+      if (tr) Unew[b * NU + a] = 1.f; else Unew[a * NU + b] = 1.f;
     }
   }
+  __threadfence_block();
+  __syncthreads();
+  gl_finish_projection<64>(gr, cfg, w, s_c, g, Unew, Ucur, Uprev, true);
 }
 
 // control word after `t` enqueued iterations -> w.res (what the host polls)
@@ -586,8 +625,11 @@ int ttdg_gagm_large_solve(const float* Apack, const float* W, const float* U0, t
   const int r = cmax < NU ? cmax : NU, c = cmax < NU ? NU : cmax;
   // [projector scratch: GL_VL_OFF floats][V_g tile: n x 33][LAP scratch]; the generic Sinkhorn of a < 32-node graph in
   // a large batch (rows = nodes) needs 2*32+1 + 31*33 floats and runs after the tile was consumed (it re-reads V from L2)
-  const size_t bytes = (size_t)(GL_VL_OFF + ((cmax * 33 + 3) & ~3)) * sizeof(float) + lap_scratch_bytes(r, c) + 16;
-  TTDG_ALLOW_LDS(gagm_large_project_kernel, bytes);
+  const size_t bytes = (size_t)(GL_VL_OFF + ((cmax * 33 + 3) & ~3)) * sizeof(float) + 16;
+  const size_t lbytes = (size_t)((cmax * 33 + 3) & ~3) * sizeof(float) + (c > 256 ? lap_scratch_bytes(r, c) : 0) + 16;
+  TTDG_ALLOW_LDS(gagm_large_project_kernel<512>, bytes);
+  TTDG_ALLOW_LDS(gagm_large_project_kernel<1024>, bytes);
+  TTDG_ALLOW_LDS(gagm_large_lap_kernel, lbytes);
   const int M = gr.off[gr.G];
   const int cblocks = (M * NU + 255) / 256 < 256 ? (M * NU + 255) / 256 : 256;
   hipLaunchKernelGGL(gagm_large_init_kernel, dim3(cblocks), dim3(256), 0, st, U0, cfg, w);
@@ -597,7 +639,9 @@ int ttdg_gagm_large_solve(const float* Apack, const float* W, const float* U0, t
   for (;;) {
     for (int k = 0; k < chunk; ++k, ++t) {
       hipLaunchKernelGGL(gagm_large_mul_kernel, dim3(w.ntiles, w.ks + 1), dim3(256), 0, st, Apack, W, gr, cfg, w, t);
-      hipLaunchKernelGGL(gagm_large_project_kernel, dim3(gr.G), dim3(GL_PTHREADS), bytes, st, gr, cfg, w, t);
+      if (cmax <= 512) hipLaunchKernelGGL(gagm_large_project_kernel<512>, dim3(gr.G), dim3(512), bytes, st, gr, cfg, w, t);
+      else hipLaunchKernelGGL(gagm_large_project_kernel<1024>, dim3(gr.G), dim3(1024), bytes, st, gr, cfg, w, t);
+      hipLaunchKernelGGL(gagm_large_lap_kernel, dim3(gr.G), dim3(64), lbytes, st, gr, cfg, w, t);      // returns at once outside the Hungarian stage
     }
     hipLaunchKernelGGL(gagm_large_peek_kernel, dim3(1), dim3(256), 0, st, gr, cfg, w, t);
     if (int e = ttdg_launch_status("gagm_large")) return e;
