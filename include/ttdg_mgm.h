@@ -144,8 +144,8 @@ int ttdg_debug_set_lap_variant(int v);
 /* benchmarking aid: total node count from which ttdg_gagm_solve takes the multi-workgroup solver even though every graph
  * fits the single-workgroup kernel (<= 0 restores the built-in default) */
 int ttdg_debug_set_gagm_large_from(int total_nodes);
-/* A/B hook: workgroup size of the single-workgroup solver (256 or 512; anything else = automatic: 256 threads - one
- * wavefront per SIMD, no register spills - for up to four graphs, 512 beyond). */
+/* A/B hook: workgroup size of the single-workgroup solver (256 = one wavefront per SIMD, no register spills; anything else
+ * = the default 512, which is faster: gagm.hip). */
 int ttdg_debug_set_gagm_threads(int threads);
 /* micro-benchmark hook: `reps` projections (mode 0 Sinkhorn, 1 LAP) of G graphs x n nodes from LDS, one wavefront per
  * graph, as inside ttdg_gagm_solve; ticks[0] receives the shader-cycle count. */

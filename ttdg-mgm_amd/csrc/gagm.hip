@@ -621,7 +621,7 @@ int ttdg_gagm_large_solve(const float* Apack, const float* W, const float* U0, t
 // the single workgroup streams the M x M matrix W once per iteration, which stops paying once W has left LDS and the
 // per-iteration W U product outgrows one CU (Mode S: the gathered multi-graph of 8 ranks is ~1000 nodes)
 static int g_gagm_large_from = GAGM_LARGE_FROM_DEFAULT;
-static int g_gagm_threads = 0;   // 0 = automatic (256 threads for <= 4 graphs, else 512); 256 / 512 force a size (A/B runs)
+static int g_gagm_threads = 0;   // 0 / 512 = the default 512 threads; 256 = the spill-free one-wavefront-per-SIMD build (A/B runs)
 extern "C" int ttdg_debug_set_gagm_threads(int threads) { g_gagm_threads = (threads == 256 || threads == 512) ? threads : 0; return 0; }
 extern "C" int ttdg_debug_set_gagm_large_from(int total_nodes) { g_gagm_large_from = total_nodes > 0 ? total_nodes : GAGM_LARGE_FROM_DEFAULT; return 0; }
 
@@ -648,10 +648,11 @@ extern "C" int ttdg_gagm_solve(const float* Apack, const float* W, const float* 
   TTDG_LIMIT(gr.off[gr.G] <= 4096, "gagm: more than 4096 nodes in total");
   const int cmaxp = (cmax + 63) & ~63;
   const int M = gr.off[gr.G], Mp = ga_mp(M);
-  // 256 threads (one wavefront per SIMD, the whole 512-VGPR file each) when there are at most four graphs to project:
-  // with 512 threads the 256-VGPR cap makes the kernel spill ~100 VGPRs at its phase boundaries
-  // (graphs of 65..128 nodes, CWMAX 2, keep 512 threads: their two-columns-per-lane projector does not fit either way)
-  const int threads = (cmax <= 64 && (g_gagm_threads == 256 || (g_gagm_threads == 0 && gr.G <= 4))) ? 256 : 512;
+  // 512 threads (8 wavefronts).  With the 256-VGPR cap the kernel spills ~100 VGPRs, all at phase boundaries (none inside
+  // the Sinkhorn / LAP loops); the spill-free 256-thread build (one wavefront per SIMD, 440 VGPRs) was measured SLOWER on
+  // the bench (30.2 vs 27.1 us per iteration, 67.9 vs 72.0 images/s): B = A U and the convergence sweep want the eight
+  // wavefronts.  It stays selectable for A/B runs (ttdg_debug_set_gagm_threads).
+  const int threads = (cmax <= 64 && g_gagm_threads == 256) ? 256 : 512;
   const int waves = threads / 64;
   const int cw = cmax <= 64 ? 1 : 2;
   const size_t fixed = ga_fixed_lds_bytes(cmaxp, waves, cw, M);

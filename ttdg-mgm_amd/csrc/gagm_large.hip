@@ -534,56 +534,37 @@ __global__ __launch_bounds__(PT) void gagm_large_project_kernel(ttdg_graphs_t gr
       gl_project_cols(vl, n, pb.scale, cfg.sk_iter, Unew, gl_smem);
     }
   } else {
-    // Hungarian stage: V_g is in the workspace; the LAP, the norms and the state hash belong to gagm_large_lap_kernel.
-    // (A 1024-thread kernel is limited to 128 VGPRs: compiled in here, the register-resident LAP spilled 44 VGPRs to
-    // scratch inside its per-step chain - 88 us per 32 x 256 LAP.)
-    return;
-  }
-  __syncthreads();
-  gl_finish_projection<PT>(gr, cfg, w, s_c, g, Unew, Ucur, Uprev, false);
-}
-
-// One wavefront per graph, 64 threads = the whole 512-VGPR file: the scipy-exact LAP of the Hungarian stage
-// (utils/hungarian.py:8-66 inside multi_graph_matching.py:324-328), then the graph's norms and state hash.
-__global__ __launch_bounds__(64) void gagm_large_lap_kernel(ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg, GlWs w, int t) {
-  extern __shared__ __attribute__((aligned(16))) float gl_lap_smem[];
-  __shared__ GlCtl s_c;
-  const int lane = threadIdx.x, M = w.M;
-  const size_t MU = (size_t)M * NU;
-  if (lane == 0) s_c = w.ctl[(t + 1) & 1];
-  __syncthreads();
-  if (s_c.done || !s_c.hung) return;
-  const int total = s_c.total;
-  const int g = blockIdx.x, o = gr.off[g], n = gr.off[g + 1] - o;
-  const float* Ucur = w.ring + (size_t)(total % 3) * MU + (size_t)o * NU;
-  float* Unew = w.ring + (size_t)((total + 1) % 3) * MU + (size_t)o * NU;
-  const float* Uprev = w.ring + (size_t)((total + 2) % 3) * MU + (size_t)o * NU;
-  const float* Vg = w.V + (size_t)o * NU;
-  float* vl = gl_lap_smem;                      // V_g tile, row stride 33: row and column walks are both conflict-free
-  for (int e = lane; e < n * NU; e += 64) { vl[(e >> 5) * 33 + (e & 31)] = Vg[e]; Unew[e] = 0.f; }
-  __syncthreads();
-  const bool tr = n > NU;
-  const int nr = tr ? NU : n, nc = tr ? n : NU;
-  if (nc <= 64) {
-    const int b = lap_wave_solve_reg<0, true>(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1);
-    wave_sync();
-    if (lane < nr) { if (tr) Unew[b * NU + lane] = 1.f; else Unew[lane * NU + b] = 1.f; }
-  } else if (nc <= 256) {   // 2 or 4 columns per lane, register-resident
-    const int b = nc <= 128 ? lap_wave_solve_regw<2>(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1) : lap_wave_solve_regw<4>(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1);
-    wave_sync();
-    if (lane < nr) { if (tr) Unew[b * NU + lane] = 1.f; else Unew[lane * NU + b] = 1.f; }
-  } else {
-    LapScratch sc = lap_carve(vl + ((n * 33 + 3) & ~3), nr, nc);      // behind the V_g tile
-    lap_wave_solve(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1, sc);
-    wave_sync();
-    for (int a = lane; a < nr; a += 64) {
-      const int b = sc.col4row[a];
-      if (tr) Unew[b * NU + a] = 1.f; else Unew[a * NU + b] = 1.f;
+    // Hungarian stage: one wavefront runs the scipy-exact LAP on the LDS tile of V_g.  (With 1024 threads per workgroup
+    // the 128-VGPR cap made this code spill 44 VGPRs to scratch; the 512-thread build has the registers.  Tried and
+    // dropped in round 2: the LAP as its own 64-thread launch - spill-free too, but the third launch per iteration and
+    // the V_g reload cost more than they saved: 100.8 vs 91.5 us per iteration at 8 x 256.)
+    const bool tr = n > NU;
+    const int nr = tr ? NU : n, nc = tr ? n : NU;
+    for (int e = tid; e < n * NU; e += PT) Unew[e] = 0.f;       // (V_g is already in the LDS tile)
+    __syncthreads();                                                     // zeros land before wavefront 0 writes the ones
+    if (wave == 0) {
+      if (nc <= 64) {
+        const int b = lap_wave_solve_reg<0, true>(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1);
+        wave_sync();
+        if (lane < nr) { if (tr) Unew[b * NU + lane] = 1.f; else Unew[lane * NU + b] = 1.f; }
+      } else if (nc <= 256) {   // 2 or 4 columns per lane, still register-resident
+        const int b = nc <= 128 ? lap_wave_solve_regw<2>(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1) : lap_wave_solve_regw<4>(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1);
+        wave_sync();
+        if (lane < nr) { if (tr) Unew[b * NU + lane] = 1.f; else Unew[lane * NU + b] = 1.f; }
+      } else {
+        LapScratch sc = lap_carve(vl + ((n * 33 + 3) & ~3), nr, nc);      // behind the V_g tile
+        lap_wave_solve(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1, sc);
+        wave_sync();
+        for (int a = lane; a < nr; a += 64) {
+          const int b = sc.col4row[a];
+          if (tr) Unew[b * NU + a] = 1.f; else Unew[a * NU + b] = 1.f;
+        }
+      }
     }
+    __threadfence_block();
   }
-  __threadfence_block();
   __syncthreads();
-  gl_finish_projection<64>(gr, cfg, w, s_c, g, Unew, Ucur, Uprev, true);
+  gl_finish_projection<PT>(gr, cfg, w, s_c, g, Unew, Ucur, Uprev, hung);
 }
 
 // control word after `t` enqueued iterations -> w.res (what the host polls)
@@ -625,11 +606,9 @@ int ttdg_gagm_large_solve(const float* Apack, const float* W, const float* U0, t
   const int r = cmax < NU ? cmax : NU, c = cmax < NU ? NU : cmax;
   // [projector scratch: GL_VL_OFF floats][V_g tile: n x 33][LAP scratch]; the generic Sinkhorn of a < 32-node graph in
   // a large batch (rows = nodes) needs 2*32+1 + 31*33 floats and runs after the tile was consumed (it re-reads V from L2)
-  const size_t bytes = (size_t)(GL_VL_OFF + ((cmax * 33 + 3) & ~3)) * sizeof(float) + 16;
-  const size_t lbytes = (size_t)((cmax * 33 + 3) & ~3) * sizeof(float) + (c > 256 ? lap_scratch_bytes(r, c) : 0) + 16;
+  const size_t bytes = (size_t)(GL_VL_OFF + ((cmax * 33 + 3) & ~3)) * sizeof(float) + lap_scratch_bytes(r, c) + 16;
   TTDG_ALLOW_LDS(gagm_large_project_kernel<512>, bytes);
   TTDG_ALLOW_LDS(gagm_large_project_kernel<1024>, bytes);
-  TTDG_ALLOW_LDS(gagm_large_lap_kernel, lbytes);
   const int M = gr.off[gr.G];
   const int cblocks = (M * NU + 255) / 256 < 256 ? (M * NU + 255) / 256 : 256;
   hipLaunchKernelGGL(gagm_large_init_kernel, dim3(cblocks), dim3(256), 0, st, U0, cfg, w);
@@ -641,7 +620,6 @@ int ttdg_gagm_large_solve(const float* Apack, const float* W, const float* U0, t
       hipLaunchKernelGGL(gagm_large_mul_kernel, dim3(w.ntiles, w.ks + 1), dim3(256), 0, st, Apack, W, gr, cfg, w, t);
       if (cmax <= 512) hipLaunchKernelGGL(gagm_large_project_kernel<512>, dim3(gr.G), dim3(512), bytes, st, gr, cfg, w, t);
       else hipLaunchKernelGGL(gagm_large_project_kernel<1024>, dim3(gr.G), dim3(1024), bytes, st, gr, cfg, w, t);
-      hipLaunchKernelGGL(gagm_large_lap_kernel, dim3(gr.G), dim3(64), lbytes, st, gr, cfg, w, t);      // returns at once outside the Hungarian stage
     }
     hipLaunchKernelGGL(gagm_large_peek_kernel, dim3(1), dim3(256), 0, st, gr, cfg, w, t);
     if (int e = ttdg_launch_status("gagm_large")) return e;
