@@ -42,7 +42,10 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4)
-    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--size", type=int, default=0, help="image side (0 = the workload's: 512 for cfg2, 384 for cfg5)")
+    ap.add_argument("--workload", choices=("cfg2", "cfg5"), default="cfg2",
+                    help="cfg2: 512x512 2-class fundus stream, fp32 (the headline); cfg5: 384x384 3-class polyp stream with the bf16 "
+                         "backbone / fp32 matching split (BASELINE configs[4], here per GPU)")
     ap.add_argument("--images", type=int, default=0,
                     help="strong-scaling mode (cfg-4): a FIXED stream of this many images is sharded over the ranks "
                          "(steps per rank = images / (gpus * batch)); 0 = weak scaling with --steps per rank")
@@ -67,11 +70,16 @@ def parse(argv=None):
                     help="Mode S (SURVEY.md 8e): all ranks adapt on ONE multi-graph (RCCL all-gather of the node embeddings, gradient "
                          "all-reduce) = the single-GPU algorithm at batch N*B; default is Mode R (independent shards, as the reference)")
     ap.add_argument("--gagm-threads", type=int, default=0, help="A/B: workgroup size of the single-workgroup solver (256 / 512; 0 = automatic)")
+    ap.add_argument("--roi-align-flat", action="store_true", help="A/B: the flat (non XCD-sliced) work mapping of the ROIPooler kernel")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch, rendezvous, sharding and the collectives of the bench without any GPU work (CPU test of --gpus N)")
     a = ap.parse_args(argv)
     if a.random_init:
         a.weights = "random"
+    a.kind, a.num_cls, a.stream_id = ("fundus", 2, 2) if a.workload == "cfg2" else ("polyp", 3, 5)
+    if a.workload == "cfg5":
+        a.bf16_backbone = True
+    a.size = a.size or (512 if a.workload == "cfg2" else 384)
     return a
 
 
@@ -82,14 +90,18 @@ def base_cfg(args, device):
     cfg.merge_from_file(os.path.join(ROOT, "configs", "test_segment.yaml"))
     cfg.TEST.BATCH = args.batch
     cfg.MODEL.DEVICE = str(device)
+    cfg.MODEL.ROI_HEADS.NUM_CLASSES = args.num_cls
+    if args.workload == "cfg5":
+        cfg.INPUT.MIN_SIZE_TEST = args.size          # cfg-5 keeps the stream's own 384 x 384 (the reference's polyp configs resize less)
     return cfg
 
 
-def staged_batches(cfg, name, n_images, args, device, rank, world, cfg_id=2, id_offset=0):
+def staged_batches(cfg, name, n_images, args, device, rank, world, cfg_id=None, id_offset=0):
     """The rank's shard of a synthetic stream, mapped (resize to 800) and uploaded: resident in HBM before the timed region."""
     from ttdg_mgm_amd import data
     from ttdg_mgm_amd.engine import BaselineTrainer
-    data.register_synthetic(name, n_images, size=args.size, cfg_id=cfg_id, id_offset=id_offset)
+    data.register_synthetic(name, n_images, size=args.size, cfg_id=args.stream_id if cfg_id is None else cfg_id, id_offset=id_offset,
+                            kind=args.kind, num_cls=args.num_cls)
     BaselineTrainer.rank, BaselineTrainer.world, BaselineTrainer.device = rank, world, device
     BaselineTrainer.resident_inputs = True
     loader = BaselineTrainer.build_test_loader(cfg, name)
@@ -101,6 +113,8 @@ def trained_checkpoint(cfg, args, device, rank, world):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import synth_checkpoint as sc
     kw = {}
+    if args.kind != "fundus":
+        kw["kind"], kw["size"] = args.kind, args.size
     if args.ckpt_steps >= 0:
         kw["steps"] = args.ckpt_steps
     if args.ckpt_tta_steps >= 0:
@@ -256,9 +270,9 @@ def pmc_traffic(stamp_name):
     """HBM bytes per launch from the committed PMC passes of this command (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in
     separate runs -> tools/pmc_summary.py -> profiles/r02_bench_pmc.json).  Counters cannot be read from inside the timed
     process, so this is the recorded figure, not a live one; None when absent."""
-    names = {"gagm": ("gagm_kernel", False), "sgd": ("sgd_multi_tensor", True), "affinity_fwd": ("affinity_fwd_kernel", False),
-             "affinity_bwd": ("affinity_bwd_kernel", False), "sinkhorn_pairs_fwd": ("sinkhorn_pairs_fwd_kernel", False),
-             "sinkhorn_pairs_bwd": ("sinkhorn_pairs_bwd_kernel", False)}
+    names = {"gagm": ("gagm_kernel", False), "sgd": ("sgd_multi_tensor", True), "affinity_fwd": ("affinity_fwd", False),
+             "affinity_bwd": ("affinity_bwd_kernel", False), "sinkhorn_pairs_fwd": ("sinkhorn_pairs_fwd", False),
+             "sinkhorn_pairs_bwd": ("sinkhorn_pairs_bwd", False)}
     kernel, streaming = names[stamp_name]
     for f in ("r02_bench_pmc.json", "r01_bench_pmc.json"):
         try:
@@ -419,14 +433,15 @@ def gpu_main(args, rank, world, local):
     from ttdg_mgm_amd import ops as _ops
     from ttdg_mgm_amd.modeling import detector as _det
     assert _det._backend is _ops, "the GPU legs must run on the HIP operators (detector._backend was re-pointed)"
-    if args.gagm_threads:
+    if args.gagm_threads or args.roi_align_flat:
         from ttdg_mgm_amd import _lib
         _lib.load().ttdg_debug_set_gagm_threads(args.gagm_threads)
+        _lib.load().ttdg_debug_set_roi_align_sliced(0 if args.roi_align_flat else 1)
     if args.images:
         # strong scaling: the FIXED stream is sharded; warm-up batches come from another stream so that the timed work is
         # exactly args.images images whatever the rank count
         timed, dicts_t = staged_batches(cfg, "synthfundus_bench", args.images, args, device, rank, world)
-        warm, dicts_w = staged_batches(cfg, "synthfundus_warm", world * W * B, args, device, rank, world, cfg_id=3, id_offset=10 ** 6)
+        warm, dicts_w = staged_batches(cfg, "synthfundus_warm", world * W * B, args, device, rank, world, cfg_id=args.stream_id + 10, id_offset=10 ** 6)
         batches, local_dicts = warm + timed, dicts_w + dicts_t
     else:
         # weak scaling: every rank owns (K + W) batches of a (world * (K + W) * B)-image stream
@@ -466,7 +481,8 @@ def gpu_main(args, rank, world, local):
         # inputs through the streaming loader inside the timed region (synthesise + resize + pinned H2D, 2-deep prefetch)
         note("A/B: loader-inclusive")
         from ttdg_mgm_amd import data
-        data.register_synthetic("synthfundus_stream", K * B, size=args.size, cfg_id=4, id_offset=2 * 10 ** 6)
+        data.register_synthetic("synthfundus_stream", K * B, size=args.size, cfg_id=args.stream_id + 20, id_offset=2 * 10 ** 6, kind=args.kind,
+                                num_cls=args.num_cls)
 
         def stream():
             return data.TestLoader("synthfundus_stream", B, 0, 1, device, cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST, resident=False)
@@ -474,6 +490,8 @@ def gpu_main(args, rank, world, local):
         ab["loader_inclusive"] = short(
             timed_pass(cfg, model, init_state, batches, local_dicts + sd, name, K, W, args, world, device, tf, loader_factory=stream),
             "timed batches stream through the test loader (image synthesis standing for decode, resize 512->800, pinned H2D; 2-deep prefetch) in both passes")
+    if args.workload != "cfg2":
+        args.no_cpu_baseline = True           # the CPU port is set up for the headline workload only
     if world == 1 and args.weights == "trained" and not args.no_cpu_baseline:
         note("Dice parity leg (GPU)")
         parity = {"gpu": gpu_dice_parity_leg(cfg, model, init_state, batches[0], local_dicts, name, tf)}
@@ -483,13 +501,15 @@ def gpu_main(args, rank, world, local):
     images = world * K * B
     roofs = kernel_rooflines(main)
     out = {
-        "metric": "adapted images/sec (512x512, 2-class)", "value": images / main["elapsed"], "unit": "images/s",
+        "metric": "adapted images/sec (%dx%d, %d-class)" % (args.size, args.size, args.num_cls), "value": images / main["elapsed"], "unit": "images/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": main["elapsed"] / K * 1e3,
         "higher_is_better": True, "scaling": "strong" if args.images else "weak", "vs_baseline": None,
         "dtype": "f32" if not args.bf16_backbone else "bf16 backbone / f32 matching", "data": "synthetic",
-        "config": {"workload": "cfg-2: %d-image synthetic %dx%d 2-class fundus stream%s, TEST.BATCH=%d (800x800 after the test mapper), "
+        "config": {"workload": "%s: %d-image synthetic %dx%d %d-class %s stream%s, TEST.BATCH=%d (%dx%d after the test mapper), "
                                "ResNet-50-FPN stand-in + 20-sweep Sinkhorn, 1 TTA step per batch + Dice pass"
-                               % (args.images or K * B, args.size, args.size, " in total" if args.images else " per GPU", B),
+                               % ("cfg-2" if args.workload == "cfg2" else "cfg-5 (per GPU)", args.images or K * B, args.size, args.size, args.num_cls, args.kind,
+                                  " in total" if args.images else " per GPU", B, cfg.INPUT.MIN_SIZE_TEST if args.workload == "cfg5" else 800,
+                                  cfg.INPUT.MIN_SIZE_TEST if args.workload == "cfg5" else 800),
                    "global_batch": world * B,
                    "parallelism": ("dp%d (independent shards, no data-path collective; Dice scores all-gathered)" % world) if not (args.sync_universe and world > 1)
                    else "dp%d synchronous universe graph (all-gather of node embeddings + gradient all-reduce)" % world,

@@ -254,6 +254,8 @@ int ttdg_bias_act(float* y, const float* bias, const float* residual, const floa
  * out (R, C, P, P).  No per-level compaction, hence no host read. */
 int ttdg_roi_align_multilevel(ttdg_fpn_t fp, ttdg_levels_t lv, const float* rois, int R, int P, float canonical_size,
                               int canonical_level, int min_level, float* out, ttdg_stream_t stream);
+/* A/B hook: 1 (default) = XCD-sliced work mapping of ttdg_roi_align_multilevel (each XCD owns C/8 channel planes), 0 = flat. */
+int ttdg_debug_set_roi_align_sliced(int on);
 
 /* DiceEvaluator reductions (reference evaluation/dice_metric.py:25-92 with enhanced_align :110-143 and
  * Structure_measure :147-240): for `npairs` (predicted mask, same-class ground-truth mask) pairs of H x W byte maps (0/1,

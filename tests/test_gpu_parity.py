@@ -955,7 +955,7 @@ def test_roi_align_multilevel_matches_per_level_pooler(dev):
     from ttdg_mgm_amd import ops
     cb = _cpu_backend()
     g = synth.gen(7500)
-    B, C = 2, 8
+    B, C = 2, 16
     feats = [synth.normal(g, (B, C, 64 // s, 64 // s), 1.0) for s in (1, 2, 4, 8)]      # strides 4, 8, 16, 32 of a 256 px image
     R = 60
     xy = np.abs(synth.normal(g, (R, 2), 60.0).numpy())
@@ -963,10 +963,20 @@ def test_roi_align_multilevel_matches_per_level_pooler(dev):
     img = g.integers(0, B, size=R).astype(np.float32)
     rois = torch.from_numpy(np.concatenate((img[:, None], xy, xy + wh), 1).astype(np.float32))
     rois[0, 1:] = torch.tensor([10.0, 10.0, 10.0, 10.0])             # degenerate box
+    from ttdg_mgm_amd import _lib
     for P in (7, 14):
         ref = cb.roi_align_multilevel(feats, rois, [4, 8, 16, 32], P)
-        got = ops.roi_align_multilevel([f.to(dev) for f in feats], rois.to(dev), [4, 8, 16, 32], P)
-        assert maxerr(got, ref) <= 1e-4, P
+        for sliced in (1, 0):            # XCD-sliced work mapping (default) and the flat one: same results
+            _lib.load().ttdg_debug_set_roi_align_sliced(sliced)
+            try:
+                got = ops.roi_align_multilevel([f.to(dev) for f in feats], rois.to(dev), [4, 8, 16, 32], P)
+            finally:
+                _lib.load().ttdg_debug_set_roi_align_sliced(1)
+            assert maxerr(got, ref) <= 1e-4, (P, sliced)
+    # a channel count that is not a multiple of 8 takes the flat mapping
+    f5 = [f[:, :5].contiguous() for f in feats]
+    assert maxerr(ops.roi_align_multilevel([f.to(dev) for f in f5], rois.to(dev), [4, 8, 16, 32], 7),
+                  cb.roi_align_multilevel(f5, rois, [4, 8, 16, 32], 7)) <= 1e-4
 
 
 # ------------------------------------------------------------------------------------------- N3: HiPPI / U_sup

@@ -297,9 +297,10 @@ def _ground_truth(items, device):
     return out
 
 
-def source_batches(cfg, n_images, size, device, name="synthfundus_source"):
+def source_batches(cfg, n_images, size, device, name="synth_source", kind="fundus"):
     from ttdg_mgm_amd import data
-    data.register_synthetic(name, n_images, size=size, cfg_id=SOURCE_CFG_ID)
+    data.register_synthetic(name + "_" + kind, n_images, size=size, cfg_id=SOURCE_CFG_ID, kind=kind, num_cls=cfg.MODEL.ROI_HEADS.NUM_CLASSES)
+    name = name + "_" + kind
     return list(data.TestLoader(name, cfg.TEST.BATCH, 0, 1, device, cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST))
 
 
@@ -455,7 +456,7 @@ def solver_regime(model, batches):
 
 
 def make(cfg, device, steps=600, tta_steps=16, n_images=64, size=512, lr=0.01, seed=0, log=print, train_all=False, matching_weight=1.0,
-         unsup_weight=20.0, matching_lr=1e-3, probe=None, probe_every=0, profile=False, roi_grad=False):
+         unsup_weight=20.0, matching_lr=1e-3, probe=None, probe_every=0, profile=False, roi_grad=False, kind="fundus"):
     """Build, fit and return (model, report).  ``cfg`` is the test config (TEST.BATCH, INPUT sizes, NUM_CLASSES)."""
     from ttdg_mgm_amd.engine import BaselineTrainer
     from ttdg_mgm_amd.modeling import calibrate_frozen_bn
@@ -464,7 +465,7 @@ def make(cfg, device, steps=600, tta_steps=16, n_images=64, size=512, lr=0.01, s
     cfg = cfg.clone()
     cfg.MODEL.DEVICE = str(device)
     model = BaselineTrainer.build_model(cfg)
-    batches = source_batches(cfg, n_images, size, device)
+    batches = source_batches(cfg, n_images, size, device, kind=kind)
     calibrate_frozen_bn(model, batches[0])
     with torch.no_grad():       # unit-norm universe rows (the reference's init, randn + 1/32 over 256 dims, has norm 16): see train_source
         model.multi_matching_sup.U.div_(model.multi_matching_sup.U.norm(dim=1, keepdim=True))

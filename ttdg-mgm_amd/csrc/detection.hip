@@ -414,14 +414,24 @@ extern "C" int ttdg_bias_act(float* y, const float* bias, const float* residual,
 //   level = clamp(floor(canonical_level + log2(sqrt(area) / canonical_size + 1e-8)), min_level, max_level) - min_level
 // and is sampled from that level's map (same adaptive bilinear sampling as roi_align_fwd_kernel).  The torch formulation
 // is a per-level nonzero() (a host read each) + index + ROIAlign + index_put: 4 syncs and ~40 launches per call.
+// Work mapping (round 2): the eight XCDs of the chip have private 4 MB L2s and workgroup b is observed to run on XCD
+// b % 8 (placement affects speed only).  With the flat (roi, channel, bin) order every XCD touched every channel plane of
+// every ROI patch: the rocprofv3 FETCH_SIZE of one box-head call (4000 proposals of a trained RPN, all stacked on the same
+// few objects) was 2.1 - 4.0 GB for 218 MB of feature maps.  Now XCD x owns the channel slice [x C/8, (x+1) C/8): its L2
+// only ever sees 1/8 of the planes, and the proposals of an image - consecutive in the roi list - re-read them from there.
+template <bool kSliced>
 __global__ __launch_bounds__(256) void roi_align_ml_kernel(ttdg_fpn_t fp, ttdg_levels_t lv, const float* __restrict__ rois, int R, int P,
                                                            float canon_size, int canon_level, int min_level,
                                                            float* __restrict__ out) {
   const int C = fp.C;
-  const long total = (long)R * C * P * P;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-    const int pw = idx % P, ph = (idx / P) % P, c = (idx / ((long)P * P)) % C;
-    const int r = idx / ((long)P * P * C);
+  const int CS = kSliced ? C >> 3 : C;                       // channels per slice
+  const int slice = kSliced ? (int)(blockIdx.x & 7) : 0;
+  const long per = (long)R * CS * P * P;                     // outputs per slice
+  const long nblk = kSliced ? (long)(gridDim.x >> 3) : (long)gridDim.x;
+  for (long e = (long)(kSliced ? blockIdx.x >> 3 : blockIdx.x) * 256 + threadIdx.x; e < per; e += nblk * 256) {
+    const int pw = e % P, ph = (e / P) % P, c = slice * CS + (int)((e / ((long)P * P)) % CS);
+    const int r = e / ((long)P * P * CS);
+    const long idx = (((long)r * C + c) * P + ph) * P + pw;
     const float* roi = rois + (size_t)r * 5;
     const int b = (int)roi[0];
     const float area = fmaxf((roi[3] - roi[1]) * (roi[4] - roi[2]), 0.f);
@@ -452,14 +462,24 @@ __global__ __launch_bounds__(256) void roi_align_ml_kernel(ttdg_fpn_t fp, ttdg_l
   }
 }
 
+static int g_roi_align_sliced = 1;
+extern "C" int ttdg_debug_set_roi_align_sliced(int on) { g_roi_align_sliced = on != 0; return 0; }
+
 extern "C" int ttdg_roi_align_multilevel(ttdg_fpn_t fp, ttdg_levels_t lv, const float* rois, int R, int P, float canonical_size,
                                          int canonical_level, int min_level, float* out, ttdg_stream_t stream) {
   TTDG_REQUIRE(rois && out && R >= 0 && P > 0 && fp.n >= 1 && fp.n <= TTDG_MAX_LEVELS && fp.C > 0 && lv.n == fp.n,
                "roi_align_multilevel: bad arguments");
   if (R == 0) return 0;
+  if (fp.C % 8 == 0 && g_roi_align_sliced) {      // XCD-sliced mapping: 8 x (blocks per slice)
+    const long per = (long)R * (fp.C / 8) * P * P;
+    const int bps = (int)((per + 255) / 256 < 16384 ? (per + 255) / 256 : 16384);
+    hipLaunchKernelGGL(roi_align_ml_kernel<true>, dim3(8 * bps), dim3(256), 0, (hipStream_t)stream, fp, lv, rois, R, P, canonical_size,
+                       canonical_level, min_level, out);
+    return ttdg_launch_status("roi_align_multilevel");
+  }
   const long total = (long)R * fp.C * P * P;
   const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-  hipLaunchKernelGGL(roi_align_ml_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, fp, lv, rois, R, P, canonical_size,
+  hipLaunchKernelGGL(roi_align_ml_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, fp, lv, rois, R, P, canonical_size,
                      canonical_level, min_level, out);
   return ttdg_launch_status("roi_align_multilevel");
 }
