@@ -70,7 +70,8 @@ def parse(argv=None):
                     help="Mode S (SURVEY.md 8e): all ranks adapt on ONE multi-graph (RCCL all-gather of the node embeddings, gradient "
                          "all-reduce) = the single-GPU algorithm at batch N*B; default is Mode R (independent shards, as the reference)")
     ap.add_argument("--gagm-threads", type=int, default=0, help="A/B: workgroup size of the single-workgroup solver (256 / 512; 0 = automatic)")
-    ap.add_argument("--roi-align-flat", action="store_true", help="A/B: the flat (non XCD-sliced) work mapping of the ROIPooler kernel")
+    ap.add_argument("--roi-align-mode", type=int, default=3, help="A/B: 3 = channels-last ROIPooler kernel (default), 2 = separable table kernel on NCHW, "
+                                                                  "1 = direct kernel, XCD-sliced, 0 = direct, flat (round 1)")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch, rendezvous, sharding and the collectives of the bench without any GPU work (CPU test of --gpus N)")
     a = ap.parse_args(argv)
@@ -433,10 +434,11 @@ def gpu_main(args, rank, world, local):
     from ttdg_mgm_amd import ops as _ops
     from ttdg_mgm_amd.modeling import detector as _det
     assert _det._backend is _ops, "the GPU legs must run on the HIP operators (detector._backend was re-pointed)"
-    if args.gagm_threads or args.roi_align_flat:
+    if args.gagm_threads or args.roi_align_mode != 3:
         from ttdg_mgm_amd import _lib
         _lib.load().ttdg_debug_set_gagm_threads(args.gagm_threads)
-        _lib.load().ttdg_debug_set_roi_align_sliced(0 if args.roi_align_flat else 1)
+        _ops.ROI_ALIGN_NHWC = args.roi_align_mode == 3
+        _lib.load().ttdg_debug_set_roi_align_sliced(min(args.roi_align_mode, 2))
     if args.images:
         # strong scaling: the FIXED stream is sharded; warm-up batches come from another stream so that the timed work is
         # exactly args.images images whatever the rank count

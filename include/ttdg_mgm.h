@@ -254,7 +254,14 @@ int ttdg_bias_act(float* y, const float* bias, const float* residual, const floa
  * out (R, C, P, P).  No per-level compaction, hence no host read. */
 int ttdg_roi_align_multilevel(ttdg_fpn_t fp, ttdg_levels_t lv, const float* rois, int R, int P, float canonical_size,
                               int canonical_level, int min_level, float* out, ttdg_stream_t stream);
-/* A/B hook: 1 (default) = XCD-sliced work mapping of ttdg_roi_align_multilevel (each XCD owns C/8 channel planes), 0 = flat. */
+/* The same pooler on channels-last copies of the FPN maps (fp.feat[l] = (B, H_l, W_l, C)): a lane is a channel, every tap one
+ * coalesced read per wavefront; ttdg_nchw_to_nhwc makes the copies ((B, C, H, W) -> (B, H, W, C), tiled through LDS), once per
+ * forward for every pooler call that shares the maps.  out is (R, C, P, P) as above; P <= 14. */
+int ttdg_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, ttdg_stream_t stream);
+int ttdg_roi_align_multilevel_nhwc(ttdg_fpn_t fp, ttdg_levels_t lv, const float* rois, int R, int P, float canonical_size,
+                                   int canonical_level, int min_level, float* out, ttdg_stream_t stream);
+/* A/B hook for ttdg_roi_align_multilevel: 2 (default) = separable table kernel, one workgroup per (ROI, channel slice = XCD);
+ * 1 = direct per-output kernel with the XCD-sliced work mapping; 0 = direct kernel, flat mapping (round 1). */
 int ttdg_debug_set_roi_align_sliced(int on);
 
 /* DiceEvaluator reductions (reference evaluation/dice_metric.py:25-92 with enhanced_align :110-143 and

@@ -966,16 +966,31 @@ def test_roi_align_multilevel_matches_per_level_pooler(dev):
     from ttdg_mgm_amd import _lib
     for P in (7, 14):
         ref = cb.roi_align_multilevel(feats, rois, [4, 8, 16, 32], P)
-        for sliced in (1, 0):            # XCD-sliced work mapping (default) and the flat one: same results
-            _lib.load().ttdg_debug_set_roi_align_sliced(sliced)
+        for mode in (2, 1, 0):           # separable table kernel (default), direct kernel XCD-sliced, direct kernel flat
+            _lib.load().ttdg_debug_set_roi_align_sliced(mode)
             try:
                 got = ops.roi_align_multilevel([f.to(dev) for f in feats], rois.to(dev), [4, 8, 16, 32], P)
             finally:
-                _lib.load().ttdg_debug_set_roi_align_sliced(1)
-            assert maxerr(got, ref) <= 1e-4, (P, sliced)
-    # a channel count that is not a multiple of 8 takes the flat mapping
+                _lib.load().ttdg_debug_set_roi_align_sliced(2)
+            assert maxerr(got, ref) <= 1e-4, (P, mode)
+        fd = [f.to(dev) for f in feats]                # channels-last kernel (lane = channel) on transposed copies
+        assert maxerr(ops.roi_align_multilevel(fd, rois.to(dev), [4, 8, 16, 32], P, nhwc=ops.to_nhwc(fd)), ref) <= 1e-4, P
+    # a channel count that is not a multiple of 8 (one slice), ROIs beyond the table limits (> 8 samples per bin: direct
+    # formula inside the kernel), ROIs hanging over every border, a one-pixel map
     f5 = [f[:, :5].contiguous() for f in feats]
     assert maxerr(ops.roi_align_multilevel([f.to(dev) for f in f5], rois.to(dev), [4, 8, 16, 32], 7),
+                  cb.roi_align_multilevel(f5, rois, [4, 8, 16, 32], 7)) <= 1e-4
+    big = torch.tensor([[0, -300.0, -200.0, 900.0, 800.0], [1, 0.0, 0.0, 256.0, 256.0], [1, 250.0, 250.0, 700.0, 262.0], [0, -50.0, 100.0, 20.0, 400.0],
+                        [1, 3.0, 3.0, 3.5, 3.5], [0, 255.0, 255.0, 256.0, 256.0]])
+    fd = [f.to(dev) for f in feats]
+    tf = ops.to_nhwc(fd)
+    assert all(torch.equal(t, f.permute(0, 2, 3, 1)) for t, f in zip(tf, fd))                     # the transposition itself
+    for P in (7, 14):
+        want = cb.roi_align_multilevel(feats, big, [4, 8, 16, 32], P)
+        assert maxerr(ops.roi_align_multilevel(fd, big.to(dev), [4, 8, 16, 32], P), want) <= 1e-4, P
+        assert maxerr(ops.roi_align_multilevel(fd, big.to(dev), [4, 8, 16, 32], P, nhwc=tf), want) <= 1e-4, P
+    f5d = [f.to(dev) for f in f5]
+    assert maxerr(ops.roi_align_multilevel(f5d, rois.to(dev), [4, 8, 16, 32], 7, nhwc=ops.to_nhwc(f5d)),
                   cb.roi_align_multilevel(f5, rois, [4, 8, 16, 32], 7)) <= 1e-4
 
 

@@ -82,6 +82,8 @@ SIGNATURES = {
     "ttdg_box_inference": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _P, _P, _S]),
     "ttdg_roi_align_multilevel": (C.c_int, [Fpn, Levels, _P, _I, _I, _F, _I, _I, _P, _S]),
     "ttdg_debug_set_roi_align_sliced": (C.c_int, [_I]),
+    "ttdg_nchw_to_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _S]),
+    "ttdg_roi_align_multilevel_nhwc": (C.c_int, [Fpn, Levels, _P, _I, _I, _F, _I, _I, _P, _S]),
     "ttdg_bias_act": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _S]),
     "ttdg_paste_masks": (C.c_int, [_P, _P, _I, _I, _I, _I, _F, _P, _S]),
     "ttdg_mask_pair_counts": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _S]),

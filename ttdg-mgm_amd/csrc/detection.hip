@@ -462,14 +462,321 @@ __global__ __launch_bounds__(256) void roi_align_ml_kernel(ttdg_fpn_t fp, ttdg_l
   }
 }
 
-static int g_roi_align_sliced = 1;
-extern "C" int ttdg_debug_set_roi_align_sliced(int on) { g_roi_align_sliced = on != 0; return 0; }
+// ---- separable ROIPooler (round 2) ---------------------------------------------------------------------------------
+// ROIAlign (aligned, adaptive sampling) is a separable linear map of the ROI's patch:
+//     out[ph][pw] = sum_yy sum_xx Wy[ph][yy] Wx[pw][xx] F[ylo + yy][xlo + xx]
+// where Wy[ph][.] collects, over the g_h samples of bin row ph, the two bilinear row weights of every sample (the skip rule
+// `y < -1 || y > H` and the border clamp are per-axis, so they live in the tables too), likewise Wx, and 1 / (g_h g_w) is
+// folded into Wy.  The direct kernel above spends ~300 VALU instructions per output on addresses and weights that are the
+// same for all C channels of a ROI; here one workgroup owns (ROI, channel slice = XCD), builds the two tables ONCE in LDS
+// (<= g + 2 weights per bin: sample spacing b / ceil(b) <= 1 pixel), and every wavefront then streams channels: the patch
+// rows come in coalesced, T[yy][pw] = sum_xx Wx F is contracted first, then out = sum_yy Wy T.  ~760 FMAs and ~600 loaded
+// floats per channel instead of 784 scattered taps x 4 + their arithmetic.
+#define RA_MAXP 14         /* pooled size handled (7: box head, 14: mask head) */
+#define RA_MAXW 10         /* weights per bin and axis: g + 2 with g <= 8 */
+#define RA_MAXPATCH 48     /* patch rows / columns handled by the table path (48 KB of LDS per workgroup: 3 per CU) */
+#define RA_WAVES 4
+
+struct RaAxis {            // one axis of one ROI
+  float w[RA_MAXP][RA_MAXW];
+  int start[RA_MAXP];      // first patch index (absolute pixel index) of bin p
+  int cnt[RA_MAXP];        // number of weights (0 = every sample of the bin was skipped)
+};
+
+__device__ __forceinline__ void ra_build_axis(RaAxis& ax, int p, float v1, float b, int g, int L) {
+  // bin p of an axis of length L: samples v = v1 + p b + (s + 0.5) b / g, s < g
+  float w[RA_MAXW];
+#pragma unroll
+  for (int k = 0; k < RA_MAXW; ++k) w[k] = 0.f;
+  int first = -1, last = -1;
+  for (int s = 0; s < g; ++s) {
+    float v = v1 + p * b + (s + 0.5f) * b / g;
+    if (v < -1.f || v > (float)L) continue;
+    float vv = fmaxf(v, 0.f);
+    int i0 = (int)vv, i1;
+    if (i0 >= L - 1) { i0 = i1 = L - 1; vv = (float)i0; } else i1 = i0 + 1;
+    const float l = vv - i0, h = 1.f - l;
+    if (first < 0) first = i0;                  // samples are visited in increasing order: i0 is non-decreasing
+    last = i1;
+    const int k0 = i0 - first, k1 = i1 - first;
+#pragma unroll
+    for (int k = 0; k < RA_MAXW; ++k) { if (k == k0) w[k] += h; if (k == k1) w[k] += l; }
+  }
+  ax.start[p] = first < 0 ? 0 : first;
+  ax.cnt[p] = first < 0 ? 0 : last - first + 1;
+#pragma unroll
+  for (int k = 0; k < RA_MAXW; ++k) ax.w[p][k] = w[k];
+}
+
+__global__ __launch_bounds__(64 * RA_WAVES) void roi_align_sep_kernel(ttdg_fpn_t fp, ttdg_levels_t lv, const float* __restrict__ rois, int R, int P,
+                                                                       int nslice, float canon_size, int canon_level, int min_level,
+                                                                       float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float ra_smem[];
+  __shared__ RaAxis s_y, s_x;
+  __shared__ int s_geo[8];      // ylo, hp, xlo, wp, ok
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = blockIdx.x / nslice, slice = blockIdx.x % nslice;
+  const int C = fp.C, CS = C / nslice;
+  const float* roi = rois + (size_t)r * 5;
+  const int b = (int)roi[0];
+  const float area = fmaxf((roi[3] - roi[1]) * (roi[4] - roi[2]), 0.f);
+  int l = (int)floorf((float)canon_level + log2f(sqrtf(area) / canon_size + 1e-8f));
+  l = min(max(l, min_level), min_level + fp.n - 1) - min_level;
+  const int H = fp.h[l], W = fp.w[l];
+  const float scale = 1.f / (float)lv.stride[l];
+  const float x1 = roi[1] * scale - 0.5f, y1 = roi[2] * scale - 0.5f;
+  const float rw = roi[3] * scale - 0.5f - x1, rh = roi[4] * scale - 0.5f - y1;
+  const float bw = rw / P, bh = rh / P;
+  const int gh = max(1, (int)ceilf(rh / P)), gw = max(1, (int)ceilf(rw / P));
+  const bool tables = gh <= RA_MAXW - 2 && gw <= RA_MAXW - 2;
+  if (tables) {
+    if (tid < P) ra_build_axis(s_y, tid, y1, bh, gh, H);
+    else if (tid >= 64 && tid < 64 + P) ra_build_axis(s_x, tid - 64, x1, bw, gw, W);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int ylo = 1 << 30, yhi = -1, xlo = 1 << 30, xhi = -1;
+    if (tables)
+      for (int p = 0; p < P; ++p) {
+        if (s_y.cnt[p]) { ylo = min(ylo, s_y.start[p]); yhi = max(yhi, s_y.start[p] + s_y.cnt[p] - 1); }
+        if (s_x.cnt[p]) { xlo = min(xlo, s_x.start[p]); xhi = max(xhi, s_x.start[p] + s_x.cnt[p] - 1); }
+      }
+    const bool empty = yhi < 0 || xhi < 0;
+    s_geo[0] = empty ? 0 : ylo; s_geo[1] = empty ? 0 : yhi - ylo + 1;
+    s_geo[2] = empty ? 0 : xlo; s_geo[3] = empty ? 0 : xhi - xlo + 1;
+    s_geo[4] = tables && (empty || (yhi - ylo + 1 <= RA_MAXPATCH && xhi - xlo + 1 <= RA_MAXPATCH));
+  }
+  __syncthreads();
+  const int ylo = s_geo[0], hp = s_geo[1], xlo = s_geo[2], wp = s_geo[3];
+  float* obase = out + ((size_t)r * C + (size_t)slice * CS) * P * P;
+  const float* fbase = fp.feat[l] + ((size_t)b * C + (size_t)slice * CS) * H * W;
+  if (!s_geo[4]) {
+    // a ROI outside the table limits (more than 8 samples per bin, or a patch above 64 pixels): the direct formula
+    const float inv = 1.f / (float)(gh * gw);
+    for (int e = tid; e < CS * P * P; e += 64 * RA_WAVES) {
+      const int pw = e % P, ph = (e / P) % P, cc = e / (P * P);
+      const float* f = fbase + (size_t)cc * H * W;
+      float acc = 0.f;
+      for (int iy = 0; iy < gh; ++iy) {
+        float y = y1 + ph * bh + (iy + 0.5f) * bh / gh;
+        for (int ix = 0; ix < gw; ++ix) {
+          float x = x1 + pw * bw + (ix + 0.5f) * bw / gw;
+          if (y < -1.f || y > H || x < -1.f || x > W) continue;
+          float yy = fmaxf(y, 0.f), xx = fmaxf(x, 0.f);
+          int y0 = (int)yy, x0 = (int)xx, y1i, x1i;
+          if (y0 >= H - 1) { y0 = y1i = H - 1; yy = (float)y0; } else y1i = y0 + 1;
+          if (x0 >= W - 1) { x0 = x1i = W - 1; xx = (float)x0; } else x1i = x0 + 1;
+          const float ly = yy - y0, lx = xx - x0, hy = 1.f - ly, hx = 1.f - lx;
+          acc += hy * hx * f[y0 * W + x0] + hy * lx * f[y0 * W + x1i] + ly * hx * f[y1i * W + x0] + ly * lx * f[y1i * W + x1i];
+        }
+      }
+      obase[e] = acc * inv;
+    }
+    return;
+  }
+  // per-wavefront scratch: patch (hp x wpad) and T (hp x P)
+  const int wpad = wp | 1;
+  float* patch = ra_smem + (size_t)wave * (RA_MAXPATCH * (RA_MAXPATCH + 1) + RA_MAXPATCH * RA_MAXP);
+  float* T = patch + RA_MAXPATCH * (RA_MAXPATCH + 1);
+  const float inv = 1.f / (float)(gh * gw);
+  const int rows_per = wp <= 32 ? 2 : 1;                     // patch rows fetched per load round
+  const int lx_ = rows_per == 2 ? (lane & 31) : lane, lr_ = rows_per == 2 ? (lane >> 5) : 0;
+  for (int cc = wave; cc < CS; cc += RA_WAVES) {
+    const float* f = fbase + (size_t)cc * H * W + (size_t)ylo * W + xlo;
+    // eight load rounds in flight before the first LDS store (a load -> wait -> store loop pays one L2 round trip per row)
+    for (int y0 = lr_; y0 < hp; y0 += 8 * rows_per) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int yy = y0 + k * rows_per;
+        v[k] = (yy < hp && lx_ < wp) ? f[(size_t)yy * W + lx_] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int yy = y0 + k * rows_per;
+        if (yy < hp && lx_ < wp) patch[yy * wpad + lx_] = v[k];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int it = lane; it < hp * P; it += 64) {
+      const int yy = it / P, pw = it - yy * P;
+      const int n = s_x.cnt[pw], st = s_x.start[pw] - xlo;
+      const float* pr = patch + yy * wpad + st;
+      float t = 0.f;
+      for (int k = 0; k < n; ++k) t = fmaf(s_x.w[pw][k], pr[k], t);
+      T[it] = t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float* o = obase + (size_t)cc * P * P;
+    for (int it = lane; it < P * P; it += 64) {
+      const int ph = it / P, pw = it - ph * P;
+      const int n = s_y.cnt[ph], st = s_y.start[ph] - ylo;
+      float a = 0.f;
+      for (int k = 0; k < n; ++k) a = fmaf(s_y.w[ph][k], T[(st + k) * P + pw], a);
+      o[it] = a * inv;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- channels-last ROIPooler (round 2) ------------------------------------------------------------------------------
+// Same tables as roi_align_sep_kernel, but the feature maps are NHWC copies (ttdg_nchw_to_nhwc) and a LANE IS A CHANNEL:
+// every tap of a bin is one fully coalesced 256-byte read per wavefront, its weight wy[ph][ky] * wx[pw][kx] is uniform
+// (LDS broadcast), so a wavefront spends ~(g+1)^2 FMAs + as many loads per bin for 64 channels - against ~600 wave
+// instructions per CHANNEL in the patch-staging kernel, which the profile showed to be VALU-issue bound (0.87 ms for
+// 4000 ROIs).  The (64 channels x 49 bins) result block is contiguous in the (R, C, P, P) output: it is transposed through
+// LDS and written coalesced.
+#define RN_CHUNK 49        /* bins staged per output flush (P = 7: all of them; P = 14: four flushes) */
+
+__global__ __launch_bounds__(256) void roi_align_nhwc_kernel(ttdg_fpn_t fp, ttdg_levels_t lv, const float* __restrict__ rois, int R, int P,
+                                                             float canon_size, int canon_level, int min_level, float* __restrict__ out) {
+  __shared__ RaAxis s_y, s_x;
+  __shared__ float s_tile[4][64 * (RN_CHUNK + 1)];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = blockIdx.x;
+  const int C = fp.C;
+  const float* roi = rois + (size_t)r * 5;
+  const int b = (int)roi[0];
+  const float area = fmaxf((roi[3] - roi[1]) * (roi[4] - roi[2]), 0.f);
+  int l = (int)floorf((float)canon_level + log2f(sqrtf(area) / canon_size + 1e-8f));
+  l = min(max(l, min_level), min_level + fp.n - 1) - min_level;
+  const int H = fp.h[l], W = fp.w[l];
+  const float scale = 1.f / (float)lv.stride[l];
+  const float x1 = roi[1] * scale - 0.5f, y1 = roi[2] * scale - 0.5f;
+  const float rw = roi[3] * scale - 0.5f - x1, rh = roi[4] * scale - 0.5f - y1;
+  const float bw = rw / P, bh = rh / P;
+  const int gh = max(1, (int)ceilf(rh / P)), gw = max(1, (int)ceilf(rw / P));
+  const bool tables = gh <= RA_MAXW - 2 && gw <= RA_MAXW - 2;
+  if (tables) {
+    if (tid < P) ra_build_axis(s_y, tid, y1, bh, gh, H);
+    else if (tid >= 64 && tid < 64 + P) ra_build_axis(s_x, tid - 64, x1, bw, gw, W);
+  }
+  __syncthreads();
+  const float inv = 1.f / (float)(gh * gw);
+  const int PP = P * P;
+  float* tile = s_tile[wave];
+  for (int c0 = wave * 64; c0 < C; c0 += 256) {
+    const int c = c0 + lane;
+    const bool cok = c < C;
+    const float* f = fp.feat[l] + (size_t)b * H * W * C + (cok ? c : 0);
+    float* o = out + ((size_t)r * C + c0) * PP;
+    const int nch = min(64, C - c0);
+    for (int q0 = 0; q0 < PP; q0 += RN_CHUNK) {
+      const int nb = min(RN_CHUNK, PP - q0);
+      for (int j = 0; j < nb; ++j) {
+        const int bin = q0 + j, ph = bin / P, pw = bin - ph * P;
+        float acc = 0.f;
+        if (tables) {
+          // all taps of four patch rows are issued before the first FMA consumes one (a tap-by-tap loop is one L2 round trip
+          // per tap: 4 us per bin measured); rows / columns beyond the bin's extent are predicated off, their weights are 0
+          const int ny = s_y.cnt[ph], nx = s_x.cnt[pw], ys = s_y.start[ph], xs = s_x.start[pw];
+          float wxr[RA_MAXW];
+#pragma unroll
+          for (int kx = 0; kx < RA_MAXW; ++kx) wxr[kx] = s_x.w[pw][kx];
+          for (int ky0 = 0; ky0 < ny; ky0 += 4) {
+            float v[4][RA_MAXW];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+              const float* rowp = f + ((size_t)(ys + ky0 + a) * W + xs) * C;
+#pragma unroll
+              for (int kx = 0; kx < RA_MAXW; ++kx) v[a][kx] = (ky0 + a < ny && kx < nx) ? rowp[(size_t)kx * C] : 0.f;
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+              const float wyv = (ky0 + a < ny) ? s_y.w[ph][ky0 + a] : 0.f;
+#pragma unroll
+              for (int kx = 0; kx < RA_MAXW; ++kx) acc = fmaf(wyv * wxr[kx], v[a][kx], acc);
+            }
+          }
+        } else {      // more than 8 samples per bin and axis: the direct formula, still one channel per lane
+          for (int iy = 0; iy < gh; ++iy) {
+            float y = y1 + ph * bh + (iy + 0.5f) * bh / gh;
+            for (int ix = 0; ix < gw; ++ix) {
+              float x = x1 + pw * bw + (ix + 0.5f) * bw / gw;
+              if (y < -1.f || y > H || x < -1.f || x > W) continue;
+              float yy = fmaxf(y, 0.f), xx = fmaxf(x, 0.f);
+              int y0 = (int)yy, x0 = (int)xx, y1i, x1i;
+              if (y0 >= H - 1) { y0 = y1i = H - 1; yy = (float)y0; } else y1i = y0 + 1;
+              if (x0 >= W - 1) { x0 = x1i = W - 1; xx = (float)x0; } else x1i = x0 + 1;
+              const float ly = yy - y0, lx = xx - x0, hy = 1.f - ly, hx = 1.f - lx;
+              acc += hy * hx * f[((size_t)y0 * W + x0) * C] + hy * lx * f[((size_t)y0 * W + x1i) * C] +
+                     ly * hx * f[((size_t)y1i * W + x0) * C] + ly * lx * f[((size_t)y1i * W + x1i) * C];
+            }
+          }
+        }
+        tile[lane * (RN_CHUNK + 1) + j] = acc * inv;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // channel ch of the block owns out[ch * PP + q0 .. + nb): runs of nb floats, the whole block when nb == PP
+      for (int idx = lane; idx < nch * nb; idx += 64) {
+        const int ch = idx / nb, jj = idx - ch * nb;
+        o[(size_t)ch * PP + q0 + jj] = tile[ch * (RN_CHUNK + 1) + jj];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// NCHW -> NHWC copy of one feature level: (B, C, HW) -> (B, HW, C), 32 x 32 tiles through LDS (both sides coalesced)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW) {
+  __shared__ float t[32][33];
+  const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+  const float* s = src + (size_t)b * C * HW;
+  float* d = dst + (size_t)b * HW * C;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + 8 * k, p = p0 + tx;
+    if (c < C && p < HW) t[ty + 8 * k][tx] = s[(size_t)c * HW + p];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int p = p0 + ty + 8 * k, c = c0 + tx;
+    if (c < C && p < HW) d[(size_t)p * C + c] = t[tx][ty + 8 * k];
+  }
+}
+
+extern "C" int ttdg_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, ttdg_stream_t stream) {
+  TTDG_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc: bad arguments");
+  TTDG_LIMIT(B <= 65535 && (C + 31) / 32 <= 65535, "nchw_to_nhwc: too many images / channels");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((H * W + 31) / 32, (C + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, src, dst, C, H * W);
+  return ttdg_launch_status("nchw_to_nhwc");
+}
+
+extern "C" int ttdg_roi_align_multilevel_nhwc(ttdg_fpn_t fp, ttdg_levels_t lv, const float* rois, int R, int P, float canonical_size,
+                                              int canonical_level, int min_level, float* out, ttdg_stream_t stream) {
+  TTDG_REQUIRE(rois && out && R >= 0 && P > 0 && P <= RA_MAXP && fp.n >= 1 && fp.n <= TTDG_MAX_LEVELS && fp.C > 0 && lv.n == fp.n,
+               "roi_align_multilevel_nhwc: bad arguments");
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(roi_align_nhwc_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, fp, lv, rois, R, P, canonical_size,
+                     canonical_level, min_level, out);
+  return ttdg_launch_status("roi_align_multilevel_nhwc");
+}
+
+static int g_roi_align_sliced = 1;   // 2 = separable table kernel (default below), 1 = direct kernel with the XCD-sliced mapping, 0 = direct, flat
+static int g_roi_align_mode = 2;
+extern "C" int ttdg_debug_set_roi_align_sliced(int on) { g_roi_align_mode = on < 0 ? 2 : (on > 2 ? 2 : on); g_roi_align_sliced = on != 0; return 0; }
 
 extern "C" int ttdg_roi_align_multilevel(ttdg_fpn_t fp, ttdg_levels_t lv, const float* rois, int R, int P, float canonical_size,
                                          int canonical_level, int min_level, float* out, ttdg_stream_t stream) {
   TTDG_REQUIRE(rois && out && R >= 0 && P > 0 && fp.n >= 1 && fp.n <= TTDG_MAX_LEVELS && fp.C > 0 && lv.n == fp.n,
                "roi_align_multilevel: bad arguments");
   if (R == 0) return 0;
+  if (g_roi_align_mode == 2 && P <= RA_MAXP) {   // separable table kernel: one workgroup per (ROI, channel slice = XCD)
+    const int nslice = fp.C % 8 == 0 ? 8 : 1;
+    const size_t bytes = (size_t)RA_WAVES * (RA_MAXPATCH * (RA_MAXPATCH + 1) + RA_MAXPATCH * RA_MAXP) * sizeof(float);
+    TTDG_ALLOW_LDS(roi_align_sep_kernel, bytes);
+    TTDG_LIMIT((long)R * nslice < 2147483647L, "roi_align_multilevel: too many ROIs");
+    hipLaunchKernelGGL(roi_align_sep_kernel, dim3(R * nslice), dim3(64 * RA_WAVES), bytes, (hipStream_t)stream, fp, lv, rois, R, P, nslice,
+                       canonical_size, canonical_level, min_level, out);
+    return ttdg_launch_status("roi_align_multilevel");
+  }
   if (fp.C % 8 == 0 && g_roi_align_sliced) {      // XCD-sliced mapping: 8 x (blocks per slice)
     const long per = (long)R * (fp.C / 8) * P * P;
     const int bps = (int)((per + 255) / 256 < 16384 ? (per + 255) / 256 : 16384);

@@ -148,11 +148,22 @@ class ROIPooler:
         """(R, 5) = (image index, x1, y1, x2, y2) for the boxes of a batch."""
         return torch.cat([torch.cat((b.tensor.new_full((len(b), 1), float(i)), b.tensor), 1) for i, b in enumerate(box_lists)], 0)
 
-    def __call__(self, feats, box_lists, rois=None):
+    @staticmethod
+    def channels_last(feats):
+        """Channels-last copies of the maps for the HIP pooler (one transposition per forward, shared by the box and the
+        mask pooler); None on a backend without that kernel."""
+        fn = getattr(_backend, "to_nhwc", None)
+        if fn is None or not getattr(_backend, "ROI_ALIGN_NHWC", False) or not feats[0].is_cuda:
+            return None
+        return fn(feats)
+
+    def __call__(self, feats, box_lists, rois=None, nhwc=None):
         """One launch for the whole batch: every ROI picks its level inside the kernel (no per-level nonzero / host read)."""
         if rois is None:
             rois = self.make_rois(box_lists)
         strides = [int(round(1.0 / s)) for s in self.scales]
+        if nhwc is not None:
+            return _backend.roi_align_multilevel(feats, rois, strides, self.P, self.cbs, self.cl, self.min_level, nhwc=nhwc)
         return _backend.roi_align_multilevel(feats, rois, strides, self.P, self.cbs, self.cl, self.min_level)
 
 
@@ -217,7 +228,7 @@ class StandardROIHeadsPseudoLab(nn.Module):
     def _forward_box(self, feats, proposals):
         C = self.num_classes
         rois = ROIPooler.make_rois([p.proposal_boxes for p in proposals])
-        x = self.box_pooler(feats, None, rois)
+        x = self.box_pooler(feats, None, rois, ROIPooler.channels_last(feats))
         logits, deltas = self.box_predictor(self.box_head(x))
         sizes_t = _backend.image_sizes_tensor([p.image_size for p in proposals], rois.device)
         # softmax + per-class decode + clip + validity + score threshold for the whole batch, then per-class NMS and the
@@ -233,7 +244,7 @@ class StandardROIHeadsPseudoLab(nn.Module):
     @torch.no_grad()
     def forward_with_given_boxes(self, features, instances):
         feats = [features[f].detach() for f in self.mask_in_features]
-        x = self.mask_pooler(feats, [i.pred_boxes for i in instances])
+        x = self.mask_pooler(feats, [i.pred_boxes for i in instances], None, ROIPooler.channels_last(feats))
         logits = self.mask_head(x)
         R = logits.shape[0]
         cls = torch.cat([i.pred_classes for i in instances]) if R else logits.new_zeros(0, dtype=torch.int64)
@@ -256,7 +267,7 @@ class StandardROIHeadsPseudoLab(nn.Module):
         return c
 
     @torch.no_grad()
-    def box_dense(self, features, boxes, scores, keep, image_sizes, counts=None):
+    def box_dense(self, features, boxes, scores, keep, image_sizes, counts=None, nhwc=None):
         """Box head on the RPN's dense output (boxes (B, K, 4), scores (B, K), keep (B, post) by descending score, counts (B,)
         = proposals per image: the slots of ``keep`` beyond an image's count are padding - they point at candidates the NMS
         suppressed - and yield no detection).  Returns the detections padded to ``topk`` per image: boxes (B, topk, 4),
@@ -271,7 +282,9 @@ class StandardROIHeadsPseudoLab(nn.Module):
             ps = torch.where(slot[None, :] < counts[:, None].to(dev), ps, ps.new_full((), float("-inf")))
         img = self._const(("img", B, post, str(dev)), lambda: torch.arange(B, device=dev, dtype=torch.float32).repeat_interleave(post)[:, None])
         rois = torch.cat((img, pb.reshape(-1, 4)), 1)
-        logits, deltas = self.box_predictor(self.box_head(self.box_pooler(feats, None, rois)))
+        if nhwc is None:
+            nhwc = ROIPooler.channels_last(feats)
+        logits, deltas = self.box_predictor(self.box_head(self.box_pooler(feats, None, rois, nhwc)))
         sizes_t = _backend.image_sizes_tensor(image_sizes, dev)
         cb, cs = _backend.box_inference(logits, deltas, rois, sizes_t, C, self.bbox_weights, self.score_thresh)
         cs = torch.where(ps.reshape(-1, 1) > float("-inf"), cs, cs.new_full((), float("-inf")))       # padded proposals
@@ -291,11 +304,12 @@ class StandardROIHeadsPseudoLab(nn.Module):
         """Whole eval-mode ROI stage + detector_postprocess on padded tensors, ONE host read at the end.  All images share
         the output size `out_size` (H, W).  Returns the per-image Instances of detector_postprocess."""
         dev = boxes.device
-        dboxes, dscores, dcls, _ = self.box_dense(features, boxes, scores, keep, image_sizes, counts)
-        B, T = dscores.shape
         feats = [features[f].detach() for f in self.mask_in_features]
+        nhwc = ROIPooler.channels_last(feats)          # box and mask pooler read the same maps: transposed once
+        dboxes, dscores, dcls, _ = self.box_dense(features, boxes, scores, keep, image_sizes, counts, nhwc)
+        B, T = dscores.shape
         img = self._const(("img", B, T, str(dev)), lambda: torch.arange(B, device=dev, dtype=torch.float32).repeat_interleave(T)[:, None])
-        mlogits = self.mask_head(self.mask_pooler(feats, None, torch.cat((img, dboxes.reshape(-1, 4)), 1)))
+        mlogits = self.mask_head(self.mask_pooler(feats, None, torch.cat((img, dboxes.reshape(-1, 4)), 1), nhwc))
         ar = self._const(("ar", B * T, str(dev)), lambda: torch.arange(B * T, device=dev))
         prob = mlogits[ar, dcls.reshape(-1)].sigmoid()
         # detector_postprocess: rescale to the output size, clip, drop empty boxes

@@ -470,11 +470,41 @@ def roi_align(feat, rois, scale, P):
     return out
 
 
-def roi_align_multilevel(feats, rois, strides, P, canonical_size=224, canonical_level=4, min_level=2):
+ROI_ALIGN_NHWC = True     # the ROI heads pool from channels-last copies of the FPN maps (one transposition per forward)
+
+
+def to_nhwc(feats):
+    """Channels-last copies (B, H, W, C) of NCHW fp32 maps for roi_align_multilevel(..., nhwc=...): one LDS-tiled
+    transposition per level, shared by every pooler call of a forward."""
+    out = []
+    for f in feats:
+        f = f.detach()
+        if f.dtype != torch.float32 or not f.is_contiguous():
+            f = f.float().contiguous()
+        B, Cc, H, W = f.shape
+        t = torch.empty(B, H, W, Cc, device=f.device, dtype=torch.float32)
+        call("ttdg_nchw_to_nhwc", ptr(f), ptr(t), B, Cc, H, W, stream())
+        out.append(t)
+    return out
+
+
+def roi_align_multilevel(feats, rois, strides, P, canonical_size=224, canonical_level=4, min_level=2, nhwc=None):
     """ROIPooler [3P] in one launch: feats = the FPN maps of levels min_level.. (fp32 NCHW), rois (R, 5); every ROI picks
-    its level inside the kernel.  Returns (R, C, P, P).  No host read."""
+    its level inside the kernel.  Returns (R, C, P, P).  No host read.  ``nhwc`` (from ``to_nhwc(feats)``) selects the
+    channels-last kernel (lane = channel, coalesced taps)."""
     rois = rois.detach().float().contiguous()
     R = rois.shape[0]
+    if nhwc is not None and P <= 14:
+        Cc = nhwc[0].shape[3]
+        fp = _lib.Fpn()
+        fp.n, fp.C = len(nhwc), Cc
+        for l, t in enumerate(nhwc):
+            fp.h[l], fp.w[l], fp.feat[l] = t.shape[1], t.shape[2], ptr(t)
+        lv = levels_desc([t.shape[1:3] for t in nhwc], strides=tuple(strides) + (0,) * (8 - len(strides)), ranges=((0, 0),) * len(nhwc))
+        out = torch.empty(R, Cc, P, P, device=rois.device, dtype=torch.float32)
+        call("ttdg_roi_align_multilevel_nhwc", fp, lv, ptr(rois), R, int(P), float(canonical_size), int(canonical_level), int(min_level),
+             ptr(out), stream())
+        return out
     Cc = feats[0].shape[1]
     fp = _lib.Fpn()
     fp.n, fp.C = len(feats), Cc
