@@ -147,7 +147,11 @@ int ttdg_debug_set_gagm_large_from(int total_nodes);
 /* A/B hook: workgroup size of the single-workgroup solver (256 = one wavefront per SIMD, no register spills; anything else
  * = the default 512, which is faster: gagm.hip). */
 int ttdg_debug_set_gagm_threads(int threads);
-/* micro-benchmark hook: `reps` projections (mode 0 Sinkhorn, 1 LAP) of G graphs x n nodes from LDS, one wavefront per
+/* A/B hook: bit 0 set = graphs of up to 64 nodes use round 1's LDS-exchange Sinkhorn projectors (two copies of the matrix,
+ * potentials through LDS) instead of the block-layout one (gagm.hip: sk_wave_project_blk). */
+int ttdg_debug_set_gagm_flags(int flags);
+/* micro-benchmark hook: `reps` projections (mode 0 Sinkhorn with the product's block-layout projector, 1 LAP, 2 the
+ * LDS-exchange Sinkhorn projectors of round 1) of G graphs x n nodes from LDS, one wavefront per
  * graph, as inside ttdg_gagm_solve; ticks[0] receives the shader-cycle count. */
 int ttdg_debug_project(const float* V, int n, int G, float tau, int iters, int reps, int mode, float* U,
                        long long* ticks, ttdg_stream_t stream);

@@ -133,12 +133,13 @@ def _project_sinkhorn(V, ms, n_univ, tau, sk_iter):
 
 # --------------------------------------------------------------------------- A6
 def gagm(A, W, U0, ms, n_univ=UNIV_SIZE, quad_weight=QUAD_WEIGHT, init_tau=GA_TAU0, min_tau=GA_MIN_TAU,
-         max_iter=GA_MGM_ITER, sk_iter=GA_SK_ITER, sk_gamma=GA_GAMMA, tol=GA_TOL, trace=None):
+         max_iter=GA_MGM_ITER, sk_iter=GA_SK_ITER, sk_gamma=GA_GAMMA, tol=GA_TOL, trace=None, max_stages=0):
     """multi_graph_matching.py:300-389 with num_clusters==1 (cluster_M == 1, hung_iter True),
     entered from GA_GM.forward :223-244 (W detached :225).
 
     ``trace`` (optional dict) receives 'V0' (first-iteration V), 'iters' (per-stage
-    iteration counts) and 'stages' (projector/tau per stage) for parity tests."""
+    iteration counts) and 'stages' (projector/tau per stage) for parity tests.  ``max_stages`` > 0 (test hook, not
+    in the reference) returns the state after that many stages of the schedule."""
     ms = [int(m) for m in ms]
     G = len(ms)
     W = W.detach()
@@ -146,6 +147,7 @@ def gagm(A, W, U0, ms, n_univ=UNIV_SIZE, quad_weight=QUAD_WEIGHT, init_tau=GA_TA
     lastU = torch.zeros_like(U)
     tau = init_tau
     projector = "sinkhorn"
+    nstages = 0
     if trace is not None:
         trace.update(iters=[], stages=[])
     while True:
@@ -171,7 +173,8 @@ def gagm(A, W, U0, ms, n_univ=UNIV_SIZE, quad_weight=QUAD_WEIGHT, init_tau=GA_TA
         if trace is not None:
             trace["iters"].append(i + 1)
             trace["stages"].append((projector, tau))
-        if projector == "hungarian":
+        nstages += 1
+        if projector == "hungarian" or (max_stages and nstages >= max_stages):
             break
         elif tau > min_tau:
             tau *= sk_gamma

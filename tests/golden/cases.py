@@ -257,3 +257,16 @@ def skref_log_alpha(name):
     if r < c:
         la = torch.cat([la, torch.full((b, c - r, c), SKREF_DUMMY_FILL)], dim=1)
     return la
+
+
+# ---- trained-regime solver inputs (trained_solver_inputs.npz: A / Wds / U0 of four TTA steps of the synthetic checkpoint,
+# recorded on the MI355X by tools/gagm_trained_probe.py; data only) ----
+def trained_solver_case(gold, j):
+    sizes = [int(n) for n in gold["sizes_%d" % j]]
+    M = sum(sizes)
+    A, o, a = torch.zeros(M, M), 0, 0
+    ap = torch.from_numpy(gold["apack_%d" % j])
+    for n in sizes:
+        A[o:o + n, o:o + n] = ap[a:a + n * n].view(n, n)
+        o, a = o + n, a + n * n
+    return sizes, A, ap, torch.from_numpy(gold["Wds_%d" % j]), torch.from_numpy(gold["U0_%d" % j])

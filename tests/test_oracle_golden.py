@@ -183,3 +183,18 @@ def test_u_sup_forward_backward(golden, name, sizes, seed):
         check_pgrad(gold, f"usup_{name}_d_Net_U.g_gene.{k}", p["Net_U.g_gene." + k].grad, 1e-6)
     free = og.u_sup_forward(p, [x.detach() for x in nodes], labels)
     assert torch.isfinite(free)
+
+
+# ---- trained-regime solver inputs (A / Wds / U0 recorded by tools/gagm_trained_probe.py on the synthetic checkpoint) ------
+@pytest.mark.parametrize("j", range(4))
+def test_gagm_trained_regime_is_reproducible_through_four_stages(golden, j):
+    """On trained-regime inputs the solve is chaotic in its LAST Sinkhorn stage (tau = 0.00625: float32 and float64 runs of
+    this very restatement end in different permutations), but the trajectory through the first four stages
+    (tau 0.1 ... 0.0125, 15-50 free-running iterations) is not: that is the part the device is held to
+    (tests/test_gpu_parity.py::test_gagm_trained_regime_trajectory)."""
+    sizes, A, _, W, U0 = cases.trained_solver_case(golden("trained_solver_inputs"), j)
+    t32, t64 = {}, {}
+    U32 = og.gagm(A, W, U0, sizes, trace=t32, max_stages=4)
+    U64 = og.gagm(A.double(), W.double(), U0.double(), sizes, trace=t64, max_stages=4)
+    assert t32["iters"] == t64["iters"] and len(t32["iters"]) == 4
+    assert float((U32.double() - U64).abs().max()) <= 5e-6

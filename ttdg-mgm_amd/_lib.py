@@ -67,6 +67,7 @@ SIGNATURES = {
     "ttdg_debug_set_lap_variant": (C.c_int, [_I]),
     "ttdg_debug_set_gagm_large_from": (C.c_int, [_I]),
     "ttdg_debug_set_gagm_threads": (C.c_int, [_I]),
+    "ttdg_debug_set_gagm_flags": (C.c_int, [_I]),
     "ttdg_debug_project": (C.c_int, [_P, _I, _I, _F, _I, _I, _I, _P, _P, _S]),
     "ttdg_perm_loss_workspace_bytes": (C.c_size_t, [Graphs]),
     "ttdg_perm_loss_fwd_bwd": (C.c_int, [_P, _P, Graphs, _F, _F, _P, _P, _P, _P, _S]),

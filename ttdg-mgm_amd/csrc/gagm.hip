@@ -218,6 +218,246 @@ __device__ __forceinline__ void sk_wave_project_narrow(const float* Vb, int n, f
   }
 }
 
+// ---- block-layout projection (graphs of up to 64 nodes): ONE copy of the matrix, no LDS, one exp per entry per sweep PAIR ------
+// Lane (bi = lane >> 3, bj = lane & 7) owns a 4 x CB block: rows 4 bi .. 4 bi + 3, CB columns.  Row sums are butterflies over
+// the three low lane bits (DPP quad_perm x 2, row_half_mirror), column sums over the three high bits (DPP row_ror:8,
+// v_permlane16_swap, v_permlane32_swap): every lane ends up with the potentials of its own rows and columns, so nothing is
+// exchanged through LDS and each sweep is one short dependency chain.  A sweep pair evaluates e = exp2(L - f - g) once: the
+// row sweep yields s_a = sum_b e and f_a += log2 s_a, and the column sweep needs exp2(L - f_new - g) = e / s_a - a multiply
+// by v_rcp_f32 instead of a second transcendental - so c_b = sum_a w_a e / s_a, g_b += log2 c_b.  The potentials are the state
+// (every pair starts from L, f, g: nothing drifts).  As in the other register projectors the previous potentials stabilise the
+// exponentials; the first pair, and any pair in which a sum leaves [2^-60, 1e6], runs in the exact max-subtracted form.
+//   kTr = false (n <= 32): rows = nodes, the dummy row sits in row slot n with weight (32 - n) in the column sums; CB = 4
+//   kTr = true  (32 <= n <= 64): rows = universe slots, columns q = bj + 8 b (b < ceil(n / 8)), the (n - 32) identical dummy
+//                                rows are one extra, wavefront-replicated row; CB = ceil(n / 8)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  const int x = __float_as_int(v);
+  return __int_as_float(__builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false));   // every lane has a source: `old` is dead
+}
+__device__ __forceinline__ float lane_xor16(float v) {
+  const int x = __float_as_int(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  return __int_as_float((threadIdx.x & 16) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float bj_sum(float v) { v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); return v; }
+__device__ __forceinline__ float bj_max(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v));
+  return v;
+}
+__device__ __forceinline__ float bi_sum(float v) { v += dpp_f<0x128>(v); v += lane_xor16(v); v += other_half(v); return v; }
+__device__ __forceinline__ float bi_max(float v) {
+  v = fmaxf(v, dpp_f<0x128>(v)); v = fmaxf(v, lane_xor16(v)); v = fmaxf(v, other_half(v));
+  return v;
+}
+
+template <bool kTr, int CB>
+__device__ __forceinline__ void sk_wave_project_blk(const float* Vb, int n, float scale, int iters, float* Ub) {
+  const int lane = threadIdx.x & 63, bi = lane >> 3, bj = lane & 7;
+  const float D = -100.0f * TTDG_LOG2E;
+  const int c = kTr ? n : NU;                       // columns of the oriented problem
+  const int mult = kTr ? n - NU : NU - n;           // identical dummy rows
+  constexpr int cbu = CB;                            // kTr: the caller instantiates CB = ceil(n / 8)
+  float L[4][CB], f[4], g[CB], w[4];
+  bool rused[4], cused[CB];
+#pragma unroll
+  for (int b = 0; b < CB; ++b) { cused[b] = kTr ? (bj + 8 * b < c) : true; g[b] = 0.f; }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int p = 4 * bi + a;
+    f[a] = 0.f;
+    if (kTr) { rused[a] = true; w[a] = 1.f; }
+    else { rused[a] = p < n || (p == n && mult > 0); w[a] = p < n ? 1.f : (rused[a] ? (float)mult : 0.f); }
+  }
+  if (kTr) {
+#pragma unroll
+    for (int b = 0; b < CB; ++b) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b < cbu && cused[b]) v = *reinterpret_cast<const float4*>(Vb + (bj + 8 * b) * NU + 4 * bi);
+      const bool u = b < cbu && cused[b];
+      L[0][b] = u ? v.x * scale : NEG_BIG; L[1][b] = u ? v.y * scale : NEG_BIG;
+      L[2][b] = u ? v.z * scale : NEG_BIG; L[3][b] = u ? v.w * scale : NEG_BIG;
+    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int p = 4 * bi + a;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p < n) v = *reinterpret_cast<const float4*>(Vb + p * NU + 4 * bj);
+      const float fill = rused[a] ? D : NEG_BIG;
+      L[a][0] = p < n ? v.x * scale : fill; L[a][1] = p < n ? v.y * scale : fill;
+      L[a][2] = p < n ? v.z * scale : fill; L[a][3] = p < n ? v.w * scale : fill;
+    }
+  }
+  float fd = 0.f;                                    // kTr: potential of the dummy rows
+  const bool dummy = kTr && mult > 0;
+  for (int it = 0; it < iters; it += 2) {
+    const bool cols_too = it + 1 < iters;
+    float fn[4], gn[CB], fdn = fd;
+    bool exact = it == 0;
+    if (!exact) {
+      float e[4][CB], s[4], ed[CB], sd = 0.f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        float acc = 0.f;
+#pragma unroll
+        for (int b = 0; b < CB; ++b)
+          if (b < cbu) { e[a][b] = fast_exp2((L[a][b] - f[a]) - g[b]); acc += e[a][b]; }
+        s[a] = bj_sum(acc);
+      }
+      // every sum that is used must stay inside [2^-60, 1e6]: tracked as one running minimum and maximum (a NaN can only come
+      // from 0 * inf, i.e. after a zero or infinite sum that the two bounds have already caught)
+      float lo = 1.f, hi = 1.f;
+      if (dummy) {
+#pragma unroll
+        for (int b = 0; b < CB; ++b)
+          if (b < cbu) { ed[b] = cused[b] ? fast_exp2((D - fd) - g[b]) : 0.f; sd += ed[b]; }
+        sd = bj_sum(sd);
+        lo = sd; hi = sd;
+        fdn = fd + fast_log2(sd);
+      }
+      float r[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const float su = rused[a] ? s[a] : 1.f;
+        lo = fminf(lo, su); hi = fmaxf(hi, su);
+        fn[a] = rused[a] ? f[a] + fast_log2(s[a]) : 0.f;
+        r[a] = rused[a] ? w[a] * __builtin_amdgcn_rcpf(s[a]) : 0.f;
+      }
+      if (cols_too) {
+        const float rd = dummy ? (float)mult * __builtin_amdgcn_rcpf(sd) : 0.f;
+#pragma unroll
+        for (int b = 0; b < CB; ++b)
+          if (b < cbu) {
+            float acc = (e[0][b] * r[0] + e[1][b] * r[1]) + (e[2][b] * r[2] + e[3][b] * r[3]);
+            acc = bi_sum(acc);
+            if (dummy) acc += ed[b] * rd;
+            const float cu = cused[b] ? acc : 1.f;
+            lo = fminf(lo, cu); hi = fmaxf(hi, cu);
+            gn[b] = cused[b] ? g[b] + fast_log2(acc) : 0.f;
+          }
+      }
+      exact = __ballot(!(lo >= 8.6736174e-19f && hi <= 1.0e6f)) != 0ull;
+    }
+    if (exact) {
+      // rows, max-subtracted
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        float m = NEG_BIG;
+#pragma unroll
+        for (int b = 0; b < CB; ++b) if (b < cbu) m = fmaxf(m, L[a][b] - g[b]);
+        m = bj_max(m);
+        const float ms = (m == NEG_BIG) ? 0.f : m;
+        float acc = 0.f;
+#pragma unroll
+        for (int b = 0; b < CB; ++b) if (b < cbu) acc += fast_exp2((L[a][b] - g[b]) - ms);
+        acc = bj_sum(acc);
+        fn[a] = rused[a] ? ms + fast_log2(acc) : 0.f;
+      }
+      if (dummy) {
+        float m = NEG_BIG;
+#pragma unroll
+        for (int b = 0; b < CB; ++b) if (b < cbu && cused[b]) m = fmaxf(m, -g[b]);
+        m = bj_max(m);
+        float acc = 0.f;
+#pragma unroll
+        for (int b = 0; b < CB; ++b) if (b < cbu && cused[b]) acc += fast_exp2(-g[b] - m);
+        acc = bj_sum(acc);
+        fdn = D + m + fast_log2(acc);
+      }
+      if (cols_too) {
+        const float td = dummy ? D - fdn : NEG_BIG;
+#pragma unroll
+        for (int b = 0; b < CB; ++b)
+          if (b < cbu) {
+            float m = fmaxf(fmaxf(L[0][b] - fn[0], L[1][b] - fn[1]), fmaxf(L[2][b] - fn[2], L[3][b] - fn[3]));
+            m = fmaxf(bi_max(m), td);
+            const float ms = (m == NEG_BIG) ? 0.f : m;
+            float acc = (w[0] * fast_exp2((L[0][b] - fn[0]) - ms) + w[1] * fast_exp2((L[1][b] - fn[1]) - ms)) +
+                        (w[2] * fast_exp2((L[2][b] - fn[2]) - ms) + w[3] * fast_exp2((L[3][b] - fn[3]) - ms));
+            acc = bi_sum(acc);
+            if (dummy) acc += (float)mult * fast_exp2(td - ms);
+            gn[b] = cused[b] ? ms + fast_log2(acc) : 0.f;
+          }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) f[a] = fn[a];
+    fd = fdn;
+    if (cols_too) {
+#pragma unroll
+      for (int b = 0; b < CB; ++b) if (b < cbu) g[b] = gn[b];
+    }
+  }
+  // U = exp(L - f - g)
+  if (kTr) {
+#pragma unroll
+    for (int b = 0; b < CB; ++b)
+      if (b < cbu && cused[b]) {
+        float4 o;
+        o.x = fast_exp2((L[0][b] - f[0]) - g[b]); o.y = fast_exp2((L[1][b] - f[1]) - g[b]);
+        o.z = fast_exp2((L[2][b] - f[2]) - g[b]); o.w = fast_exp2((L[3][b] - f[3]) - g[b]);
+        *reinterpret_cast<float4*>(Ub + (bj + 8 * b) * NU + 4 * bi) = o;
+      }
+  } else {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+      if (4 * bi + a < n) {
+        float4 o;
+        o.x = fast_exp2((L[a][0] - f[a]) - g[0]); o.y = fast_exp2((L[a][1] - f[a]) - g[1]);
+        o.z = fast_exp2((L[a][2] - f[a]) - g[2]); o.w = fast_exp2((L[a][3] - f[a]) - g[3]);
+        *reinterpret_cast<float4*>(Ub + (4 * bi + a) * NU + 4 * bj) = o;
+      }
+  }
+}
+
+// one instantiation per number of column groups in use: no guards inside the sweeps
+__device__ __forceinline__ void sk_project_blk(const float* Vb, int n, bool rows_are_nodes, float scale, int iters, float* Ub) {
+  if (rows_are_nodes) { sk_wave_project_blk<false, 4>(Vb, n, scale, iters, Ub); return; }
+  switch ((n + 7) >> 3) {
+    case 4: sk_wave_project_blk<true, 4>(Vb, n, scale, iters, Ub); break;      // the 32-node block that stays transposed
+    case 5: sk_wave_project_blk<true, 5>(Vb, n, scale, iters, Ub); break;
+    case 6: sk_wave_project_blk<true, 6>(Vb, n, scale, iters, Ub); break;
+    case 7: sk_wave_project_blk<true, 7>(Vb, n, scale, iters, Ub); break;
+    default: sk_wave_project_blk<true, 8>(Vb, n, scale, iters, Ub); break;
+  }
+}
+
+// Convergence terms of one graph block (cnt = 32 n values), by the wavefront that has just projected it: adds the block's share
+// of ||U - lastU||^2 and ||U - lastU2||^2, then lastU2 <- lastU.  lastU2 is in global memory: a batch of float4 loads is issued
+// before anything depends on it (one L2 round trip per batch).
+__device__ __forceinline__ void conv_block(const float* Unew, const float* Uold, float* Uprev2, float* U1snap, int cnt, float& d1,
+                                           float& d2) {
+  const int lane = threadIdx.x & 63;
+  const int n4 = cnt >> 2;
+  const float4* N4 = reinterpret_cast<const float4*>(Unew);
+  const float4* O4 = reinterpret_cast<const float4*>(Uold);
+  float4* P4 = reinterpret_cast<float4*>(Uprev2);
+  float4* S4 = reinterpret_cast<float4*>(U1snap);
+  for (int e0 = 0; e0 < n4; e0 += 64 * 4) {
+    float4 p[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = e0 + q * 64 + lane;
+      p[q] = P4[min(e, n4 - 1)];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = e0 + q * 64 + lane;
+      if (e < n4) {
+        const float4 un = N4[e], uc = O4[e];
+        if (U1snap) S4[e] = un;
+        float a, b;
+        a = un.x - uc.x; b = un.x - p[q].x; d1 = fmaf(a, a, d1); d2 = fmaf(b, b, d2);
+        a = un.y - uc.y; b = un.y - p[q].y; d1 = fmaf(a, a, d1); d2 = fmaf(b, b, d2);
+        a = un.z - uc.z; b = un.z - p[q].z; d1 = fmaf(a, a, d1); d2 = fmaf(b, b, d2);
+        a = un.w - uc.w; b = un.w - p[q].w; d1 = fmaf(a, a, d1); d2 = fmaf(b, b, d2);
+        P4[e] = uc;
+      }
+    }
+  }
+}
+
 template <int GA_WAVES>
 __device__ __forceinline__ float block_sum2(float a, float b, float* red, float& outb) {
   a = wave_sum_f32_dpp(a);
@@ -241,56 +481,172 @@ __host__ __device__ inline size_t ga_ws_hist_off(int M) {
   return (size_t)2 * M * NU + (size_t)M * Mp + (size_t)4 * NU * (Mp + 1);
 }
 
-// V rows [i0, i0+32): (2q * B S + W U) / G on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
-//   W U : A operand = W^T stored [k][i] (leading dimension Mp, zero padded) -> the 32 lanes of a half-wave read 32
-//         consecutive words; B operand = U[k][u].
-//   B S : A operand = B^T stored [v][i] (leading dimension Mp + 1); B operand = S[v][u].
-__device__ __forceinline__ void v_row_tile(int i0, int M, int Mp, const float* WT, const float* Ucur, const float* BT,
-                                           const float* S, float qw2, float invG, float* V, float* V0snap) {
-  const int lane = threadIdx.x & 63, li = lane & 31, kh = lane >> 5;
-  f32x16 acc;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- MFMA tiles of the three products (v_mfma_f32_16x16x4_f32, exact fp32) ------------------------------------------------
+// Operand mapping: A[i][k] in lane (i = lane & 15, k = lane >> 4), B[k][j] likewise, D[4 * (lane >> 4) + r][lane & 15].
+// All three walk K in blocks of 16 (four MFMA k-steps) with the operands of the NEXT block requested before the MFMAs of the
+// current one are issued (two register sets, ping-pong): left to itself the compiler schedules load - wait - MFMA pair by pair
+// (an LDS round trip per k-step: 170 cycles for 64 cycles of matrix work); __builtin_amdgcn_sched_barrier pins the order.
+// Addresses past the end of K are clamped and the operand zeroed by select: no branches, one wait per block.
+struct MmBlk { float a[4], b0[4], b1[4]; };
+
+__device__ __forceinline__ void mm_issue(const MmBlk& x, f32x4& acc0, f32x4& acc1) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  // operands are fetched eight k-pairs ahead of the MFMAs that consume them (LDS / L2 latency off the chain)
-  int k0 = 0;
-  for (; k0 + 16 <= M; k0 += 16) {
-    float a[8], b[8];
+  for (int q = 0; q < 4; ++q) {
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.a[q], x.b0[q], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.a[q], x.b1[q], acc1, 0, 0, 0);
+  }
+}
+
+// K loop shared by the tiles: load(blk, k0) requests one block of raw operands (clamped addresses, nothing depends on the
+// values yet); fix(blk, k0) zeroes / scales the A operand of the k-steps past the end right before the block's MFMAs, so the
+// wait for a block's loads sits AFTER the previous block's matrix work.  One zero operand is enough: B stays raw.
+template <class Load, class Fix>
+__device__ __forceinline__ void mm_k_loop(int K, Load load, Fix fix, f32x4& acc0, f32x4& acc1) {
+  MmBlk p, q;
+  load(p, 0);
+  for (int k0 = 0;;) {
+    if (k0 + 16 < K) load(q, k0 + 16);
+    __builtin_amdgcn_sched_barrier(0);
+    fix(p, k0);
+    mm_issue(p, acc0, acc1);
+    __builtin_amdgcn_sched_barrier(0);
+    k0 += 16;
+    if (k0 >= K) break;
+    if (k0 + 16 < K) load(p, k0 + 16);
+    __builtin_amdgcn_sched_barrier(0);
+    fix(q, k0);
+    mm_issue(q, acc0, acc1);
+    __builtin_amdgcn_sched_barrier(0);
+    k0 += 16;
+    if (k0 >= K) break;
+  }
+}
+
+// V rows [i0, i0 + 16): (2q * B S + W U) / G; two 16-column accumulators share the A operand.  16-row tiles: a multi-graph of
+// ~120 nodes is 8 tiles = one per wavefront (round 1's 32-row tiles kept half of the workgroup idle).
+//   W U : A operand = W^T stored [k][i] (leading dimension Mp, zero padded): 16 consecutive words per k; B operand = U[k][u]
+//   B S : A operand = B^T stored [v][i] (leading dimension Mp + 1); B operand = S[v][u], summed here from its KS K-split partials
+template <int KS>
+__device__ __forceinline__ void v_row_tile16(int i0, int M, int Mp, const float* WT, const float* Ucur, const float* BT,
+                                             const float* S, float qw2, float invG, float* V, float* V0snap) {
+  const int lane = threadIdx.x & 63, li = lane & 15, kq = lane >> 4;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  mm_k_loop(M, [&](MmBlk& x, int k0) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int k = k0 + 2 * q + kh;
-      a[q] = WT[(size_t)k * Mp + i0 + li];
-      b[q] = Ucur[k * NU + li];
+    for (int q = 0; q < 4; ++q) {
+      const int kc = min(k0 + 4 * q + kq, M - 1);
+      x.a[q] = WT[(size_t)kc * Mp + i0 + li];
+      x.b0[q] = Ucur[kc * NU + li];
+      x.b1[q] = Ucur[kc * NU + 16 + li];
     }
+  }, [&](MmBlk& x, int k0) {
+    if (k0 + 16 > M) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
-  }
-  for (; k0 < M; k0 += 2) {
-    const int k = k0 + kh;
-    const bool ok = k < M;
-    const float a = ok ? WT[(size_t)k * Mp + i0 + li] : 0.f;
-    const float b = ok ? Ucur[k * NU + li] : 0.f;
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-  }
+      for (int q = 0; q < 4; ++q) x.a[q] = (k0 + 4 * q + kq < M) ? x.a[q] : 0.f;
+    }
+  }, acc0, acc1);
   const int ldb = Mp + 1;
-  {
-    float a[16], b[16];
-    const bool rok = i0 + li < M;
+  const bool rok = i0 + li < M;
+  mm_k_loop(NU, [&](MmBlk& x, int k0) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int k = 2 * q + kh;
-      a[q] = rok ? BT[k * ldb + i0 + li] * qw2 : 0.f;
-      b[q] = S[k * NU + li];
+    for (int q = 0; q < 4; ++q) {
+      const int k = k0 + 4 * q + kq;
+      x.a[q] = BT[k * ldb + i0 + li];                // i0 + li < Mp: inside the buffer; rows >= M are not B
+      x.b0[q] = S[k * NU + li];
+      x.b1[q] = S[k * NU + 16 + li];
+      if (KS == 2) { x.b0[q] += S[NU * NU + k * NU + li]; x.b1[q] += S[NU * NU + k * NU + 16 + li]; }
     }
+  }, [&](MmBlk& x, int) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc, 0, 0, 0);
+    for (int q = 0; q < 4; ++q) x.a[q] = rok ? x.a[q] * qw2 : 0.f;
+  }, acc0, acc1);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = i0 + 4 * kq + r;
+    if (row < M) {
+      const float v0 = acc0[r] * invG, v1 = acc1[r] * invG;
+      V[row * NU + li] = v0;
+      V[row * NU + 16 + li] = v1;
+      if (V0snap) { V0snap[row * NU + li] = v0; V0snap[row * NU + 16 + li] = v1; }
+    }
+  }
+}
+
+// One 16 x 16 tile (ti, tj) of S = U^T B over the node rows [rbeg, rend): A operand = U[r][u] (16 consecutive words per r),
+// B operand = B[r][v] read from the transposed store X[v][r] (odd leading dimension: conflict-free).  Even and odd k-steps
+// go to two accumulators (two independent MFMA chains), added at the end.
+__device__ __forceinline__ void s_tile16(int ti, int tj, int rbeg, int rend, int ldb, const float* Ucur, const float* X, float* Sout) {
+  const int lane = threadIdx.x & 63, li = lane & 15, kq = lane >> 4;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  struct Blk { float a[4], b[4]; };
+  const int K = rend - rbeg;
+  auto load = [&](Blk& x, int k0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int rc = min(rbeg + k0 + 4 * q + kq, rend - 1);
+      x.a[q] = Ucur[rc * NU + ti * 16 + li];
+      x.b[q] = X[(tj * 16 + li) * ldb + rc];
+    }
+  };
+  auto issue = [&](Blk& x, int k0) {
+    if (k0 + 16 > K) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x.a[q] = (k0 + 4 * q + kq < K) ? x.a[q] : 0.f;
+    }
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.a[0], x.b[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.a[1], x.b[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.a[2], x.b[2], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x.a[3], x.b[3], acc1, 0, 0, 0);
+  };
+  Blk p, q;
+  load(p, 0);
+  for (int k0 = 0;;) {
+    if (k0 + 16 < K) load(q, k0 + 16);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(p, k0);
+    __builtin_amdgcn_sched_barrier(0);
+    k0 += 16;
+    if (k0 >= K) break;
+    if (k0 + 16 < K) load(p, k0 + 16);
+    __builtin_amdgcn_sched_barrier(0);
+    issue(q, k0);
+    __builtin_amdgcn_sched_barrier(0);
+    k0 += 16;
+    if (k0 >= K) break;
   }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-    if (row < M) {
-      const float val = acc[r] * invG;
-      V[row * NU + li] = val;
-      if (V0snap) V0snap[row * NU + li] = val;
+  for (int r = 0; r < 4; ++r) Sout[(ti * 16 + 4 * kq + r) * NU + tj * 16 + li] = acc0[r] + acc1[r];
+}
+
+// B_g = A_g U_g, rows [i0, i0 + 16) of graph g (n nodes starting at node o), stored transposed X[u][node] (leading
+// dimension ldb).  kAT: the A block is the TRANSPOSED copy staged in LDS (At[k][i]: 16 consecutive words per k),
+// otherwise the caller's row-major block in global memory.
+template <bool kAT>
+__device__ __forceinline__ void b_row_tile16(int o, int n, int i0, const float* Ag, const float* Ucur, float* X, int ldb) {
+  const int lane = threadIdx.x & 63, li = lane & 15, kq = lane >> 4;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  const int i = i0 + li, ic = min(i, n - 1);
+  const bool iok = i < n;
+  mm_k_loop(n, [&](MmBlk& x, int k0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int kc = min(k0 + 4 * q + kq, n - 1);
+      x.a[q] = kAT ? Ag[kc * n + ic] : Ag[ic * n + kc];
+      x.b0[q] = Ucur[(o + kc) * NU + li];
+      x.b1[q] = Ucur[(o + kc) * NU + 16 + li];
+    }
+  }, [&](MmBlk& x, int k0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) x.a[q] = (iok && k0 + 4 * q + kq < n) ? x.a[q] : 0.f;
+  }, acc0, acc1);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = i0 + 4 * kq + r;
+    if (row < n) {
+      X[li * ldb + o + row] = acc0[r];
+      X[(16 + li) * ldb + o + row] = acc1[r];
     }
   }
 }
@@ -303,7 +659,7 @@ template <bool kLds, bool kWLds, bool kALds, int GA_THREADS, int CWMAX>
 __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restrict__ Apack, const float* __restrict__ W,
                                                           const float* __restrict__ U0, ttdg_graphs_t gr,
                                                           ttdg_gagm_cfg_t cfg, float* __restrict__ Uout,
-                                                          int32_t* __restrict__ info, float* __restrict__ ws, int cmaxp) {
+                                                          int32_t* __restrict__ info, float* __restrict__ ws, int cmaxp, int flags) {
   extern __shared__ __attribute__((aligned(16))) float ga_smem[];
   constexpr int GA_WAVES = GA_THREADS / 64;
   const int M = gr.off[gr.G], G = gr.G;
@@ -324,16 +680,13 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
   float* lds = ga_smem;
   float* base = kLds ? lds : WTg + (size_t)M * Mp;
   if (kLds) lds += 3 * SB;
-  // lastU2 is only touched by the convergence check, always by the same thread for the same element: it lives in
-  // registers (kLds: M <= 256 -> at most 16 values per thread) or in the workspace, never in LDS
+  // lastU2 is only touched by the convergence check: it lives in the (L2-resident) workspace, read and rewritten by the
+  // wavefront that has just projected the graph (conv_block) - round 1 kept it in 16 registers per thread, which the register
+  // allocator spilled to scratch around the projection and reloaded one dependent access at a time (11k cycles per iteration)
   float* Ucur = base;
   float* X = base + SB;
   float* V = base + 2 * SB;
-  float* Uprev_g = base + 3 * SB;             // used only when !kLds
-  constexpr int UPK = 8192 / GA_THREADS;     // lastU2 values per thread: covers M * 32 <= 8192
-  float uprev[UPK];
-#pragma unroll
-  for (int k = 0; k < UPK; ++k) uprev[k] = 0.f;
+  float* Uprev_g = WTg + (size_t)M * Mp + (size_t)3 * SB;
   const float* WT = WTg;
   const float* Ap = Apack;
   if (kWLds) { WT = lds; lds += M * Mp; }
@@ -358,16 +711,24 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
     for (int g = 0; g < G; ++g) { s_aoff[g] = a; const int n = gr.off[g + 1] - gr.off[g]; a += n * n; }
   }
   for (int r = tid; r < M; r += GA_THREADS) s_gid[r] = (unsigned char)graph_of(gr, r);
-  for (int e = tid; e < MU; e += GA_THREADS) { Ucur[e] = U0[e]; if (!kLds) Uprev_g[e] = 0.f; }   // lastU = zeros (:305)
+  for (int e = tid; e < MU; e += GA_THREADS) { Ucur[e] = U0[e]; Uprev_g[e] = 0.f; }   // lastU = zeros (:305)
   {  // W^T[k][i] = W[i][k], zero padded to Mp columns; A blocks
     float* wt = kWLds ? const_cast<float*>(WT) : WTg;
     for (int e = tid; e < M * Mp; e += GA_THREADS) {
       const int k = e / Mp, i = e - k * Mp;
       wt[e] = (i < M) ? W[(size_t)i * M + k] : 0.f;
     }
-    if (kALds) {
+    if (kALds) {   // every block TRANSPOSED (At[k][i]): the MFMA A operand of B = A U reads 16 consecutive words per k
       float* ap = const_cast<float*>(Ap);
-      for (int e = tid; e < asz; e += GA_THREADS) ap[e] = Apack[e];
+      int a0 = 0;
+      for (int g = 0; g < G; ++g) {
+        const int n = gr.off[g + 1] - gr.off[g];
+        for (int e = tid; e < n * n; e += GA_THREADS) {
+          const int i = e / n, k = e - i * n;
+          ap[a0 + k * n + i] = Apack[a0 + e];
+        }
+        a0 += n * n;
+      }
     }
   }
   __syncthreads();
@@ -378,88 +739,49 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
   const float qw2 = cfg.quad_weight * 2.f, invG = 1.f / (float)G;
   bool first = true;
   const int ldb = Mp + 1;
-  long long tick = 0, tph[5] = {0, 0, 0, 0, 0};
+  // phase timers (cfg.profile): kept in LDS, not in registers that would be live across the whole solve
+  __shared__ long long s_tph[6];
+  if (tid < 6) s_tph[tid] = 0;
 #define GA_PHASE(k)                                                    \
   if (cfg.profile && tid == 0) {                                       \
     const long long now = (long long)__builtin_readcyclecounter();     \
-    tph[k] += now - tick;                                              \
-    tick = now;                                                        \
+    s_tph[k] += now - s_tph[5];                                        \
+    s_tph[5] = now;                                                    \
   }
-  if (cfg.profile && tid == 0) tick = (long long)__builtin_readcyclecounter();
+  __syncthreads();
+  if (cfg.profile && tid == 0) s_tph[5] = (long long)__builtin_readcyclecounter();
 
   for (;;) {   // stages (:311)
     int i = 0;
     for (; i < cfg.max_iter; ++i) {   // :312
-      // ---- B = A U, block diagonal, stored transposed: X[u][row] ----
-      for (int e = tid; e < M * 8; e += GA_THREADS) {
-        const int row = e >> 3, u = (e & 7) * 4;
-        const int g = s_gid[row];
-        const int o = s_off[g], n = s_off[g + 1] - o;
-        const float* arow = Ap + s_aoff[g] + (size_t)(row - o) * n;
-        const float* ub = Ucur + o * NU + u;
-        float4 c0 = make_float4(0.f, 0.f, 0.f, 0.f), c1 = c0;
-        int j = 0;
-        // eight columns per round, all sixteen LDS reads issued before the first FMA (the two-at-a-time loop below pays
-        // one LDS round trip per pair); same two accumulators, same order: bit-identical sums
-        for (; j + 8 <= n; j += 8) {
-          float a[8];
-          float4 x[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) { a[q] = arow[j + q]; x[q] = *reinterpret_cast<const float4*>(ub + (j + q) * NU); }
-#pragma unroll
-          for (int q = 0; q < 8; q += 2) {
-            c0.x = fmaf(a[q], x[q].x, c0.x); c0.y = fmaf(a[q], x[q].y, c0.y); c0.z = fmaf(a[q], x[q].z, c0.z); c0.w = fmaf(a[q], x[q].w, c0.w);
-            c1.x = fmaf(a[q + 1], x[q + 1].x, c1.x); c1.y = fmaf(a[q + 1], x[q + 1].y, c1.y);
-            c1.z = fmaf(a[q + 1], x[q + 1].z, c1.z); c1.w = fmaf(a[q + 1], x[q + 1].w, c1.w);
-          }
+      // ---- B = A U, block diagonal, stored transposed: X[u][row]; 16-row MFMA tiles dealt round-robin to the wavefronts ----
+      {
+        int t = 0;
+        for (int g = 0; g < G; ++g) {
+          const int o = s_off[g], n = s_off[g + 1] - o;
+          for (int i0 = 0; i0 < n; i0 += 16, ++t)
+            if ((t % GA_WAVES) == wave) b_row_tile16<kALds>(o, n, i0, Ap + s_aoff[g], Ucur, X, ldb);
         }
-        for (; j + 2 <= n; j += 2) {
-          const float a0 = arow[j], a1 = arow[j + 1];
-          const float4 x0 = *reinterpret_cast<const float4*>(ub + j * NU), x1 = *reinterpret_cast<const float4*>(ub + (j + 1) * NU);
-          c0.x = fmaf(a0, x0.x, c0.x); c0.y = fmaf(a0, x0.y, c0.y); c0.z = fmaf(a0, x0.z, c0.z); c0.w = fmaf(a0, x0.w, c0.w);
-          c1.x = fmaf(a1, x1.x, c1.x); c1.y = fmaf(a1, x1.y, c1.y); c1.z = fmaf(a1, x1.z, c1.z); c1.w = fmaf(a1, x1.w, c1.w);
-        }
-        if (j < n) {
-          const float a0 = arow[j];
-          const float4 x0 = *reinterpret_cast<const float4*>(ub + j * NU);
-          c0.x = fmaf(a0, x0.x, c0.x); c0.y = fmaf(a0, x0.y, c0.y); c0.z = fmaf(a0, x0.z, c0.z); c0.w = fmaf(a0, x0.w, c0.w);
-        }
-        X[(u + 0) * ldb + row] = c0.x + c1.x;
-        X[(u + 1) * ldb + row] = c0.y + c1.y;
-        X[(u + 2) * ldb + row] = c0.z + c1.z;
-        X[(u + 3) * ldb + row] = c0.w + c1.w;
       }
       __syncthreads();
       GA_PHASE(0)
-      // ---- S = U^T B : 32x32 output, K = M split over the first four wavefronts (MFMA), partials summed in LDS ----
-      if (wave < 4) {
-        const int li = lane & 31, kh = lane >> 5;
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        const int chunk = ((M + 7) / 8) * 2;              // rows per wavefront, even
-        const int rbeg = wave * chunk, rend = min(M, rbeg + chunk);
-        for (int r0 = rbeg; r0 < rend; r0 += 2) {
-          const int r = r0 + kh;
-          const bool ok = r < rend;
-          const float a = ok ? Ucur[r * NU + li] : 0.f;      // (u = li, k = r)
-          const float b = ok ? X[li * ldb + r] : 0.f;        // (k = r, v = li)
-          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Spart[wave * NU * NU + ((r & 3) + 8 * (r >> 2) + 4 * kh) * NU + li] = acc[r];
+      // ---- S = U^T B : four 16 x 16 tiles x KS halves of K = M, one per wavefront; the V tiles add the KS partials ----
+      {
+        constexpr int KS = GA_WAVES / 4;
+        const int kh = ((M + KS - 1) / KS + 3) & ~3;
+        const int half = wave >> 2, t = wave & 3;
+        if (half * kh < M) s_tile16(t >> 1, t & 1, half * kh, min(M, (half + 1) * kh), ldb, Ucur, X, Spart + half * NU * NU);
+        else for (int e = lane; e < 16 * 16; e += 64) Spart[half * NU * NU + ((t >> 1) * 16 + (e >> 4)) * NU + (t & 1) * 16 + (e & 15)] = 0.f;
       }
       __syncthreads();
-      for (int e = tid; e < NU * NU; e += GA_THREADS)
-        S[e] = (Spart[e] + Spart[NU * NU + e]) + (Spart[2 * NU * NU + e] + Spart[3 * NU * NU + e]);
-      __syncthreads();
       GA_PHASE(1)
-      // ---- V = (2q B S + W U) / G : one wavefront per 32-row tile, MFMA ----
-      for (int t = wave; t * 32 < M; t += GA_WAVES)
-        v_row_tile(t * 32, M, Mp, WT, Ucur, X, S, qw2, invG, V, first ? V0snap : nullptr);
+      // ---- V = (2q B S + W U) / G : one wavefront per 16-row tile, MFMA ----
+      for (int t = wave; t * 16 < M; t += GA_WAVES)
+        v_row_tile16<GA_WAVES / 4>(t * 16, M, Mp, WT, Ucur, X, Spart, qw2, invG, V, first ? V0snap : nullptr);
       __syncthreads();
       GA_PHASE(2)
-      // ---- projection (X <- projected U), one wavefront per graph ----
+      // ---- projection (X <- projected U) and the graph's convergence terms, one wavefront per graph ----
+      float d1 = 0.f, d2 = 0.f;
       for (int g = wave; g < G; g += GA_WAVES) {
         const int o = s_off[g], n = s_off[g + 1] - o;
         float* Ub = X + o * NU;
@@ -468,7 +790,9 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
           float* fbuf = wex + wave * wex_stride;
           float* gbuf = fbuf + 40;
           const float scale = TTDG_LOG2E / tau;
-          if (n < NU || (n == NU && !sq_tr)) sk_wave_project_narrow(Vb, n, scale, cfg.sk_iter, Ub, fbuf, gbuf);
+          const bool rows_are_nodes = n < NU || (n == NU && !sq_tr);
+          if (!(flags & 1) && n <= 64) sk_project_blk(Vb, n, rows_are_nodes, scale, cfg.sk_iter, Ub);
+          else if (rows_are_nodes) sk_wave_project_narrow(Vb, n, scale, cfg.sk_iter, Ub, fbuf, gbuf);
           else if (CWMAX == 1 || n <= 64) sk_wave_project<1>(Vb, n, scale, cfg.sk_iter, Ub, fbuf, gbuf, n == NU);
           else sk_wave_project<CWMAX>(Vb, n, scale, cfg.sk_iter, Ub, fbuf, gbuf);
         } else {
@@ -489,39 +813,13 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
             }
           }
         }
+        if (G == 2 && g == 0)   // :358-359
+          for (int e = lane; e < n * NU; e += 64) Ub[e] = ((e >> 5) == (e & 31)) ? 1.f : 0.f;
+        wave_sync();
+        conv_block(Ub, Ucur + o * NU, Uprev_g + o * NU, first ? U1snap + o * NU : nullptr, n * NU, d1, d2);
       }
-      __syncthreads();
       GA_PHASE(3)
-      if (G == 2) {   // :358-359
-        const int n0 = s_off[1];
-        for (int e = tid; e < n0 * NU; e += GA_THREADS) X[e] = ((e >> 5) == (e & 31)) ? 1.f : 0.f;
-        __syncthreads();
-      }
-      // ---- convergence (:361) ----
-      float d1 = 0.f, d2 = 0.f;
-      if (kLds) {
-#pragma unroll
-        for (int k = 0; k < UPK; ++k) {
-          const int e = tid + k * GA_THREADS;
-          if (e < MU) {
-            const float un = X[e], uc = Ucur[e];
-            if (first) U1snap[e] = un;
-            const float a = un - uc, b = un - uprev[k];
-            d1 = fmaf(a, a, d1);
-            d2 = fmaf(b, b, d2);
-            uprev[k] = uc;                       // lastU2 <- lastU
-          }
-        }
-      } else {
-        for (int e = tid; e < MU; e += GA_THREADS) {
-          const float un = X[e], uc = Ucur[e];
-          if (first) U1snap[e] = un;
-          const float a = un - uc, b = un - Uprev_g[e];
-          d1 = fmaf(a, a, d1);
-          d2 = fmaf(b, b, d2);
-          Uprev_g[e] = uc;
-        }
-      }
+      // ---- convergence (:361): the per-wavefront terms are added up; both barriers of the reduction also publish X ----
       float s2;
       const float s1 = block_sum2<GA_WAVES>(d1, d2, red, s2);
       GA_PHASE(4)
@@ -597,7 +895,7 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
   for (int e = tid; e < MU; e += GA_THREADS) Uout[e] = Ucur[e];
   if (tid == 0) {
     info[6] = total; info[7] = stage; info[8] = 0;
-    for (int k = 0; k < 5; ++k) info[9 + k] = (int32_t)(tph[k] >> 6);   // cycle counter ticks / 64 per phase
+    for (int k = 0; k < 5; ++k) info[9 + k] = (int32_t)(s_tph[k] >> 6);   // cycle counter ticks / 64 per phase
   }
 #undef GA_PHASE
 }
@@ -623,6 +921,8 @@ int ttdg_gagm_large_solve(const float* Apack, const float* W, const float* U0, t
 static int g_gagm_large_from = GAGM_LARGE_FROM_DEFAULT;
 static int g_gagm_threads = 0;   // 0 / 512 = the default 512 threads; 256 = the spill-free one-wavefront-per-SIMD build (A/B runs)
 extern "C" int ttdg_debug_set_gagm_threads(int threads) { g_gagm_threads = (threads == 256 || threads == 512) ? threads : 0; return 0; }
+static int g_gagm_flags = 0;     // bit 0: graphs of 32..64 nodes take the generic register projector instead of sk_wave_project_mid (A/B, parity tests)
+extern "C" int ttdg_debug_set_gagm_flags(int flags) { g_gagm_flags = flags; return 0; }
 extern "C" int ttdg_debug_set_gagm_large_from(int total_nodes) { g_gagm_large_from = total_nodes > 0 ? total_nodes : GAGM_LARGE_FROM_DEFAULT; return 0; }
 
 extern "C" size_t ttdg_gagm_workspace_bytes(int M) {
@@ -660,14 +960,13 @@ extern "C" int ttdg_gagm_solve(const float* Apack, const float* W, const float* 
   const size_t wb = (size_t)M * Mp * sizeof(float), ab = (size_t)((asz + 3) & ~3) * sizeof(float);
   const size_t cap = 158 * 1024;
   // what fits decides what is staged: state, then W^T (largest per-iteration reader), then the A blocks
-  const bool regs_ok = (size_t)M * NU <= (size_t)8192;   // lastU2 in registers: 8192 / threads values per thread
-  const int mode = !regs_ok ? 0 : (fixed + state + wb + ab <= cap) ? 3 : (fixed + state + wb <= cap) ? 2 : (fixed + state <= cap) ? 1 : 0;
+  const int mode = (fixed + state + wb + ab <= cap) ? 3 : (fixed + state + wb <= cap) ? 2 : (fixed + state <= cap) ? 1 : 0;
   const size_t bytes = fixed + (mode >= 1 ? state : 0) + (mode >= 2 ? wb : 0) + (mode >= 3 ? ab : 0);
   hipStream_t st = (hipStream_t)stream;
 #define GA_LAUNCH_T(L, WL, AL, C, T)                                                                                 \
   do {                                                                                                               \
     TTDG_ALLOW_LDS((gagm_kernel<L, WL, AL, T, C>), bytes);                                                           \
-    hipLaunchKernelGGL((gagm_kernel<L, WL, AL, T, C>), dim3(1), dim3(T), bytes, st, Apack, W, U0, gr, cfg, U, info, (float*)ws, cmaxp); \
+    hipLaunchKernelGGL((gagm_kernel<L, WL, AL, T, C>), dim3(1), dim3(T), bytes, st, Apack, W, U0, gr, cfg, U, info, (float*)ws, cmaxp, g_gagm_flags); \
   } while (0)
 #define GA_LAUNCH(L, WL, AL, C)                                          \
   do {                                                                   \
@@ -706,7 +1005,8 @@ __global__ __launch_bounds__(512) void debug_project_kernel(const float* __restr
     float* Ub = U + wave * n * NU;
     float* fbuf = wex + wave * 104;
     for (int r = 0; r < reps; ++r) {
-      if (mode == 0) { if (n <= NU) sk_wave_project_narrow(Vb, n, scale, iters, Ub, fbuf, fbuf + 40); else sk_wave_project<1>(Vb, n, scale, iters, Ub, fbuf, fbuf + 40); }
+      if (mode == 0) sk_project_blk(Vb, n, n <= NU, scale, iters, Ub);
+      else if (mode == 2) { if (n <= NU) sk_wave_project_narrow(Vb, n, scale, iters, Ub, fbuf, fbuf + 40); else sk_wave_project<1>(Vb, n, scale, iters, Ub, fbuf, fbuf + 40); }
       else {
         const bool tr = n > NU;
         const int nr = tr ? NU : n, nc = tr ? n : NU;
