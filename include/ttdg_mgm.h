@@ -247,10 +247,13 @@ int ttdg_paste_masks(const float* masks, const float* boxes, int R, int S, int H
                      unsigned char* out, ttdg_stream_t stream);
 
 /* y (N, C, H*W) <- act(y + bias[c] (+ residual) (+ bias2[c])) in place; bias / residual / bias2 may be NULL; relu != 0
- * applies max(., 0).  The shift of a folded FrozenBN, the residual add and the ReLU of a bottleneck in one pass
- * (forward-only: frozen stem / res2, the eval pass, the RPN head). */
+ * applies max(., 0), evaluated as (y + bias) + (residual + bias2).  The shift of a folded FrozenBN, the residual add and the
+ * ReLU of a bottleneck in one pass. */
 int ttdg_bias_act(float* y, const float* bias, const float* residual, const float* bias2, int N, int C, int HW,
                   int relu, ttdg_stream_t stream);
+/* backward of that epilogue with relu != 0: gin[e] = out[e] > 0 ? gout[e] : 0 over `total` floats (torch threshold_backward
+ * behind F.relu_, one pass; the result is the gradient of both the convolution output and the residual branch). */
+int ttdg_relu_bwd(const float* gout, const float* out, float* gin, size_t total, ttdg_stream_t stream);
 
 /* detectron2 ROIPooler [3P] in one launch: every ROI (image, x1, y1, x2, y2) picks its FPN level
  * clamp(floor(canonical_level + log2(sqrt(area) / canonical_size + 1e-8)), min_level, min_level + fp.n - 1) inside the

@@ -979,6 +979,40 @@ def test_fused_bias_residual_relu_epilogue(dev):
     assert maxerr(fused, plain) <= 1e-4 * max(1.0, float(plain.abs().max()))
 
 
+def test_fused_epilogue_with_gradients_is_the_plain_torch_block(dev):
+    """The adapted bottlenecks (gradients flow) take ops.BiasActFn - in-place shift / residual / ReLU with a one-pass backward.
+    Same arithmetic in the same order as conv-with-bias, add, F.relu_: outputs, input gradient and every filter gradient must
+    coincide with the plain torch formulation (the only difference allowed is the rounding inside the vendor convolutions,
+    which see bit-identical operands)."""
+    from ttdg_mgm_amd.modeling import backbone as bb
+    g = synth.gen(7410)
+    torch.manual_seed(1)
+    blocks = torch.nn.Sequential(bb.Bottleneck(64, 256, 64, 1), bb.Bottleneck(256, 256, 64, 1)).to(dev).train()
+    for m in blocks.modules():
+        if isinstance(m, bb.FrozenBatchNorm2d):
+            m.weight.copy_(synth.normal(g, m.weight.shape, 0.2).to(dev) + 1.0)
+            m.bias.copy_(synth.normal(g, m.bias.shape, 0.2).to(dev))
+            m.running_mean.copy_(synth.normal(g, m.bias.shape, 0.2).to(dev))
+    x0 = synth.normal(g, (2, 64, 56, 56), 1.0).to(dev)
+    wts = synth.normal(g, (2, 256, 56, 56), 1.0).to(dev)
+    res = {}
+    for fused in (True, False):
+        bb.FUSED_EPILOGUE = fused
+        try:
+            x = x0.clone().requires_grad_()
+            blocks.zero_grad(set_to_none=True)
+            out = blocks(x)
+            (out * wts).sum().backward()
+            res[fused] = (out.detach().clone(), x.grad.clone(), [p.grad.clone() for p in blocks.parameters()])
+        finally:
+            bb.FUSED_EPILOGUE = True
+    assert torch.equal(res[True][0], res[False][0])
+    assert maxerr(res[True][1], res[False][1]) <= 1e-5 * max(1.0, float(res[False][1].abs().max()))
+    assert len(res[True][2]) == 7 and all(t is not None for t in res[True][2])
+    for a, b in zip(res[True][2], res[False][2]):
+        assert maxerr(a, b) <= 1e-5 * max(1.0, float(b.abs().max()))
+
+
 def test_roi_align_multilevel_matches_per_level_pooler(dev):
     """ttdg_roi_align_multilevel (level chosen inside the kernel) against detectron2's ROIPooler formulation
     (level by level: assign, compact, ROIAlign, scatter) on the host."""

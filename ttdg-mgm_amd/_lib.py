@@ -86,6 +86,7 @@ SIGNATURES = {
     "ttdg_nchw_to_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _S]),
     "ttdg_roi_align_multilevel_nhwc": (C.c_int, [Fpn, Levels, _P, _I, _I, _F, _I, _I, _P, _S]),
     "ttdg_bias_act": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _S]),
+    "ttdg_relu_bwd": (C.c_int, [_P, _P, _P, C.c_size_t, _S]),
     "ttdg_paste_masks": (C.c_int, [_P, _P, _I, _I, _I, _I, _F, _P, _S]),
     "ttdg_mask_pair_counts": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _S]),
 }

@@ -367,31 +367,37 @@ extern "C" int ttdg_paste_masks(const float* masks, const float* boxes, int R, i
 // ---------------------------------------------------------------------------------------------------
 // y <- act(y + bias[c] (+ residual) (+ bias2[c])) in place on an NCHW activation: the per-channel shift of a folded
 // FrozenBN (or a conv bias), the residual add and the ReLU of a bottleneck in ONE pass over the tensor instead of three
-// or four (each pass over a 164 MB res2 activation costs ~65 us of HBM time).  Forward-only: used where no gradient
-// flows (frozen stem / res2, the eval pass, the RPN head).
+// or four (each pass over a 164 MB res2 activation costs ~65 us of HBM time).  In place; where gradients flow (res3 - res5 of
+// a TTA step) ops.BiasActFn pairs it with relu_bwd_kernel below.
 __global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias,
                                                        const float* __restrict__ res, const float* __restrict__ bias2, int C, int HW,
                                                        size_t total, int relu) {
+  // evaluation order of the unfused formulation, (y + bias) + (residual + bias2): bit-identical to conv-with-bias, add, ReLU
   if ((HW & 3) == 0) {
     const size_t nvec = total >> 2;
     for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (size_t)gridDim.x * 256) {
       const int c = (int)((v * 4 / HW) % C);
-      float b = bias ? bias[c] : 0.f;
-      if (bias2) b += bias2[c];
+      const float b = bias ? bias[c] : 0.f;
       float4 t = reinterpret_cast<float4*>(y)[v];
+      if (bias) { t.x += b; t.y += b; t.z += b; t.w += b; }
       if (res) {
-        const float4 r = reinterpret_cast<const float4*>(res)[v];
+        float4 r = reinterpret_cast<const float4*>(res)[v];
+        if (bias2) { const float b2 = bias2[c]; r.x += b2; r.y += b2; r.z += b2; r.w += b2; }
         t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
+      } else if (bias2) {
+        const float b2 = bias2[c];
+        t.x += b2; t.y += b2; t.z += b2; t.w += b2;
       }
-      t.x += b; t.y += b; t.z += b; t.w += b;
       if (relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
       reinterpret_cast<float4*>(y)[v] = t;
     }
   } else {
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
       const int c = (int)((e / HW) % C);
-      float t = y[e] + (bias ? bias[c] : 0.f) + (bias2 ? bias2[c] : 0.f);
-      if (res) t += res[e];
+      float t = y[e];
+      if (bias) t += bias[c];
+      if (res) t += bias2 ? res[e] + bias2[c] : res[e];
+      else if (bias2) t += bias2[c];
       y[e] = relu ? fmaxf(t, 0.f) : t;
     }
   }
@@ -407,6 +413,30 @@ extern "C" int ttdg_bias_act(float* y, const float* bias, const float* residual,
   const int blocks = (int)(want < 8192 ? want : 8192);
   hipLaunchKernelGGL(bias_act_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, bias, residual, bias2, C, HW, total, relu);
   return ttdg_launch_status("bias_act");
+}
+
+// Backward of the ReLU epilogue above where gradients do flow (the adapted res3 - res5 blocks): gin = out > 0 ? gout : 0,
+// one pass; the same tensor is the gradient of the convolution output AND of the residual branch.
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ out,
+                                                       float* __restrict__ gin, size_t total) {
+  const size_t nvec = total >> 2;
+  for (size_t v = (size_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (size_t)gridDim.x * 256) {
+    const float4 g = reinterpret_cast<const float4*>(gout)[v], o = reinterpret_cast<const float4*>(out)[v];
+    float4 r;
+    r.x = o.x > 0.f ? g.x : 0.f; r.y = o.y > 0.f ? g.y : 0.f; r.z = o.z > 0.f ? g.z : 0.f; r.w = o.w > 0.f ? g.w : 0.f;
+    reinterpret_cast<float4*>(gin)[v] = r;
+  }
+  for (size_t e = (nvec << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256)
+    gin[e] = out[e] > 0.f ? gout[e] : 0.f;
+}
+
+extern "C" int ttdg_relu_bwd(const float* gout, const float* out, float* gin, size_t total, ttdg_stream_t stream) {
+  TTDG_REQUIRE(gout && out && gin, "relu_bwd: null pointer");
+  if (total == 0) return 0;
+  const size_t want = (total / 4 + 255) / 256 + 1;
+  const int blocks = (int)(want < 8192 ? want : 8192);
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gout, out, gin, total);
+  return ttdg_launch_status("relu_bwd");
 }
 
 // ---------------------------------------------------------------------------------------------------

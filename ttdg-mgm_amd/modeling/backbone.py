@@ -32,6 +32,12 @@ def _fusable(x, *mods):
     return not x.requires_grad and not any(p.requires_grad for m in mods for p in m.parameters())
 
 
+def _fusable_on_tape(x):
+    """The adapted blocks (gradients flow): fp32 GPU tensors outside autocast take the in-place epilogue WITH its backward
+    (ops.BiasActFn); anything else (CPU host pipeline, bf16 autocast, calibration hooks) keeps the plain torch formulation."""
+    return FUSED_EPILOGUE and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled() and torch.is_grad_enabled()
+
+
 class FrozenBatchNorm2d(nn.Module):
     def __init__(self, c, eps=1e-5):
         super().__init__()
@@ -76,6 +82,11 @@ class ConvNorm(nn.Conv2d):
             with torch.no_grad():
                 self._wfold = (key, _publish(self.weight * scale))
         return F.conv2d(x, self._wfold[1], None, self.stride, self.padding), shift
+
+    def raw_on_tape(self, x):
+        """raw() for a filter that is being adapted: the folded filter stays on the autograd tape."""
+        scale, shift = self.norm.folded()
+        return F.conv2d(x, self.weight * scale, None, self.stride, self.padding), shift
 
     def forward(self, x):
         if self.norm is None:
@@ -125,6 +136,16 @@ class Bottleneck(nn.Module):
                 sc, bs = self.shortcut.raw(x)
                 return ops.bias_act_(y, b, sc, bs)
             return ops.bias_act_(y, b, x.contiguous())
+        if _fusable_on_tape(x):
+            # gradients flow: the same three in-place epilogues, each paired with a one-pass backward (ops.BiasActFn)
+            fused = ops.BiasActFn.apply
+            y, b = self.conv1.raw_on_tape(x)
+            y, b = self.conv2.raw_on_tape(fused(y, b, None, None))
+            y, b = self.conv3.raw_on_tape(fused(y, b, None, None))
+            if self.shortcut is not None:
+                sc, bs = self.shortcut.raw_on_tape(x)
+                return fused(y, b, sc, bs)
+            return fused(y, b, x.contiguous(), None)
         out = F.relu_(self.conv1(x))
         out = F.relu_(self.conv2(out))
         out = self.conv3(out)

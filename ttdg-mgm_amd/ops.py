@@ -563,7 +563,8 @@ def nms_collect(launched):
 
 
 def bias_act_(y, bias=None, residual=None, bias2=None, relu=True):
-    """In place on a contiguous fp32 NCHW tensor: y <- act(y + bias[c] (+ residual) (+ bias2[c])).  Forward-only."""
+    """In place on a contiguous fp32 NCHW tensor: y <- act((y + bias[c]) + (residual + bias2[c])).  No autograd: where
+    gradients flow use BiasActFn."""
     for t in (y, bias, residual, bias2):
         if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
             raise TypeError("bias_act_: contiguous float32 tensors only (got %s)" % t.dtype)
@@ -573,6 +574,30 @@ def bias_act_(y, bias=None, residual=None, bias2=None, relu=True):
     HW = y.numel() // max(1, N * C)
     call("ttdg_bias_act", ptr(y), ptr(bias), ptr(residual), ptr(bias2), N, C, HW, int(bool(relu)), stream())
     return y
+
+
+class BiasActFn(torch.autograd.Function):
+    """relu((y + bias[c]) + (residual + bias2[c])) IN PLACE on the convolution output y, with gradients: the fused epilogue of
+    the adapted res3 - res5 bottlenecks (FrozenBN shift, residual add, ReLU: one pass forward, one pass backward, instead of
+    torch's bias add_, add, clamp_min_ and threshold_backward kernels).  bias / bias2 are FrozenBN shifts (buffers, no gradient)."""
+
+    @staticmethod
+    def forward(ctx, y, bias, residual, bias2):
+        bias_act_(y, bias, residual, bias2, relu=True)
+        ctx.mark_dirty(y)
+        ctx.save_for_backward(y)
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gout):
+        (out,) = ctx.saved_tensors
+        gout = gout.contiguous()
+        if gout.dtype != torch.float32:
+            raise TypeError("BiasActFn: float32 gradients only")
+        gin = torch.empty_like(out)
+        call("ttdg_relu_bwd", ptr(gout), ptr(out), ptr(gin), C.c_size_t(out.numel()), stream())
+        return gin, None, (gin if ctx.has_res else None), None
 
 
 _SIZES_CACHE = {}
