@@ -230,27 +230,6 @@ __device__ __forceinline__ void sk_wave_project_narrow(const float* Vb, int n, f
 //   kTr = false (n <= 32): rows = nodes, the dummy row sits in row slot n with weight (32 - n) in the column sums; CB = 4
 //   kTr = true  (32 <= n <= 64): rows = universe slots, columns q = bj + 8 b (b < ceil(n / 8)), the (n - 32) identical dummy
 //                                rows are one extra, wavefront-replicated row; CB = ceil(n / 8)
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-  const int x = __float_as_int(v);
-  return __int_as_float(__builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false));   // every lane has a source: `old` is dead
-}
-__device__ __forceinline__ float lane_xor16(float v) {
-  const int x = __float_as_int(v);
-  const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
-  return __int_as_float((threadIdx.x & 16) ? r[0] : r[1]);
-}
-__device__ __forceinline__ float bj_sum(float v) { v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); return v; }
-__device__ __forceinline__ float bj_max(float v) {
-  v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v));
-  return v;
-}
-__device__ __forceinline__ float bi_sum(float v) { v += dpp_f<0x128>(v); v += lane_xor16(v); v += other_half(v); return v; }
-__device__ __forceinline__ float bi_max(float v) {
-  v = fmaxf(v, dpp_f<0x128>(v)); v = fmaxf(v, lane_xor16(v)); v = fmaxf(v, other_half(v));
-  return v;
-}
-
 template <bool kTr, int CB>
 __device__ __forceinline__ void sk_wave_project_blk(const float* Vb, int n, float scale, int iters, float* Ub) {
   const int lane = threadIdx.x & 63, bi = lane >> 3, bj = lane & 7;

@@ -189,6 +189,30 @@ __device__ __forceinline__ float other_half(float v) {
   return __int_as_float((threadIdx.x & 32) ? r[0] : r[1]);
 }
 
+// ---- butterflies of the block-layout Sinkhorn kernels (gagm.hip, sinkhorn.hip): lane = (bi = lane >> 3, bj = lane & 7);
+// sums / maxima over bj (three low lane bits: DPP quad_perm x 2, row_half_mirror) and over bi (three high bits: DPP row_ror:8,
+// v_permlane16_swap, v_permlane32_swap); every lane of the group ends up with the group's result
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  const int x = __float_as_int(v);
+  return __int_as_float(__builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false));   // every lane has a source: `old` is dead
+}
+__device__ __forceinline__ float lane_xor16(float v) {
+  const int x = __float_as_int(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  return __int_as_float((threadIdx.x & 16) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float bj_sum(float v) { v += dpp_f<0xB1>(v); v += dpp_f<0x4E>(v); v += dpp_f<0x141>(v); return v; }
+__device__ __forceinline__ float bj_max(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v)); v = fmaxf(v, dpp_f<0x4E>(v)); v = fmaxf(v, dpp_f<0x141>(v));
+  return v;
+}
+__device__ __forceinline__ float bi_sum(float v) { v += dpp_f<0x128>(v); v += lane_xor16(v); v += other_half(v); return v; }
+__device__ __forceinline__ float bi_max(float v) {
+  v = fmaxf(v, dpp_f<0x128>(v)); v = fmaxf(v, lane_xor16(v)); v = fmaxf(v, other_half(v));
+  return v;
+}
+
 // Exact fp64 minimum over the wavefront, hand-scheduled: per stage one `s_nop 1` (VALU-write -> DPP-read hazard),
 // two v_mov_b32_dpp (lo/hi words; rows excluded by row_mask keep their own value) and one v_min_f64.  hipcc's own
 // lowering of the same reduction spends six instructions per stage (two plain moves and a canonicalising v_max_f64

