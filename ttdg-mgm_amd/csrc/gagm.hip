@@ -455,8 +455,11 @@ __device__ __forceinline__ float block_sum2(float a, float b, float* red, float&
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // workspace layout (floats): [V0: M*32][U1: M*32][W^T: M*Mp][state: 4*32*(Mp+1)][history: GA_HIST*M bytes]
+// leading dimension of W^T / B^T: M rounded up to the 16-row MFMA tile (round 1's 32-row tiles needed 32: a 129-node
+// multi-graph then paid for 160 columns of W^T and fell out of LDS)
+__host__ __device__ inline int ga_mp(int M) { return (M + 15) & ~15; }
 __host__ __device__ inline size_t ga_ws_hist_off(int M) {
-  const int Mp = (M + 31) & ~31;
+  const int Mp = ga_mp(M);
   return (size_t)2 * M * NU + (size_t)M * Mp + (size_t)4 * NU * (Mp + 1);
 }
 
@@ -644,7 +647,7 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
   const int M = gr.off[gr.G], G = gr.G;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int MU = M * NU;
-  const int Mp = (M + 31) & ~31;
+  const int Mp = ga_mp(M);
   const int SB = NU * (Mp + 1);              // one state buffer: M x 32 row-major, or 32 x (Mp+1) for B^T
   int asz = 0, nmax = 0, nmin = 1 << 30;
   for (int g = 0; g < G; ++g) { const int n = gr.off[g + 1] - gr.off[g]; asz += n * n; nmax = max(nmax, n); nmin = min(nmin, n); }
@@ -670,9 +673,8 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
   const float* Ap = Apack;
   if (kWLds) { WT = lds; lds += M * Mp; }
   if (kALds) { Ap = lds; lds += (asz + 3) & ~3; }
-  float* S = lds;                // 1024
-  float* Spart = S + NU * NU;    // 4 x 1024 partial tiles of S
-  float* red = Spart + 4 * NU * NU;  // 64
+  float* Spart = lds;            // 2 x 1024: the K-split partial tiles of S (the V tiles add them)
+  float* red = Spart + 2 * NU * NU;  // 64
   float* wex = red + 64;         // GA_WAVES * (40 + cmaxp)
   const int wex_stride = 40 + cmaxp;
   unsigned char* lapb = (unsigned char*)(wex + GA_WAVES * wex_stride);   // LDS LAP scratch: CWMAX == 2 only
@@ -880,13 +882,12 @@ __global__ __launch_bounds__(GA_THREADS) void gagm_kernel(const float* __restric
 }
 
 static size_t ga_fixed_lds_bytes(int cmaxp, int GA_WAVES, int cwmax, int M) {
-  // static LDS (s_off, s_aoff) ~ 0.6 KB + S, 4 partial S tiles, reduction scratch, per-wave potentials, optional LDS-LAP
+  // static LDS (s_off, s_aoff, timers) ~ 0.6 KB + 2 partial S tiles, reduction scratch, per-wave potentials, optional LDS-LAP
   // scratch, node->graph bytes
   const size_t lap = cwmax == 2 ? GA_WAVES * ((lap_scratch_bytes(NU, cmaxp) + 15) & ~(size_t)15) : 0;
-  return (size_t)1024 + (size_t)(5 * NU * NU + 64 + GA_WAVES * (40 + cmaxp)) * sizeof(float) + lap + ((M + 15) & ~15) + 32 + GA_HIST * 8;
+  return (size_t)1024 + (size_t)(2 * NU * NU + 64 + GA_WAVES * (40 + cmaxp)) * sizeof(float) + lap + ((M + 15) & ~15) + 32 + GA_HIST * 8;
 }
 
-static inline int ga_mp(int M) { return (M + 31) & ~31; }
 
 // gagm_large.hip
 #define GAGM_LARGE_FROM_DEFAULT 320   // measured (tools/bench_gagm_scale.py): 140 vs 89 us per iteration at 451 nodes, 392 vs 95 at 892; 69 vs 69 at 221
