@@ -230,3 +230,21 @@ def test_measures_from_quadrant_counts_equal_the_elementwise_measures(golden):
             assert (math.isnan(got) and math.isnan(ref)) or abs(got - ref) <= 1e-10, (i, (d, e, s), want)
         if i < 6:
             assert abs(d - float(gold[f"c{i}_dice"])) <= 1e-9 and abs(e - float(gold[f"c{i}_ea"])) <= 1e-9 and abs(s - float(gold[f"c{i}_sm"])) <= 1e-6
+
+
+def test_sampler_box_tables_match_the_per_image_formulation():
+    """GModule.build_graph.padded_tables (one concatenation + one scatter) against the slice assignment per image it replaced,
+    for equal and ragged detection counts, float64 / int64 inputs included."""
+    from ttdg_mgm_amd.GModule.build_graph import padded_tables
+    g = torch.Generator().manual_seed(3)
+    for lens in ((2, 2, 2, 2), (3, 1, 2), (1,), (4, 2)):
+        bc = [(torch.rand(n, 4, generator=g, dtype=torch.float64) * 100, torch.randint(0, 3, (n,), generator=g)) for n in lens]
+        kmax = max(lens)
+        boxes, classes = padded_tables(bc, list(lens), kmax, torch.device("cpu"))
+        ref_b = torch.zeros(len(lens), kmax, 4)
+        ref_c = torch.zeros(len(lens), kmax, dtype=torch.int32)
+        for k, (b, c) in enumerate(bc):
+            ref_b[k, :len(b)] = b.to(torch.float32)
+            ref_c[k, :len(c)] = c.to(torch.int32)
+        assert boxes.dtype == torch.float32 and classes.dtype == torch.int32
+        assert torch.equal(boxes, ref_b) and torch.equal(classes, ref_c)
