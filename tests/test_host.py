@@ -248,3 +248,66 @@ def test_sampler_box_tables_match_the_per_image_formulation():
             ref_c[k, :len(c)] = c.to(torch.int32)
         assert boxes.dtype == torch.float32 and classes.dtype == torch.int32
         assert torch.equal(boxes, ref_b) and torch.equal(classes, ref_c)
+
+
+def _blk_projector_model(V, n, tau, iters=20):
+    """float32 numpy model of the ARITHMETIC of csrc/gagm.hip:sk_wave_project_blk (no lanes: the butterflies are plain sums):
+    potentials f / g / dummy as the state, one exponential per entry per sweep pair (the column sweep reuses the row sweep's
+    exponentials through the reciprocal of the row sums), previous potentials as stabilisers, the exact max-subtracted pair
+    first and whenever a sum leaves [2^-60, 1e6].  V: (n, 32) block; rows of the oriented problem are the universe slots when
+    n > 32."""
+    import numpy as np
+    f32 = np.float32
+    LOG2E = f32(1.4426950408889634)
+    tr = n > 32
+    L = (V.T if tr else V).astype(f32) * f32(LOG2E / f32(tau))                # (r, c), r <= c
+    r, c = L.shape
+    mult = c - r
+    D = f32(-100.0) * LOG2E
+    f, g, fd = np.zeros(r, f32), np.zeros(c, f32), f32(0)
+    lo_ok, hi_ok = f32(8.6736174e-19), f32(1.0e6)
+    with np.errstate(over="ignore", under="ignore", divide="ignore", invalid="ignore"):
+        for it in range(0, iters, 2):
+            exact = it == 0
+            if not exact:
+                e = np.exp2((L - f[:, None]) - g[None, :]).astype(f32)
+                s = e.sum(1, dtype=f32)
+                ed = np.exp2((D - fd) - g).astype(f32) if mult else None
+                sd = ed.sum(dtype=f32) if mult else f32(1)
+                cs = (e * (f32(1) / s)[:, None]).sum(0, dtype=f32) + (ed * (f32(mult) / sd) if mult else f32(0))
+                allv = np.concatenate([s, cs, [sd]])
+                if np.all(allv >= lo_ok) and np.all(allv <= hi_ok):
+                    f, g = f + np.log2(s).astype(f32), g + np.log2(cs).astype(f32)
+                    fd = fd + np.log2(sd).astype(f32) if mult else fd
+                else:
+                    exact = True
+            if exact:
+                t = L - g[None, :]
+                m = t.max(1)
+                f = (m + np.log2(np.exp2(t - m[:, None]).astype(f32).sum(1, dtype=f32))).astype(f32)
+                if mult:
+                    dm = (-g).max()
+                    fd = f32(D + dm + np.log2(np.exp2(-g - dm).astype(f32).sum(dtype=f32)))
+                t = L - f[:, None]
+                td = f32(D - fd) if mult else f32(-np.inf)
+                m = np.maximum(t.max(0), td)
+                acc = np.exp2(t - m[None, :]).astype(f32).sum(0, dtype=f32)
+                if mult:
+                    acc = acc + f32(mult) * np.exp2(td - m).astype(f32)
+                g = (m + np.log2(acc)).astype(f32)
+    U = np.exp2((L - f[:, None]) - g[None, :]).astype(f32)
+    return U.T if tr else U
+
+
+@pytest.mark.parametrize("n", [20, 31, 32, 38, 64])
+@pytest.mark.parametrize("tau", [0.1, 0.0125, 0.00625])
+def test_block_projector_arithmetic_is_the_log_sinkhorn(n, tau):
+    """The arithmetic of the solver's block-layout projector - reusing the row sweep's exponentials in the column sweep, the
+    dummy rows as one replicated row, stabilising with the previous potentials - restated in numpy float32 and compared with
+    the oracle's log-Sinkhorn (float64) on one graph block: the 1e-4 bar of the device tests holds for the algorithm itself."""
+    from oracle import gmodule as og
+    g = torch.Generator().manual_seed(100 + n)
+    V = torch.rand(n, 32, generator=g)
+    ref = og._project_sinkhorn(V.double(), [n], 32, tau, 20).numpy()
+    got = _blk_projector_model(V.numpy(), n, tau)
+    assert float(abs(got - ref).max()) <= 1e-4
