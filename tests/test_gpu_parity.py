@@ -1045,7 +1045,11 @@ def test_roi_align_multilevel_matches_per_level_pooler(dev):
     assert maxerr(ops.roi_align_multilevel([f.to(dev) for f in f5], rois.to(dev), [4, 8, 16, 32], 7),
                   cb.roi_align_multilevel(f5, rois, [4, 8, 16, 32], 7)) <= 1e-4
     big = torch.tensor([[0, -300.0, -200.0, 900.0, 800.0], [1, 0.0, 0.0, 256.0, 256.0], [1, 250.0, 250.0, 700.0, 262.0], [0, -50.0, 100.0, 20.0, 400.0],
-                        [1, 3.0, 3.0, 3.5, 3.5], [0, 255.0, 255.0, 256.0, 256.0]])
+                        [1, 3.0, 3.0, 3.5, 3.5], [0, 255.0, 255.0, 256.0, 256.0],
+                        # unclipped boxes whose x samples ALL fall outside the map while some y samples do not, and vice versa
+                        # (every bin is 0; the separable kernel once contracted an unwritten LDS tile here)
+                        [0, 300.0, 40.0, 340.0, 120.0], [1, -90.0, 20.0, -30.0, 200.0], [0, 30.0, 290.0, 150.0, 330.0],
+                        [1, 20.0, -80.0, 90.0, -20.0]])
     fd = [f.to(dev) for f in feats]
     tf = ops.to_nhwc(fd)
     assert all(torch.equal(t, f.permute(0, 2, 3, 1)) for t, f in zip(tf, fd))                     # the transposition itself

@@ -311,3 +311,64 @@ def test_block_projector_arithmetic_is_the_log_sinkhorn(n, tau):
     ref = og._project_sinkhorn(V.double(), [n], 32, tau, 20).numpy()
     got = _blk_projector_model(V.numpy(), n, tau)
     assert float(abs(got - ref).max()) <= 1e-4
+
+
+def test_reference_yaml_decodes_like_yacs(tmp_path):
+    """The reference yamls write tuples as Python literals (`TEST: ("REFUGE_train", ...)`), which yaml.safe_load returns as
+    a str: yacs decodes them, so must merge_from_file; command-line overrides go through the same architecture guard."""
+    cfg = get_cfg()
+    p = tmp_path / "t.yaml"
+    p.write_text('DATASETS:\n  TEST: ("A_train", "B_test")\nTEST:\n  BATCH: 4\nSOLVER:\n  BASE_LR: "0.01"\n')
+    cfg.merge_from_file(str(p))
+    assert cfg.DATASETS.TEST == ["A_train", "B_test"] and cfg.TEST.BATCH == 4 and cfg.SOLVER.BASE_LR == 0.01
+    with pytest.raises(ValueError):
+        cfg.merge_from_list(["MODEL.MASK_ON", "False"])
+
+
+def test_streaming_loader_is_bounded_and_releases_its_producer():
+    """(1) inference_on_dataset consumes a streaming loader lazily: never more than prefetch + 2 batches alive (queue +
+    the one being produced + the one being evaluated); (2) a consumer that stops early leaves no blocked producer thread."""
+    import gc
+    import threading
+    import weakref
+    from ttdg_mgm_amd.engine import trainer as tr
+    cfg = get_cfg()
+    cfg.TEST.BATCH = 2
+    cfg.INPUT.MIN_SIZE_TEST = 64
+    data.register_synthetic("bounded_ds", 24, size=64, id_offset=300)
+    stm = data.build_detection_test_loader(cfg, "bounded_ds", 0, 1, None, resident=False)
+    alive, peak = [], [0]
+    orig = stm._load_batch
+
+    def tracked(lo, hi, stream):
+        items, ev = orig(lo, hi, stream)
+        alive.append(weakref.ref(items[0]["image"]))
+        return items, ev
+    stm._load_batch = tracked
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, batch):
+            gc.collect()
+            peak[0] = max(peak[0], sum(r() is not None for r in alive))
+            return [None] * len(batch)
+
+    class Ev:
+        def reset(self): pass
+        def process(self, b, o): pass
+        def evaluate(self): return {}
+    tr.inference_on_dataset(Model(), stm, Ev())
+    assert len(alive) == 12 and peak[0] <= stm.prefetch + 2, peak
+    n0 = threading.active_count()
+    it = iter(stm)
+    next(it)
+    it.close()                                  # MIN_BATCH_NUM / an exception in the consumer
+    for _ in range(100):
+        if threading.active_count() <= n0:
+            break
+        import time
+        time.sleep(0.05)
+    assert threading.active_count() <= n0, "the producer thread is still blocked in q.put"

@@ -23,8 +23,12 @@ class CfgNode(dict):
         for k, v in d.items():
             if isinstance(v, dict) and isinstance(self.get(k), dict):
                 self[k].merge_from_dict(v)
+            elif isinstance(v, dict):
+                self[k] = _node(v)
             else:
-                self[k] = CfgNode(v) if isinstance(v, dict) else v
+                # yacs decodes string leaves as Python literals: the reference yamls write tuples that way
+                # (`TEST: ("REFUGE_train", ...)` reaches yaml.safe_load as a str)
+                self[k] = _decode(v) if isinstance(v, str) else v
 
     def merge_from_file(self, path):
         with open(path) as f:
@@ -41,6 +45,7 @@ class CfgNode(dict):
             for p in parts[:-1]:
                 node = node[p]
             node[parts[-1]] = _decode(v) if isinstance(v, str) else v
+        check_supported(self)
 
 
 def _decode(v):

@@ -591,6 +591,12 @@ __global__ __launch_bounds__(64 * RA_WAVES) void roi_align_sep_kernel(ttdg_fpn_t
   const int ylo = s_geo[0], hp = s_geo[1], xlo = s_geo[2], wp = s_geo[3];
   float* obase = out + ((size_t)r * C + (size_t)slice * CS) * P * P;
   const float* fbase = fp.feat[l] + ((size_t)b * C + (size_t)slice * CS) * H * W;
+  if (s_geo[4] && (hp == 0 || wp == 0)) {
+    // every sample of one axis lies outside the map (the other axis may still have taps): all samples are skipped and
+    // every bin is 0 - the T tile below would never be written
+    for (int e = tid; e < CS * P * P; e += 64 * RA_WAVES) obase[e] = 0.f;
+    return;
+  }
   if (!s_geo[4]) {
     // a ROI outside the table limits (more than 8 samples per bin, or a patch above 64 pixels): the direct formula
     const float inv = 1.f / (float)(gh * gw);

@@ -119,30 +119,55 @@ class TestLoader:
         q = queue.Queue(maxsize=self.prefetch)
         cuda = self.device is not None and torch.device(self.device).type == "cuda"
         stream = torch.cuda.Stream(device=self.device) if cuda else None
+        stop = threading.Event()
+
+        def put(x):
+            """Blocking put that gives up when the consumer has gone away (early `break`, exception, `limit`)."""
+            while not stop.is_set():
+                try:
+                    q.put(x, timeout=0.05)
+                    return True
+                except queue.Full:
+                    pass
+            return False
 
         def produce():
             try:
                 if cuda:
                     torch.cuda.set_device(self.device)
                 for lo in range(self.start, self.stop, self.batch):
-                    q.put(self._load_batch(lo, min(lo + self.batch, self.stop), stream))
-                q.put(None)
+                    if stop.is_set() or not put(self._load_batch(lo, min(lo + self.batch, self.stop), stream)):
+                        return
+                put(None)
             except BaseException as e:          # surfaced on the consumer's thread
-                q.put(e)
+                put(e)
 
         t = threading.Thread(target=produce, daemon=True)
         t.start()
-        while True:
-            got = q.get()
-            if got is None:
-                break
-            if isinstance(got, BaseException):
-                raise got
-            items, ev = got
-            if ev is not None:
-                torch.cuda.current_stream().wait_event(ev)       # the upload ran on the side stream
-            yield items
-        t.join()
+        try:
+            while True:
+                got = q.get()
+                if got is None:
+                    break
+                if isinstance(got, BaseException):
+                    raise got
+                items, ev = got
+                if ev is not None:
+                    cur = torch.cuda.current_stream()
+                    cur.wait_event(ev)                           # the upload ran on the side stream
+                    for it in items:                             # allocated on the side stream, consumed on this one: the
+                        it["image"].record_stream(cur)           # caching allocator must not recycle it under queued kernels
+                yield items
+                del items, got
+        finally:
+            # consumer finished or left early (GeneratorExit / exception): release the producer and whatever it queued
+            stop.set()
+            while True:
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    break
+            t.join(timeout=30)
 
 
 def build_detection_test_loader(cfg, dataset_name, rank=0, world=1, device=None, resident=True):

@@ -47,10 +47,18 @@ def run_eval_batches(model, batches, evaluator, streams=None, coalesce=None):
     are identical to the sequential loop up to the order the evaluator receives the batches in."""
     streams = EVAL_STREAMS if streams is None else streams
     coalesce = EVAL_COALESCE if coalesce is None else coalesce
-    batches = list(batches)
     dev_is_gpu = next(model.parameters()).is_cuda
     if not dev_is_gpu:
         coalesce = 1
+    if (streams <= 1 or not dev_is_gpu) and coalesce <= 1:
+        # the plain loop: the loader is consumed lazily, one batch alive at a time (a streaming loader stays bounded by its
+        # own prefetch depth; only the multi-stream / coalescing modes below need the shard as a list)
+        with torch.no_grad():
+            for batch in batches:
+                _eval_group(model, [batch], evaluator)
+                del batch
+        return
+    batches = list(batches)
     batches = [batches[i:i + max(1, coalesce)] for i in range(0, len(batches), max(1, coalesce))]     # groups of loader batches
     if streams <= 1 or not dev_is_gpu or len(batches) < 3:
         with torch.no_grad():

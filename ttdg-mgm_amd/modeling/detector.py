@@ -305,11 +305,13 @@ class StandardROIHeadsPseudoLab(nn.Module):
     def prewarm_mask_head(self, device, full):
         """Run the mask head once at every batch size `inference_dense` can pick, so that the vendor library's first-use
         solver search / kernel build of a new shape (~1 s each) happens here and not on some later batch."""
-        if getattr(self, "_warm", None) == (str(device), full):
-            return
+        warm = self.__dict__.setdefault("_warm", set())          # (device, batch size) pairs already run: a partial last
+        conv = next(m for m in self.mask_head.modules() if isinstance(m, torch.nn.Conv2d))     # batch adds its sizes only
+        res = self.mask_pooler.P
         for n in [k for k in self.MASK_BUCKETS if k < full] + [full]:
-            self.mask_head(torch.zeros(n, 256, 14, 14, device=device))
-        self._warm = (str(device), full)
+            if (str(device), n) not in warm:
+                self.mask_head(torch.zeros(n, conv.in_channels, res, res, device=device))
+                warm.add((str(device), n))
 
     @torch.no_grad()
     def inference_dense(self, features, boxes, scores, keep, image_sizes, out_size, mask_threshold=0.5, counts=None):
