@@ -133,13 +133,16 @@ def _project_sinkhorn(V, ms, n_univ, tau, sk_iter):
 
 # --------------------------------------------------------------------------- A6
 def gagm(A, W, U0, ms, n_univ=UNIV_SIZE, quad_weight=QUAD_WEIGHT, init_tau=GA_TAU0, min_tau=GA_MIN_TAU,
-         max_iter=GA_MGM_ITER, sk_iter=GA_SK_ITER, sk_gamma=GA_GAMMA, tol=GA_TOL, trace=None, max_stages=0):
+         max_iter=GA_MGM_ITER, sk_iter=GA_SK_ITER, sk_gamma=GA_GAMMA, tol=GA_TOL, trace=None, max_stages=0, perturb=None):
     """multi_graph_matching.py:300-389 with num_clusters==1 (cluster_M == 1, hung_iter True),
     entered from GA_GM.forward :223-244 (W detached :225).
 
     ``trace`` (optional dict) receives 'V0' (first-iteration V), 'iters' (per-stage
     iteration counts) and 'stages' (projector/tau per stage) for parity tests.  ``max_stages`` > 0 (test hook, not
-    in the reference) returns the state after that many stages of the schedule."""
+    in the reference) returns the state after that many stages of the schedule.  ``perturb`` (test hook, not in the
+    reference): callable ``U = perturb(U, stage, i)`` applied to every Sinkhorn-stage projection - rounding-sized noise
+    injected where a second implementation's projector would round differently (tests/golden/make_golden.py uses it to
+    refuse goldens that sit on a rounding edge)."""
     ms = [int(m) for m in ms]
     G = len(ms)
     W = W.detach()
@@ -166,8 +169,10 @@ def gagm(A, W, U0, ms, n_univ=UNIV_SIZE, quad_weight=QUAD_WEIGHT, init_tau=GA_TA
                 U = torch.cat(parts, dim=0)
             else:
                 U = _project_sinkhorn(V, ms, n_univ, tau, sk_iter)
+                if perturb is not None:
+                    U = perturb(U, nstages, i)
             if G == 2:
-                U[:ms[0], :] = torch.eye(ms[0], n_univ)
+                U[:ms[0], :] = torch.eye(ms[0], n_univ, dtype=U.dtype)
             if torch.norm(U - lastU) < tol or torch.norm(U - lastU2) == 0:
                 break
         if trace is not None:
@@ -194,13 +199,13 @@ def mgm3_unsup_forward(p, nodes, labels, U, n_univ=UNIV_SIZE, dropout_masks=None
     off = [0] + list(np.cumsum(ms))
     M = off[-1]
 
-    A = torch.zeros(M, M)
+    A = torch.zeros(M, M, dtype=nodes[0].dtype)          # float32 on the path; float64 when a test asks for the truth
     for g, x in enumerate(nodes):
         adj = mha_adjacency(p, x, dropout_mask=None if dropout_masks is None else dropout_masks[g])
         A[off[g]:off[g + 1], off[g]:off[g + 1]].add_(adj[:ms[g], :ms[g]])
     A.fill_diagonal_(0)
 
-    Wds = torch.zeros(M, M)
+    Wds = torch.zeros(M, M, dtype=nodes[0].dtype)
     for a in range(G):          # src
         for b in range(G):      # tgt
             if a < b:

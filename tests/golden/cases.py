@@ -67,18 +67,29 @@ MGM_CASES = (  # name, sizes, seed
 
 
 # "Planted" cases: a trained-like synthetic model.  Node features are noisy copies of universe rows
-# (x = 0.2 * U[id] + noise) and the affinity weights realise M_ij ~ c * ||x_i + x_j||_1 (+ small random jitter),
+# (x = alpha * U[id] + noise) and the affinity weights realise M_ij ~ c * ||x_i + x_j||_1 (+ small random jitter),
 # so that Wds is sharp and cycle-consistent and the graduated-assignment solver converges in every stage.
 # With random weights (MGM_CASES) the Sinkhorn stages collapse U to the uniform matrix and the Hungarian stage
 # is decided by fp32 rounding noise: the REFERENCE ITSELF returns different permutations with 1 vs 8 CPU threads
 # there (DESIGN.md "Solver parity"), so identical-permutation goldens are only meaningful on planted cases.
+#
+# Round 3: every planted case must pass tests/golden/admission.py (structured rounding-sized perturbations of the front
+# end and of every projection) before make_golden.py writes it.  Round 2's small cases (alpha 0.2, un-normalised
+# universe, sizes (18,25) / (22,22,22) / (22,30,28,25) at seeds 900-902) did not: five of the six collapsed onto the
+# uniform matrix in the Sinkhorn stages and were decided by one-ulp structure.  The cases below use the same planting as
+# the big ones (unit-scale universe: U0 = x U^T is O(1), the first projection is a soft one) and cover: the G = 2 identity
+# pin with n_0 < 32 and n_0 = 32, all graphs of one size (batched Sinkhorn path) below and at the universe size, unequal
+# sizes with 3 and 4 graphs, late stages of more than one iteration.
 PLANTED_CASES = (  # name, sizes, seed
-    ("p2", (18, 25), 900),
-    ("p3", (22, 22, 22), 900),
-    ("p3b", (22, 22, 22), 901),
-    ("p4", (22, 30, 28, 25), 900),
-    ("p4b", (22, 30, 28, 25), 901),
-    ("p4c", (22, 30, 28, 25), 902),
+    ("p2", (28, 31), 920),
+    ("p2b", (32, 27), 921),
+    ("p3", (30, 32, 31), 920),
+    ("p3u", (26, 30, 22), 920),
+    ("p3eq", (32, 32, 32), 921),
+    ("p4eq", (22, 22, 22, 22), 921),
+    ("p4", (22, 30, 28, 25), 920),
+    ("p4b", (22, 30, 28, 25), 930),
+    ("p4c", (22, 30, 28, 25), 927),
 )
 
 
@@ -138,11 +149,7 @@ def mgm_inputs(name):
         if n == name:
             nodes, labels = synth.node_sets(seed, sizes, scale=0.5)
             return synth.mgm3_params(seed + 50), nodes, labels, synth.universe(seed + 70), sizes
-    for n, sizes, seed in PLANTED_CASES:
-        if n == name:
-            nodes, labels, U = planted_nodes(seed, sizes)
-            return planted_params(seed + 50), nodes, labels, U, sizes
-    for n, sizes, seed in PLANTED_BIG_CASES:
+    for n, sizes, seed in PLANTED_CASES + PLANTED_BIG_CASES:
         if n == name:
             # unit-norm universe rows: U0 = x U^T is O(1), so the first projection is a soft one (with the O(50) scores of
             # the small cases the first Sinkhorn at tau 0.1 is already a hard assignment decided by fp32 rounding once

@@ -22,6 +22,7 @@ from oracle import ref_import  # noqa: E402
 from ttdg_mgm_amd import synth  # noqa: E402
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from cases import *  # noqa: E402,F401,F403
+import admission  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 torch.set_num_threads(1)  # fixed reduction order for the goldens
@@ -122,6 +123,25 @@ def gold_gagm(mgm):
     np.savez_compressed(os.path.join(OUT, "gagm.npz"), **out)
 
 
+def ref_solve(mgm, A, W, U0, sizes, perturb=None):
+    """The reference's own GA_GM (multi_graph_matching.py:223-244,300-389) on given solver inputs.  ``perturb`` multiplies
+    rounding-sized noise into every projection of the Sinkhorn stages by wrapping the reference's Sinkhorn.forward_log
+    (utils/sinkhorn.py:85-87) for the duration of the call."""
+    solver = mgm.GA_GM(mgm_iter=[200], cluster_iter=10, sk_iter=20, sk_tau0=[0.1], sk_gamma=0.5, cluster_beta=[1.0, 0.0],
+                       converge_tol=1.0e-3, min_tau=[1.0e-2], projector0=["sinkhorn", "sinkhorn"])
+    orig = mgm.Sinkhorn.forward_log
+    if perturb is not None:
+        def noisy(self, *a, **k):
+            out = orig(self, *a, **k)
+            return perturb(out) if self.batched_operation else out
+        mgm.Sinkhorn.forward_log = noisy
+    try:
+        Ub, _ = solver(A, W, U0.clone(), torch.tensor(list(sizes), dtype=torch.int), 32, 0.5, 1)
+    finally:
+        mgm.Sinkhorn.forward_log = orig
+    return Ub.detach()
+
+
 def planted_goldens(mgm, case_list, out):
     """Free-running reference runs whose permutation matrices are golden: asserted rounding-stable (1 thread, 8 threads,
     two 1e-7-relative input perturbations give the same U)."""
@@ -152,6 +172,11 @@ def planted_goldens(mgm, case_list, out):
         torch.set_num_threads(1)
         assert all(torch.equal(runs[0][0], r[0]) for r in runs[1:]), "reference not rounding-stable on " + name
         Ub, loss, m, xs = runs[0]
+        # admission (tests/golden/admission.py): the REFERENCE's GA_GM must return this same U under structured
+        # rounding-sized perturbations of its inputs and of every Sinkhorn-stage projection
+        ok, res = admission.check(params, nodes, labels, U, sizes, solve=lambda *a, **k: ref_solve(mgm, *a, **k), golden=Ub)
+        print("admission %-9s %s" % (name, "ok" if ok else "FAILED: " + ", ".join(k for k, v in res.items() if not v)), flush=True)
+        assert ok, "planted case %s sits on a rounding edge of the reference: %s" % (name, res)
         out[f"{name}_loss"] = npy(loss)
         out[f"{name}_U"] = npy(Ub)
         for gi, x in enumerate(xs):
@@ -302,6 +327,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "mgm3_big":
         gold_mgm3_big(mgm)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "mgm3":
+        gold_mgm3(mgm)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "sinkhorn_ref":
         gold_sinkhorn_ref()

@@ -145,6 +145,18 @@ def test_mgm3_planted_cases(golden, name):
         close(x.grad, gold[f"{name}_dnode{gi}"], 1e-5)
 
 
+@pytest.mark.parametrize("name", [c[0] for c in cases.PLANTED_CASES + cases.PLANTED_BIG_CASES])
+def test_planted_goldens_do_not_sit_on_a_rounding_edge(golden, name):
+    """VERDICT r2 item 1b.  The admission test make_golden.py applies with the reference's solver, repeated with the oracle
+    against the committed golden U: a float64 front end, reversed summation order, per-block +-2 ulp on Wds, the solve in
+    float64, and 1e-6 / 1e-5 relative noise in EVERY Sinkhorn-stage projection all return the golden permutation."""
+    import admission
+    gold = golden("mgm3_big" if name.startswith("pb_") else "mgm3")
+    params, nodes, labels, U, sizes = cases.mgm_inputs(name)
+    ok, res = admission.check(params, nodes, labels, U, sizes, golden=torch.from_numpy(gold[f"{name}_U"]))
+    assert ok, res
+
+
 # ----------------------------------------------------------------------------- N3: HiPPI / U_sup (SURVEY.md §8f)
 @pytest.mark.parametrize("name,sizes,seed,proj", cases.HIPPI_CASES)
 def test_hippi(golden, name, sizes, seed, proj):

@@ -306,7 +306,7 @@ def source_batches(cfg, n_images, size, device, name="synth_source", kind="fundu
 
 def train_source(model, batches, steps, lr=0.01, warmup=50, matching_weight=1.0, seed=0, log=None, train_all=False,
                  unsup_weight=20.0, rois_per_image=256, matching_lr=1e-3, probe=None, probe_every=0, profile=False, roi_grad=False,
-                 feat_reg=0.02, ttt_weight=1.0, ttt_from=0.5):
+                 feat_reg=0.02, ttt_weight=1.0, ttt_from=0.5, u0_weight=0.0, u0_temp=1.0):
     """Stage 1.  SGD (momentum 0.9, wd 1e-4, linear warm-up, cosine decay), gradient-norm clip 10.
     Matching terms on nodes sampled inside the GT boxes (rcnn.py:262-266): ``matching_weight`` x the universe loss of
     ``multi_matching_sup`` (:136-169) and ``unsup_weight`` x the permutation loss of ``multi_matching_unsup`` (:560-564),
@@ -315,6 +315,13 @@ def train_source(model, batches, steps, lr=0.01, warmup=50, matching_weight=1.0,
     that U0 = X U^T is O(10^2..10^3), the solver's first V (cubic in U0) O(10^9) and its first projection a hard assignment
     decided by fp32 rounding - in the reference as much as here.  The regulariser (and the unit-norm universe rows set in
     ``make``) keep the synthetic model where the solve is well conditioned.
+    ``u0_weight`` x cross-entropy(X U^T / u0_temp, universe label): the solver starts from U0 = X U^T
+    (multi_graph_matching.py:531-532).  The reference's universe loss only sees U through ``Net_U`` (:145-146), so nothing
+    in it makes X U^T itself informative; if it is not, the first projection is inconsistent across graphs, the iteration
+    collapses onto the uniform fixed point for every tau >= 0.0125 and the symmetry is only broken in the last Sinkhorn
+    stage - from rounding noise (measured on the round-2 checkpoint: float32 and float64 solves of the reference's own
+    algorithm end on different permutations on 7 of 8 batches).  With this term U0 points at the nodes' universe slots,
+    the solve enters the sharp fixed point in its first stage and is well defined.
     ``ttt_weight`` x the FREE-RUNNING adaptation loss itself (solver pseudo-labels, exactly what a TTA step minimises) from
     fraction ``ttt_from`` of the schedule on: the detector heads are fitted on features that already sit near a stationary
     point of the adaptation loss, so that later TTA steps (which move the backbone but not the heads) do
@@ -385,6 +392,11 @@ def train_source(model, batches, steps, lr=0.01, warmup=50, matching_weight=1.0,
                 loss = loss + unsup_weight * l_perm
             if feat_reg > 0:
                 loss = loss + feat_reg * torch.cat(nodes).square().mean()
+            if u0_weight > 0:
+                has = Ugt.sum(1) > 0                               # a graph of more than 32 nodes leaves some unassigned
+                logits = (torch.cat(nodes) @ model.multi_matching_sup.U.t())[has] / u0_temp
+                l_u0 = F.cross_entropy(logits, Ugt[has].argmax(1))
+                loss = loss + u0_weight * l_u0
             if ttt_weight > 0 and step >= ttt_from * steps:
                 loss = loss + ttt_weight * model.multi_matching_unsup(nodes, labels, model.multi_matching_sup.U)
         tt = tick("matching_fwd", tt)
@@ -456,7 +468,8 @@ def solver_regime(model, batches):
 
 
 def make(cfg, device, steps=600, tta_steps=16, n_images=64, size=512, lr=0.01, seed=0, log=print, train_all=False, matching_weight=1.0,
-         unsup_weight=20.0, matching_lr=1e-3, probe=None, probe_every=0, profile=False, roi_grad=False, kind="fundus"):
+         unsup_weight=20.0, matching_lr=1e-3, probe=None, probe_every=0, profile=False, roi_grad=False, kind="fundus",
+         u0_weight=0.0, u0_temp=1.0, feat_reg=0.02, ttt_weight=1.0, ttt_from=0.5):
     """Build, fit and return (model, report).  ``cfg`` is the test config (TEST.BATCH, INPUT sizes, NUM_CLASSES)."""
     from ttdg_mgm_amd.engine import BaselineTrainer
     from ttdg_mgm_amd.modeling import calibrate_frozen_bn
@@ -471,7 +484,7 @@ def make(cfg, device, steps=600, tta_steps=16, n_images=64, size=512, lr=0.01, s
         model.multi_matching_sup.U.div_(model.multi_matching_sup.U.norm(dim=1, keepdim=True))
     hist = train_source(model, batches, steps, lr=lr, seed=seed, log=log, train_all=train_all, matching_weight=matching_weight,
                         unsup_weight=unsup_weight, matching_lr=matching_lr, probe=probe, probe_every=probe_every, profile=profile,
-                        roi_grad=roi_grad)
+                        roi_grad=roi_grad, u0_weight=u0_weight, u0_temp=u0_temp, feat_reg=feat_reg, ttt_weight=ttt_weight, ttt_from=ttt_from)
     stats = warm_tta(model, cfg, batches, tta_steps, log=log) if tta_steps else []
     torch.cuda.synchronize()
     report = dict(stage1_steps=steps, stage2_tta_steps=tta_steps, source_images=n_images, seconds=time.perf_counter() - t0,
