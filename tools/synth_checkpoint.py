@@ -306,7 +306,7 @@ def source_batches(cfg, n_images, size, device, name="synth_source", kind="fundu
 
 def train_source(model, batches, steps, lr=0.01, warmup=50, matching_weight=1.0, seed=0, log=None, train_all=False,
                  unsup_weight=20.0, rois_per_image=256, matching_lr=1e-3, probe=None, probe_every=0, profile=False, roi_grad=False,
-                 feat_reg=0.02, ttt_weight=1.0, ttt_from=0.5, u0_weight=0.0, u0_temp=1.0):
+                 feat_reg=0.02, ttt_weight=1.0, ttt_from=0.5, u0_weight=0.0, u0_temp=0.0):
     """Stage 1.  SGD (momentum 0.9, wd 1e-4, linear warm-up, cosine decay), gradient-norm clip 10.
     Matching terms on nodes sampled inside the GT boxes (rcnn.py:262-266): ``matching_weight`` x the universe loss of
     ``multi_matching_sup`` (:136-169) and ``unsup_weight`` x the permutation loss of ``multi_matching_unsup`` (:560-564),
@@ -321,7 +321,11 @@ def train_source(model, batches, steps, lr=0.01, warmup=50, matching_weight=1.0,
     collapses onto the uniform fixed point for every tau >= 0.0125 and the symmetry is only broken in the last Sinkhorn
     stage - from rounding noise (measured on the round-2 checkpoint: float32 and float64 solves of the reference's own
     algorithm end on different permutations on 7 of 8 batches).  With this term U0 points at the nodes' universe slots,
-    the solve enters the sharp fixed point in its first stage and is well defined.
+    the solve enters the sharp fixed point in its first stage and is well defined.  ``u0_temp`` = 0 (default when the
+    term is on) uses the squared error against the assignment: the first V is CUBIC in U0
+    (2q A U0 U0^T A U0 + W U0), and A U0 is close to the graph mean of U0, so with |U0| >> 1 the cubic term swamps W U0 and
+    makes every row prefer the same columns (measured with the cross-entropy form, |U0| up to 18: quad 1.9e3 vs linear 12,
+    first projection diffuse, same collapse); with U0 in [0, 1] the linear term leads.
     ``ttt_weight`` x the FREE-RUNNING adaptation loss itself (solver pseudo-labels, exactly what a TTA step minimises) from
     fraction ``ttt_from`` of the schedule on: the detector heads are fitted on features that already sit near a stationary
     point of the adaptation loss, so that later TTA steps (which move the backbone but not the heads) do
@@ -393,9 +397,12 @@ def train_source(model, batches, steps, lr=0.01, warmup=50, matching_weight=1.0,
             if feat_reg > 0:
                 loss = loss + feat_reg * torch.cat(nodes).square().mean()
             if u0_weight > 0:
-                has = Ugt.sum(1) > 0                               # a graph of more than 32 nodes leaves some unassigned
-                logits = (torch.cat(nodes) @ model.multi_matching_sup.U.t())[has] / u0_temp
-                l_u0 = F.cross_entropy(logits, Ugt[has].argmax(1))
+                u0 = torch.cat(nodes) @ model.multi_matching_sup.U.t()
+                if u0_temp > 0:                                    # cross-entropy variant (diagnostics: it grows |U0|, see below)
+                    has = Ugt.sum(1) > 0                           # a graph of more than 32 nodes leaves some unassigned
+                    l_u0 = F.cross_entropy(u0[has] / u0_temp, Ugt[has].argmax(1))
+                else:                                              # U0 ~ the assignment itself: entries in [0, 1]
+                    l_u0 = (u0 - Ugt).square().sum(1).mean()
                 loss = loss + u0_weight * l_u0
             if ttt_weight > 0 and step >= ttt_from * steps:
                 loss = loss + ttt_weight * model.multi_matching_unsup(nodes, labels, model.multi_matching_sup.U)
@@ -469,7 +476,7 @@ def solver_regime(model, batches):
 
 def make(cfg, device, steps=600, tta_steps=16, n_images=64, size=512, lr=0.01, seed=0, log=print, train_all=False, matching_weight=1.0,
          unsup_weight=20.0, matching_lr=1e-3, probe=None, probe_every=0, profile=False, roi_grad=False, kind="fundus",
-         u0_weight=0.0, u0_temp=1.0, feat_reg=0.02, ttt_weight=1.0, ttt_from=0.5):
+         u0_weight=0.0, u0_temp=0.0, feat_reg=0.02, ttt_weight=1.0, ttt_from=0.5):
     """Build, fit and return (model, report).  ``cfg`` is the test config (TEST.BATCH, INPUT sizes, NUM_CLASSES)."""
     from ttdg_mgm_amd.engine import BaselineTrainer
     from ttdg_mgm_amd.modeling import calibrate_frozen_bn

@@ -16,8 +16,10 @@ N*B with the backbone work sharded:
      holds every pair's contribution) and back-propagates through its own backbone activations;
   5. gradient all-reduce (SUM over ranks for backbone / FPN tensors, whose gradients are partial sums over images; the
      matching module's own gradients are already complete on every rank and are averaged, which only washes out
-     run-to-run noise) in a few large buckets launched back to back: ring all-reduce on xGMI is per-link bound
-     (~153 GB/s/link), ~105 MB of fp32 gradients = ~1.5 ms, and bucket k+1 is packed while bucket k is on the wire;
+     run-to-run noise) in a few large buckets: ring all-reduce on xGMI is per-link bound (~153 GB/s/link), ~105 MB of fp32
+     gradients = ~1.5 ms.  ``OverlappedGradReducer`` launches every bucket from autograd hooks as soon as its gradients
+     exist (reverse layer order), so the all-reduce hides behind the rest of the backbone backward; ``allreduce_grads`` is
+     the post-hoc form (same buckets, bit-identical results);
   6. the fused SGD step, identical on every rank, so the replicas never drift.
 
 Ranks whose shard has run out of batches keep taking part with zero graphs (``inputs=None``).
@@ -110,48 +112,144 @@ def gather_graphs(nodes, labels, device, dim=256):
     return list(torch.split(rows, flat)), list(torch.split(lab_all, flat))
 
 
+def plan_buckets(params, bucket_bytes=BUCKET_BYTES):
+    """Static bucket layout shared by the post-hoc and the overlapped reduction: parameters in REVERSE registration order
+    (the order their gradients become ready in a backward pass: heads / FPN first, res3 last), cut every ``bucket_bytes``.
+    -> list of lists of indices into ``params``."""
+    buckets, cur, nbytes = [], [], 0
+    for i in reversed(range(len(params))):
+        cur.append(i)
+        nbytes += params[i].numel() * params[i].element_size()
+        if nbytes >= bucket_bytes:
+            buckets.append(cur)
+            cur, nbytes = [], 0
+    if cur:
+        buckets.append(cur)
+    return buckets
+
+
+def _have_mask(params):
+    """Which parameters have a gradient on ANY rank (one small MAX all-reduce)."""
+    have = torch.tensor([p.grad is not None for p in params], dtype=torch.int32, device=params[0].device)
+    _all_reduce_async(have, dist.ReduceOp.MAX).wait()
+    return [bool(h) for h in have.tolist()]
+
+
+def _launch_bucket(params, idx, have, nsum, world):
+    """Flatten the gradients of one bucket (zeros where this rank has none, replicated ones pre-divided) and start its
+    SUM all-reduce.  -> (work handle, flat buffer, [(param, numel)]) or None for a bucket without any live gradient."""
+    items = []
+    for i in idx:
+        if not have[i]:
+            continue
+        p = params[i]
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        items.append((p, g / world if i >= nsum else g))
+    if not items:
+        return None
+    flat = torch.cat([g.reshape(-1) for _, g in items])
+    return _all_reduce_async(flat, dist.ReduceOp.SUM), flat, [(p, g.numel()) for p, g in items]
+
+
+def _finish(work):
+    for w, flat, items in work:
+        w.wait()
+        off = 0
+        for p, n in items:
+            p.grad = flat[off:off + n].view_as(p)
+            off += n
+
+
 def allreduce_grads(summed, replicated, bucket_bytes=BUCKET_BYTES):
-    """``summed``: parameters whose gradients are partial sums over this rank's images (SUM over ranks);
-    ``replicated``: parameters whose gradients are already complete on every rank (averaged).  A parameter that has no
-    gradient on ANY rank keeps ``grad is None`` (the optimizer skips it, as the single-GPU step does); one that has a
-    gradient somewhere gets zeros elsewhere."""
+    """Post-hoc reduction (after ``loss.backward()`` has returned).  ``summed``: parameters whose gradients are partial sums
+    over this rank's images (SUM over ranks); ``replicated``: parameters whose gradients are already complete on every rank
+    (averaged).  A parameter that has no gradient on ANY rank keeps ``grad is None`` (the optimizer skips it, as the
+    single-GPU step does); one that has a gradient somewhere gets zeros elsewhere."""
     params = list(summed) + list(replicated)
     if not params:
         return
     world = dist.get_world_size()
-    dev = params[0].device
-    have = torch.tensor([p.grad is not None for p in params], dtype=torch.int32, device=dev)
-    _all_reduce_async(have, dist.ReduceOp.MAX).wait()
-    have = have.tolist()
-    nsum = len(summed)
-    work, bucket, nbytes = [], [], 0
+    have = _have_mask(params)
+    work = [w for w in (_launch_bucket(params, idx, have, len(summed), world) for idx in plan_buckets(params, bucket_bytes)) if w is not None]
+    _finish(work)
 
-    def flush():
-        nonlocal bucket, nbytes
-        if not bucket:
+
+class OverlappedGradReducer:
+    """The same reduction, launched DURING the backward pass ("bucketed to overlap with bwd").
+
+    Every parameter carries a post-accumulate-grad hook; a bucket of ``plan_buckets`` is flattened and its all-reduce
+    started as soon as all of its live parameters have their gradient AND every earlier bucket has been launched (the
+    collectives must be issued in the same order on every rank), so the ring all-reduce of the FPN / res5 gradients is on
+    the wire while res4 and res3 are still being differentiated.  ``finalize()`` (after backward) launches what is left -
+    on a rank that held no graph no hook ever fires and everything is launched there, with zeros - waits, and installs the
+    reduced gradients.
+
+    Which parameters are live (have a gradient on some rank) is learned from the first step, which runs post-hoc through
+    ``allreduce_grads``; it is a property of the architecture (res3-5, FPN, the affinity module).  A
+    gradient that shows up on a parameter outside that set raises.  Same buckets, same buffers, same collectives as the
+    post-hoc path: the results are bit-identical (tests/test_distributed.py)."""
+
+    def __init__(self, summed, replicated, bucket_bytes=BUCKET_BYTES):
+        self.params = list(summed) + list(replicated)
+        self.nsum = len(summed)
+        self.bucket_bytes = bucket_bytes
+        self.buckets = plan_buckets(self.params, bucket_bytes)
+        self.have = None                         # learned on the first step
+        self.overlapped_launches = 0             # buckets launched from inside backward (diagnostics / tests)
+        self._armed = False
+        self._bucket_of = {}
+        for b, idx in enumerate(self.buckets):
+            for i in idx:
+                self._bucket_of[i] = b
+        self._handles = [p.register_post_accumulate_grad_hook(self._hook(i)) for i, p in enumerate(self.params)]
+
+    def _hook(self, i):
+        def fn(_p):
+            if not self._armed:
+                return
+            if not self.have[i]:
+                raise RuntimeError("parameter %d received a gradient but had none on any rank in the first step" % i)
+            b = self._bucket_of[i]
+            self._pending[b] -= 1
+            self._advance(from_hook=True)
+        return fn
+
+    def _advance(self, from_hook):
+        while self._next < len(self.buckets) and self._pending[self._next] <= 0:
+            w = _launch_bucket(self.params, self.buckets[self._next], self.have, self.nsum, self._world)
+            if w is not None:
+                self._work.append(w)
+                self.overlapped_launches += int(from_hook)
+            self._next += 1
+
+    def prepare(self):
+        """Call before ``loss.backward()`` (gradients must be None / zeroed: the hooks see accumulated gradients)."""
+        self._world = dist.get_world_size()
+        self._work, self._next = [], 0
+        if self.have is None:
+            self._armed = False
             return
-        flat = torch.cat([g.reshape(-1) for _, g in bucket])
-        work.append((_all_reduce_async(flat, dist.ReduceOp.SUM), flat, bucket))
-        bucket, nbytes = [], 0
+        self._pending = [sum(1 for i in idx if self.have[i]) for idx in self.buckets]
+        self._armed = True
+        self._advance(from_hook=False)           # leading buckets without any live parameter
 
-    for i, p in enumerate(params):
-        if not have[i]:
-            continue
-        g = p.grad if p.grad is not None else torch.zeros_like(p)
-        if i >= nsum:
-            g = g / world
-        bucket.append((p, g))
-        nbytes += g.numel() * g.element_size()
-        if nbytes >= bucket_bytes:
-            flush()
-    flush()
-    for w, flat, items in work:
-        w.wait()
-        off = 0
-        for p, g in items:
-            n = g.numel()
-            p.grad = flat[off:off + n].view_as(p)
-            off += n
+    def finalize(self):
+        """Call after ``loss.backward()``."""
+        if self.have is None:                    # first step: learn the live set, reduce post-hoc
+            self.have = _have_mask(self.params)
+            work = [w for w in (_launch_bucket(self.params, idx, self.have, self.nsum, self._world) for idx in self.buckets) if w is not None]
+            _finish(work)
+            return
+        self._armed = False
+        for b in range(self._next, len(self.buckets)):       # not ready by hooks (this rank had no graph / no gradient)
+            self._pending[b] = 0
+        self._advance(from_hook=False)
+        _finish(self._work)
+        self._work = []
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
 
 
 def split_params(model):

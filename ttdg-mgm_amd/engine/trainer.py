@@ -143,10 +143,16 @@ class BaselineTrainer:
         if loss is None:
             return None
         optimizer.zero_grad(set_to_none=True)
-        loss.backward()
         if getattr(model, "sync_universe", False):
             from . import sync_universe
-            sync_universe.allreduce_grads(*sync_universe.split_params(model))
+            red = model.__dict__.get("_grad_reducer")
+            if red is None:          # buckets launched from autograd hooks: the all-reduce overlaps the backbone backward
+                red = model.__dict__["_grad_reducer"] = sync_universe.OverlappedGradReducer(*sync_universe.split_params(model))
+            red.prepare()
+            loss.backward()
+            red.finalize()
+        else:
+            loss.backward()
         optimizer.step()
         return loss
 
