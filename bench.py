@@ -60,6 +60,10 @@ def parse(argv=None):
     ap.add_argument("--cpu-reps", type=int, default=3, help="timed CPU repetitions after 1 warm-up (median reported)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(os.cpu_count(), 64)")
     ap.add_argument("--cpu-1thread", action="store_true", help="also time ONE repetition with 1 thread (minutes)")
+    ap.add_argument("--cpu-allcores", action="store_true",
+                    help="also time ONE repetition with os.cpu_count() threads, under a 10-minute limit (recorded once per round in profiles/)")
+    ap.add_argument("--strong-images", type=int, default=512,
+                    help="with --gpus N > 1 and no --images: size of the fixed stream of the additional strong-scaling pass (0 = skip it)")
     ap.add_argument("--eval-streams", type=int, default=1, help="concurrent eval batches (HIP streams) in the Dice pass; 1 = sequential")
     ap.add_argument("--no-overlap-detector", action="store_true", help="A/B: keep the teacher-forced RPN + box head on the main stream")
     ap.add_argument("--eval-coalesce", type=int, default=1, help="loader batches merged into one inference call in the Dice pass; 1 = none")
@@ -123,11 +127,25 @@ def trained_checkpoint(cfg, args, device, rank, world):
     path = rep = None
     if rank == 0:
         path, rep = sc.get_or_make(cfg, device, log=lambda m: print("[ckpt] " + m, file=sys.stderr, flush=True), **kw)
+    if rank == 0:
+        rep = dict(rep or {}, content_sha16=checkpoint_hash(path))
     if world > 1:
         box = [path, rep]
         dist.broadcast_object_list(box, src=0)
         path, rep = box
     return path, rep
+
+
+def checkpoint_hash(path):
+    """sha256 over the tensors of the state dict (names + raw bytes): the fit is not bit-reproducible across boxes (vendor
+    convolutions), so every bench line names the weights it was measured on."""
+    import hashlib
+    sd = torch.load(path, map_location="cpu", weights_only=True)["model"]
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(sd[k].contiguous().numpy().tobytes())
+    return h.hexdigest()[:16]
 
 
 def build_model(cfg, args, device, weights, calib_batch, world):
@@ -298,6 +316,17 @@ def cpu_model_string():
     return "unknown"
 
 
+def allcores_note():
+    """Why `cores` is min(os.cpu_count(), 64): the recorded all-cores measurement of this round (profiles/r03_bench_cpu_allcores.json,
+    `bench.py --cpu-allcores`), when present."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_bench_cpu_allcores.json")) as f:
+            a = json.load(f)["cpu_baseline"]["all_cores"]
+        return "all %d host threads, recorded once this round: %s images/s (%s)" % (a["cores"], a["value"], a["protocol"])
+    except (OSError, ValueError, KeyError):
+        return "torch's CPU kernels stop scaling beyond 64 intra-op threads on these tensor sizes; all-cores figure not recorded"
+
+
 def cpu_baseline(args, weights, teacher_forced):
     """SURVEY.md §8d protocol: 1 warm-up + median of --cpu-reps repetitions of (one TTA step + eval pass on 4 images), each
     from the same checkpoint; the warm-up repetition's Dice is the CPU side of `dice_parity`.  Runs in a CHILD process with
@@ -319,10 +348,21 @@ def cpu_baseline(args, weights, teacher_forced):
     med = statistics.median(r["times"])
     out = {"value": args.batch / med, "unit": "adapted images/s", "cores": cores, "host_cores": os.cpu_count(), "cpu_model": cpu_model_string(),
            "kind": "port", "protocol": "1 warm-up + median of %d" % len(r["times"]), "seconds_median": med, "seconds_all": r["times"],
+           "cores_note": allcores_note(),
            "seconds_warmup": r["warmup_times"],
            "sample": "1 TTA step + eval pass on %d synthetic %dx%d images per repetition, torch-CPU model + oracle GModule, %d threads, %s weights, %s detections"
                      % (args.batch, args.size, args.size, cores, "trained-regime checkpoint" if weights else "random-init",
                         "teacher-forced" if teacher_forced else "free-running")}
+    if args.cpu_allcores and (os.cpu_count() or 1) != cores:
+        n_all = os.cpu_count()
+        speca = dict(spec, reps=1, warmup=0, threads=n_all)
+        enva = dict(env, OMP_NUM_THREADS=str(n_all), MKL_NUM_THREADS=str(n_all))
+        try:
+            pa = subprocess.run([sys.executable, "-c", code, json.dumps(speca)], capture_output=True, text=True, timeout=600, env=enva, cwd=ROOT)
+            ra = json.loads([l for l in pa.stdout.splitlines() if l.startswith("CPUJSON")][-1][7:])
+            out["all_cores"] = {"cores": n_all, "value": args.batch / ra["times"][0], "seconds": ra["times"][0], "protocol": "one cold repetition"}
+        except subprocess.TimeoutExpired:
+            out["all_cores"] = {"cores": n_all, "value": None, "seconds": None, "protocol": "one cold repetition: did not finish within 600 s"}
     if args.cpu_1thread:
         spec1 = dict(spec, reps=1, warmup=0, threads=1)
         env1 = dict(env, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
@@ -348,6 +388,41 @@ def gpu_dice_parity_leg(cfg, model, init_state, batch, dicts, name, teacher_forc
     res = ev.evaluate()
     res["kept_masks"] = len(ev.dice_scores)
     return res
+
+
+def parity_block():
+    """The parity statement a number of this line is quoted under: the gates in force in tests/ (-m gpu, through the C ABI) and
+    what the last recorded run of those tests actually asserted (profiles/r03_parity_ledger.json, r03_trained_census.json,
+    r03_trajectory.json - copied from gpurun_out/ after the round's final GPU test run).  Recorded figures, not live ones; the
+    live parity leg of this run is `dice_parity`."""
+    def rec(name):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)
+        except (OSError, ValueError):
+            return None
+    census, ledger, traj = rec("r03_trained_census.json"), rec("r03_parity_ledger.json"), rec("r03_trajectory.json")
+    out = {
+        "gates": {
+            "Wds / first V / loss / d loss / d nodes / parameter gradients vs oracle and reference goldens": "1e-4 abs (fp32)",
+            "log-domain Sinkhorn vs the reference tree's own log-Sinkhorn": "1e-4 + 40 ulp(max|s/tau|)  [above the flat 1e-4: 1.8e-4 measured at tau = 0.00625]",
+            "iterated maps (solver step, HiPPI, backward of 20 sweeps)": "max(1e-4, 2 x what the fp32 oracle loses against its own float64 statement)",
+            "planted goldens (15 cases, admitted only if the reference's answer survives structured rounding-sized perturbations)":
+                "identical permutation matrices and Sinkhorn-stage iteration counts; Hungarian-stage count +-1",
+            "trained-regime free-running solve": "identical U U^T where the reference's six-run census agrees, objective and loss inside the reference's own spread where it does not",
+            "continual TTA (8 steps, momentum carried)": "device-vs-host parameter distance <= 4 x (fp32 host vs float64 host at step 0) x (k + 1); Dice within 1e-3 relative",
+            "Dice / E / S vs the reference's numpy functions": "1e-9 / 1e-9 / 1e-6",
+        },
+    }
+    if census:
+        out["trained_regime_census"] = {k: census[k] for k in ("steps", "strong", "weak", "device_equals_oracle32", "mean_iterations") if k in census}
+    if ledger:
+        out["statement_ledger"] = ledger
+    if traj:
+        out["continual_tta"] = {"steps": traj.get("steps"), "float64_step0": traj.get("float64_step0"), "dice_device": traj.get("dice_device"),
+                                "dice_host": traj.get("dice_host"),
+                                "max_rel_param_distance": max((g["rel"] for r in traj.get("records", []) for g in r["groups"].values()), default=None)}
+    return out
 
 
 _T0 = time.perf_counter()
@@ -460,6 +535,31 @@ def gpu_main(args, rank, world, local):
     main = timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, world, device, tf)
     note("headline pass done: %.1f images/s" % (world * K * B / main["elapsed"]))
 
+    strong = None
+    if world > 1 and not args.images and args.strong_images and not args.sync_universe:
+        # the driver's `--gpus N --steps K` form is weak scaling (per-rank work fixed); north_star asks for STRONG scaling, so
+        # the same launch also times a FIXED stream sharded over the N ranks, and rank 0 alone on the whole stream (the N = 1
+        # reference of the efficiency, measured in this very process group while the other ranks wait)
+        from ttdg_mgm_amd.engine import BaselineTrainer
+        T = max(1, args.strong_images // (world * B)) * world * B
+        sb, sd = staged_batches(cfg, "synthfundus_strong", T, args, device, rank, world, cfg_id=args.stream_id + 30, id_offset=3 * 10 ** 6)
+        rs = timed_pass(cfg, model, init_state, batches[:W] + sb, local_dicts + sd, name, T // (world * B), W, args, world, device, tf)
+        solo = None
+        if rank == 0:
+            ab_, ad_ = staged_batches(cfg, "synthfundus_strong", T, args, device, 0, 1, cfg_id=args.stream_id + 30, id_offset=3 * 10 ** 6)
+            solo = timed_pass(cfg, model, init_state, batches[:W] + ab_, local_dicts + ad_, name, T // B, W, args, 1, device, tf)
+            del ab_, ad_
+        BaselineTrainer.rank, BaselineTrainer.world = rank, world
+        dist.barrier()
+        if rank == 0:
+            strong = {"images": T, "value": T / rs["elapsed"], "unit": "images/s", "n1_value_same_stream": T / solo["elapsed"],
+                      "efficiency_vs_n1": (T / rs["elapsed"]) / (world * T / solo["elapsed"]), "steps_per_rank": T // (world * B),
+                      "ranks": dist.get_world_size(), "backend": dist.get_backend(), "dice": rs["dice"], "kept_masks": rs["kept_masks"],
+                      "note": "fixed %d-image stream sharded over the ranks (continual TTA per shard, then the Dice pass + RCCL score all-gather); "
+                              "n1 = rank 0 alone on the whole stream, same process, other ranks idle" % T}
+        note("strong-scaling pass done")
+        del sb, sd
+
     ab = {}
     parity = None
     if world == 1 and not args.no_ab:
@@ -526,8 +626,11 @@ def gpu_main(args, rank, world, local):
         out["roofline"] = roofs[0]
         out["roofline"]["traffic_note"] = "HBM bytes per launch from the committed PMC passes of this command (profiles/), null when not collected"
         out["roofline_other_kernels"] = roofs[1:]
+    if strong is not None:
+        out["strong"] = strong
     if ab:
         out["ab"] = ab
+    out["parity"] = parity_block()
     if world == 1 and not args.no_cpu_baseline:
         try:
             note("CPU baseline (1 warm-up + %d repetitions)" % args.cpu_reps)

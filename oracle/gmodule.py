@@ -189,9 +189,10 @@ def gagm(A, W, U0, ms, n_univ=UNIV_SIZE, quad_weight=QUAD_WEIGHT, init_tau=GA_TA
 
 
 # --------------------------------------------------------------------------- A8
-def mgm3_unsup_forward(p, nodes, labels, U, n_univ=UNIV_SIZE, dropout_masks=None, trace=None):
+def mgm3_unsup_forward(p, nodes, labels, U, n_univ=UNIV_SIZE, dropout_masks=None, trace=None, forced_U=None):
     """multi_graph_matching.py:487-569 (+ collect_intra_class_matching_wrapper :594-633).
-    Returns the scalar loss, or None when fewer than two graphs (:489-490)."""
+    Returns the scalar loss, or None when fewer than two graphs (:489-490).  ``forced_U`` (test hook, not in the
+    reference) replaces the solver's output: teacher-forced comparisons of two implementations on the same pseudo-labels."""
     if nodes is None or len(nodes) == 1:
         return None
     ms = [len(l) for l in labels]
@@ -220,7 +221,7 @@ def mgm3_unsup_forward(p, nodes, labels, U, n_univ=UNIV_SIZE, dropout_masks=None
                 Wds[off[b]:off[b + 1], off[a]:off[a + 1]] += Wab_ds.t()
 
     U0 = torch.cat([x @ U.t() for x in nodes], dim=0).detach()
-    Ub = gagm(A, Wds, U0, ms, n_univ, trace=trace)
+    Ub = gagm(A, Wds, U0, ms, n_univ, trace=trace) if forced_U is None else forced_U.to(Wds.dtype)
     Ul = [Ub[off[g]:off[g + 1]] for g in range(G)]
     if trace is not None:
         trace.update(A=A.detach().clone(), Wds=Wds.detach().clone(), U0=U0.clone(), Ub=Ub.clone())

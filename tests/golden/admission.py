@@ -81,3 +81,60 @@ def check(params, nodes, labels, U, sizes, solve=oracle_solve, golden=None):
     for t, eps in enumerate((1e-6, 1e-6, 1e-6, 1e-6, 1e-5, 1e-5)):
         res["iternoise%d_%g" % (t, eps)] = bool(torch.equal(solve(A, W, U0, sizes, perturb=noise_hook(eps, 100 + t)), Ub))
     return all(res.values()), res
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Census of a free-running solve on inputs that were NOT planted (the trained-regime checkpoint of the bench): is the
+# reference algorithm's own answer well defined here, and if not, how far do its answers spread?
+def unpack_adjacency(apack, sizes):
+    M = sum(sizes)
+    A = torch.zeros(M, M, dtype=apack.dtype)
+    o = p = 0
+    for n in sizes:
+        A[o:o + n, o:o + n] = apack[p:p + n * n].reshape(n, n)
+        o += n
+        p += n * n
+    return A
+
+
+def perm_loss_of(W, Ub, sizes):
+    """The matching loss as a function of (Wds, U_b): multi_graph_matching.py:560-564 over collect_intra_class_matching_wrapper
+    :594-633 (orientation rule rows <= cols, x_gt = U_i U_j^T)."""
+    import itertools
+    off = [0] + list(np.cumsum(sizes))
+    tot, n = 0.0, 0
+    for i, j in itertools.combinations(range(len(sizes)), 2):
+        if sizes[j] >= sizes[i]:
+            s = W[off[i]:off[i + 1], off[j]:off[j + 1]]
+        else:
+            s = W[off[j]:off[j + 1], off[i]:off[i + 1]].t()
+        x = Ub[off[i]:off[i + 1]] @ Ub[off[j]:off[j + 1]].t()
+        tot += float(og.permutation_loss(s.unsqueeze(0), x.unsqueeze(0)))
+        n += 1
+    return tot / n
+
+
+def census(A, W, U0, sizes, nperturb=4):
+    """The oracle's solve in float32, in float64 and under ``nperturb`` 1e-7-relative perturbations of (W, U0).
+    -> dict(stable, U32, iters32, objectives, losses): ``stable`` = all of them end on the same U U^T (then the answer is a
+    property of the inputs and another implementation must reproduce it); otherwise ``objectives`` (<W, U U^T>) and
+    ``losses`` hold the reference algorithm's own spread."""
+    from ttdg_mgm_amd import synth
+    sizes = list(sizes)
+    t32 = {}
+    runs = [og.gagm(A, W, U0, sizes, trace=t32), og.gagm(A.double(), W.double(), U0.double(), sizes).float()]
+    for k in range(nperturb):
+        g = synth.gen(9100 + k)
+        runs.append(og.gagm(A, W * (1 + 1e-7 * synth.normal(g, tuple(W.shape))), U0 * (1 + 1e-7 * synth.normal(g, tuple(U0.shape))), sizes))
+    X0 = runs[0] @ runs[0].t()
+    stable = all(bool(torch.equal(U @ U.t(), X0)) for U in runs[1:])
+    return dict(stable=stable, U32=runs[0], iters32=t32["iters"], objectives=[float((W * (U @ U.t())).sum()) for U in runs],
+                losses=[perm_loss_of(W, U, sizes) for U in runs])
+
+
+def within_spread(value, samples, rel=1e-4):
+    """value in [min - range, max + range] of the reference's own answers (+ a relative 1e-4)."""
+    lo, hi = min(samples), max(samples)
+    r = hi - lo
+    slack = rel * max(abs(lo), abs(hi), 1e-12)
+    return lo - r - slack <= value <= hi + r + slack

@@ -87,7 +87,7 @@ def main():
             nstable += ok
             same_dev += dev_same
             its.append(tr["info"].cpu().tolist()[:6])
-            dump.append(dict(apack=tr["apack"].cpu(), Wds=W, U0=U0, sizes=sizes, info=tr["info"].cpu().tolist(), Ub=Ud, stable=ok, dev_same=dev_same,
+            dump.append(dict(X=tr["X"].cpu(), apack=tr["apack"].cpu(), Wds=W, U0=U0, sizes=sizes, info=tr["info"].cpu().tolist(), Ub=Ud, stable=ok, dev_same=dev_same,
                              it32=i32, it64=i64, rows=rows, loss=float(loss)))
         m.keep_trace = False
         m.last = None
@@ -97,6 +97,7 @@ def main():
         print(json.dumps(dict(variant=name, kw=kw, steps=len(dump), stable=nstable, device_equals_oracle=same_dev, iters_mean=sum(tot) / max(1, len(tot)),
                               iters_first4=its[:4], dice=res, kept=len(ev.dice_scores), fit_s=round(rep["seconds"], 1),
                               stage1_last=rep["stage1_last"])), flush=True)
+        torch.save({"U": model.multi_matching_sup.U.detach().cpu(), "params": {k: v.detach().cpu() for k, v in m.state_dict().items()}}, os.path.join(ROOT, "gpurun_out", "sweep_%s_model.pt" % name))
         torch.save(dump, os.path.join(ROOT, "gpurun_out", "sweep_%s.pt" % name))
 
 

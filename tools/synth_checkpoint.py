@@ -434,6 +434,43 @@ def train_source(model, batches, steps, lr=0.01, warmup=50, matching_weight=1.0,
     return hist
 
 
+@torch.no_grad()
+def fit_universe_readout(model, batches, device, lam, log=None):
+    """Stage 1b: the universe embedding as the ridge-regression readout of the universe labels from the (fixed) node features
+    of the whole source stream:  U = argmin ||X U^T - U_gt||_F^2 + lam * n * ||U||_F^2.
+    The TTA solver starts from U0 = X U^T (multi_graph_matching.py:531-532).  In the reference ``U`` is only trained through
+    ``Net_U`` (:145-146), nothing makes X U^T itself informative, and the detector never sees U - so this changes nothing but
+    the solver's starting point.  With an uninformative U0 the iteration falls onto the uniform fixed point for every
+    tau >= 0.0125 (its gain there is s / (32 tau) < 1) and breaks the symmetry only in the last Sinkhorn stage, chaotically
+    (DESIGN.md §4); with U0 ~ the assignment itself (entries in [0, 1], so that the cubic term of the first V stays below the
+    linear one) it enters the sharp fixed point in the first stage."""
+    from ttdg_mgm_amd.modeling.structures import Boxes, Instances
+    was = model.training
+    model.train()
+    ulab, XtX, XtY, n = None, None, None, 0
+    for k, items in enumerate(batches):
+        gts = _ground_truth(items, device)
+        images = model.preprocess_image(items)
+        features = model.backbone(images.tensor)
+        feats = [features[f] for f in ("p2", "p3", "p4", "p5", "p6")]
+        if ulab is None:
+            ulab = UniverseLabels(model.graph_generator, [tuple(f.shape[-2:]) for f in feats], device)
+            ulab.fit([_ground_truth(b, device) for b in batches])
+        inst = [Instances(sz, gt_boxes=Boxes(g["boxes"]), gt_classes=g["classes"]) for g, sz in zip(gts, images.image_sizes)]
+        nodes, _ = model.graph_generator(feats, inst)
+        Ugt, sizes = ulab.assign(k, gts)
+        X = torch.cat(nodes).double()
+        XtX = X.t() @ X if XtX is None else XtX + X.t() @ X
+        XtY = X.t() @ Ugt.double() if XtY is None else XtY + X.t() @ Ugt.double()
+        n += X.shape[0]
+    d = XtX.shape[0]
+    Ut = torch.linalg.solve(XtX + lam * n * torch.eye(d, dtype=torch.float64, device=XtX.device), XtY)        # (256, 32)
+    model.multi_matching_sup.U.copy_(Ut.t().float())
+    if log is not None:
+        log("stage1b universe readout: %d nodes, lam %g, |U| rows %.3f .. %.3f" % (n, lam, float(Ut.norm(dim=0).min()), float(Ut.norm(dim=0).max())))
+    model.train(was)
+
+
 def warm_tta(model, cfg, batches, steps, log=None):
     """Stage 2: the reference's own adaptation loop on the source stream (free-running detections)."""
     from ttdg_mgm_amd.engine import BaselineTrainer
@@ -476,7 +513,7 @@ def solver_regime(model, batches):
 
 def make(cfg, device, steps=600, tta_steps=16, n_images=64, size=512, lr=0.01, seed=0, log=print, train_all=False, matching_weight=1.0,
          unsup_weight=20.0, matching_lr=1e-3, probe=None, probe_every=0, profile=False, roi_grad=False, kind="fundus",
-         u0_weight=0.0, u0_temp=0.0, feat_reg=0.02, ttt_weight=1.0, ttt_from=0.5):
+         u0_weight=0.0, u0_temp=0.0, feat_reg=0.02, ttt_weight=1.0, ttt_from=0.5, u0_ridge=0.0):
     """Build, fit and return (model, report).  ``cfg`` is the test config (TEST.BATCH, INPUT sizes, NUM_CLASSES)."""
     from ttdg_mgm_amd.engine import BaselineTrainer
     from ttdg_mgm_amd.modeling import calibrate_frozen_bn
@@ -492,6 +529,8 @@ def make(cfg, device, steps=600, tta_steps=16, n_images=64, size=512, lr=0.01, s
     hist = train_source(model, batches, steps, lr=lr, seed=seed, log=log, train_all=train_all, matching_weight=matching_weight,
                         unsup_weight=unsup_weight, matching_lr=matching_lr, probe=probe, probe_every=probe_every, profile=profile,
                         roi_grad=roi_grad, u0_weight=u0_weight, u0_temp=u0_temp, feat_reg=feat_reg, ttt_weight=ttt_weight, ttt_from=ttt_from)
+    if u0_ridge > 0:
+        fit_universe_readout(model, batches, device, u0_ridge, log=log)
     stats = warm_tta(model, cfg, batches, tta_steps, log=log) if tta_steps else []
     torch.cuda.synchronize()
     report = dict(stage1_steps=steps, stage2_tta_steps=tta_steps, source_images=n_images, seconds=time.perf_counter() - t0,

@@ -225,6 +225,7 @@ class MGM3_unsup(nn.Module):
         self.check_range = False       # True: sync and raise like losses.py:437-442 when Wds leaves [0,1]
         self.keep_trace = False        # True: keep the intermediates of the last forward in ``self.last``
         self.last = None
+        self.forced_U = None           # test hook: pseudo-labels (M, univ) for the forwards made through the model's TTT branch
 
     def forward(self, nodes, labels, U, trace=None, forced_U=None):
         """nodes: list of (n_g, dim) tensors, labels: list of (n_g,) -> scalar loss, or None when there are
@@ -244,6 +245,8 @@ class MGM3_unsup(nn.Module):
                 return None
         if trace is None and self.keep_trace:
             trace = {}
+        if forced_U is None:
+            forced_U = self.forced_U
         X = torch.cat(list(nodes), dim=0).float().contiguous()
         aff, att = self.node_affinity, self.intra_domain_graph
         self.dropout_seed += 1
