@@ -62,6 +62,21 @@ int ttdg_gemm_f32_splitk(const float* A, int64_t sam, int64_t sak, const float* 
                          float* C, int64_t scm, int64_t scn, const float* bias, int M, int N, int K,
                          float alpha, float beta, int kslices, void* ws, ttdg_stream_t stream);
 
+/* Grouped form: up to TTDG_GEMM_GROUP_MAX independent products in ONE launch (32 x 32 output tiles, the four wavefronts of
+ * a workgroup split K).  `descs` is a HOST array; every product is
+ *     C[m,n] = alpha * (sum_{k<K} A(m,k) B(n,k) + sum_{k<K2} A2(m,k) B2(n,k)) + bias[n] + beta * C[m,n]
+ * (A2 / B2 / K2 = 0: no second segment).  Replaces the per-product launches behind nn.Linear forward / backward of
+ * utils/affinity.py:46-47,55, utils/attentions.py:72-74 and multi_graph_matching.py:531 on the matching path. */
+#define TTDG_GEMM_GROUP_MAX 8
+typedef struct {
+  const float *A, *B, *bias, *A2, *B2;
+  float* C;
+  int64_t sam, sak, sbn, sbk, scm, scn, sam2, sak2, sbn2, sbk2;
+  int M, N, K, K2;
+  float alpha, beta;
+} ttdg_gemm_desc_t;
+int ttdg_gemm_f32_grouped(const ttdg_gemm_desc_t* descs, int n, ttdg_stream_t stream);
+
 /* column sums: out[n] = sum_m X[m*ld + n]  (bias gradients) */
 int ttdg_colsum_f32(const float* X, int64_t ld, float* out, int M, int N, ttdg_stream_t stream);
 
@@ -95,6 +110,21 @@ int ttdg_sinkhorn_pairs_fwd(const float* part, int ksplit, const float* b2, ttdg
  * multi_graph_matching.py:615-631) -> dM (M x M, written for g(i) > g(j)). */
 int ttdg_sinkhorn_pairs_bwd(const float* part, int ksplit, const float* b2, const float* pot, const float* dWds,
                             ttdg_graphs_t gr, float tau, int iters, float* dM, ttdg_stream_t stream);
+
+/* ---- A4 + A5 fused: the whole pair stage of MGM3_unsup.forward in ONE launch (multi_graph_matching.py:504-525:
+ *      _forward_aff -> Affinity.forward utils/affinity.py:44-57, then self.sinkhorn(..., dummy_row=True)
+ *      utils/sinkhorn.py:85-87, then the symmetric fill) for graphs of at most 64 nodes each.
+ * One workgroup per ordered pair a >= b: affinity block over the whole hidden dimension H, oriented rows <= cols, dummy
+ * rows, `iters` sweeps in registers, exp.  Wds (M x M) is fully written; aff (M x M, may be NULL) receives the affinity
+ * WITHOUT b2 for g(i) >= g(j) (= one plane of ttdg_affinity_pairwise_fwd with ksplit 1: what the backward reads);
+ * pot as ttdg_sinkhorn_pairs_fwd ((npairs, iters, cmax+1) floats, NULL when no backward follows).
+ * Returns TTDG_EINVAL when a graph has more than 64 nodes (use the two-launch form). */
+int ttdg_pair_stage_fwd(const float* P, const float* Q, const float* w2, const float* b2, int H, ttdg_graphs_t gr, float tau,
+                        int iters, float* aff, float* Wds, float* pot, ttdg_stream_t stream);
+/* bwd of the Sinkhorn half (same contract as ttdg_sinkhorn_pairs_bwd with part = aff, ksplit = 1; graphs <= 64 nodes):
+ * dWds (blocks a < b are read) -> dM (written for g(i) > g(j)), to be followed by ttdg_affinity_pairwise_bwd. */
+int ttdg_pair_stage_bwd(const float* aff, const float* b2, const float* pot, const float* dWds, ttdg_graphs_t gr, float tau,
+                        int iters, float* dM, ttdg_stream_t stream);
 
 /* stand-alone batched Sinkhorn (the operator behind GModule.utils.sinkhorn.Sinkhorn.forward):
  * s is (b, r, c) with strides (sb, sr, sc); n1/n2 optional per-matrix valid sizes (device int32);

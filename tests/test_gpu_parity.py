@@ -87,6 +87,55 @@ def test_gemm_all_layouts(dev, M, N, K):
     assert maxerr(C3, (0.5 * ref.t() + 2.0).float()) <= tol * 4
 
 
+def test_gemm_grouped_all_layouts_and_two_segments(dev):
+    """csrc/gemm_grouped.hip: up to eight products in one launch (32 x 32 tiles, K split over the wavefronts), every operand
+    layout (NT / TN / NN, transposed C, column offsets), bias / alpha / beta, a second K segment, empty and ragged shapes - each
+    against the float64 product, and bit-for-bit against itself when launched alone (tile / group independent)."""
+    from ttdg_mgm_amd import ops
+    g = synth.gen(4711)
+    shapes = [(1, 1, 1), (7, 5, 3), (120, 256, 256), (131, 257, 70), (33, 32, 130), (512, 256, 119), (120, 32, 256), (64, 64, 64)]
+    descs, checks, keep = [], [], []
+    for i, (M, N, K) in enumerate(shapes):
+        A, B, bias = synth.normal(g, (M, K)).to(dev), synth.normal(g, (N, K)).to(dev), synth.normal(g, (N,)).to(dev)
+        ref = A.double() @ B.double().t()
+        tol = (2e-6 * K ** 0.5 * 4 + 1e-6) * 4
+        if i % 4 == 0:        # NT, bias
+            C = torch.empty(M, N, device=dev)
+            descs.append(ops.gdesc(A, K, 1, B, K, 1, C, N, 1, M, N, K, bias=bias))
+            checks.append((C, (ref + bias.double()), tol))
+        elif i % 4 == 1:      # TN (both operands m-contiguous), alpha / beta
+            At, Bt = A.t().contiguous(), B.t().contiguous()
+            C = torch.full((M, N), 2.0, device=dev)
+            descs.append(ops.gdesc(At, 1, M, Bt, 1, N, C, N, 1, M, N, K, alpha=0.5, beta=1.0))
+            checks.append((C, 0.5 * ref + 2.0, tol))
+            keep += [At, Bt]
+        elif i % 4 == 2:      # transposed C, B read at a column offset of a wider matrix
+            Bw = torch.cat((synth.normal(g, (N, 9)).to(dev), B), 1).contiguous()
+            C = torch.empty(N, M, device=dev)
+            descs.append(ops.gdesc(A, K, 1, Bw, K + 9, 1, C, 1, M, M, N, K, b_off=9))
+            checks.append((C, ref.t(), tol))
+            keep.append(Bw)
+        else:                 # two K segments: A B^T + A2 B2^T, second one NN
+            K2 = 37
+            A2, B2 = synth.normal(g, (M, K2)).to(dev), synth.normal(g, (K2, N)).to(dev)
+            C = torch.empty(M, N, device=dev)
+            descs.append(ops.gdesc(A, K, 1, B, K, 1, C, N, 1, M, N, K, second=(A2, K2, 1, B2, 1, N, K2)))
+            checks.append((C, ref + A2.double() @ B2.double(), tol * 2))
+            keep += [A2, B2]
+        keep += [A, B, bias]
+    ops.gemm_grouped(descs)
+    for (C, ref, tol), shp in zip(checks, shapes):
+        assert maxerr(C, ref.float()) <= tol, shp
+    # launched alone: same bits (the tile's arithmetic does not depend on the group)
+    M, N, K = shapes[2]
+    A, B = synth.normal(g, (M, K)).to(dev), synth.normal(g, (N, K)).to(dev)
+    Ca, Cb = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev)
+    ops.gemm_grouped([ops.gdesc(A, K, 1, B, K, 1, Ca, N, 1, M, N, K)])
+    ops.gemm_grouped([ops.gdesc(B, K, 1, A, K, 1, torch.empty(N, M, device=dev), M, 1, N, M, K), ops.gdesc(A, K, 1, B, K, 1, Cb, N, 1, M, N, K)])
+    assert torch.equal(Ca, Cb)
+    ops.gemm_grouped([ops.gdesc(A, K, 1, B, K, 1, Ca, N, 1, 0, N, K)])          # an empty product is skipped
+
+
 def test_linear_autograd(dev):
     from ttdg_mgm_amd import ops
     g = synth.gen(77)
@@ -311,6 +360,69 @@ def test_pair_sinkhorn_forward_backward(dev, sizes, ks):
         for b in range(a):
             low[off[a]:off[a + 1], off[b]:off[b + 1]] = 1
     derived_gate("pair sinkhorn bwd %s" % (sizes,), dM.cpu() * low, Mr.grad * low, M64.grad * low)
+
+
+@pytest.mark.parametrize("sizes", [(9, 14), (22, 22, 22), (22, 35, 28, 40), (5, 3), (64, 64), (1, 1), (64, 1, 33), (40,),
+                                   (30, 27, 33, 25, 38, 21)])
+def test_fused_pair_stage_forward_backward(dev, sizes):
+    """csrc/pair_stage.hip (round 3): affinity + pair Sinkhorn in ONE launch, block resident on the CU.  From P / Q rows to
+    Wds against the oracle's formulation (M_ij = sum_k w2_k relu(P_ik + Q_jk) + b2, then multi_graph_matching.py:504-525),
+    the affinity plane it leaves for the backward, the backward against autograd through the oracle (derived gate: float64
+    statement of the same computation), and both halves against the round-2 two-launch kernels on the same inputs."""
+    from oracle import gmodule as og
+    from ttdg_mgm_amd import ops
+    G, M, H = len(sizes), sum(sizes), 512
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    g = synth.gen(sum(sizes) * 17 + G)
+    P, Q = synth.normal(g, (M, H), 0.3), synth.normal(g, (M, H), 0.3)
+    w2, b2 = synth.normal(g, (H,), 0.05), torch.tensor([0.03])
+    Rw = synth.normal(g, (M, M), 1.0)
+    mask, low = torch.zeros(M, M), torch.zeros(M, M)
+    for a in range(G):
+        for b in range(a + 1, G):
+            mask[off[a]:off[a + 1], off[b]:off[b + 1]] = 1
+            low[off[b]:off[b + 1], off[a]:off[a + 1]] = 1
+
+    def host(dt):
+        Pd, Qd, wd = P.to(dt), Q.to(dt), w2.to(dt)
+        Mr = (torch.relu(Pd[:, None, :] + Qd[None, :, :]) * wd).sum(-1).detach().requires_grad_()        # without b2
+        W = torch.zeros(M, M, dtype=dt)
+        for a in range(G):
+            for b in range(a + 1):
+                blk = Mr[off[a]:off[a + 1], off[b]:off[b + 1]] + b2.to(dt)
+                ds = og.sinkhorn_pair(blk) if sizes[b] >= sizes[a] else og.sinkhorn_pair(blk.t()).t()
+                W[off[a]:off[a + 1], off[b]:off[b + 1]] += ds
+                if a != b:
+                    W[off[b]:off[b + 1], off[a]:off[a + 1]] += ds.t()
+        (W * (Rw * mask).to(dt)).sum().backward()
+        return Mr, W
+    M32, W32 = host(torch.float32)
+    M64, W64 = host(torch.float64)
+    gr = ops.graphs(sizes)
+    Pd, Qd, wd, bd = P.to(dev), Q.to(dev), w2.to(dev), b2.to(dev)
+    aff, Wd, pot = ops.pair_stage_fwd(Pd, Qd, wd, bd, gr, list(sizes), 0.05, 20)
+    tri = torch.zeros(M, M)
+    for a in range(G):
+        for b in range(a + 1):
+            tri[off[a]:off[a + 1], off[b]:off[b + 1]] = 1
+    scale = max(1.0, float(M64.detach().abs().max()))
+    assert maxerr(aff[0].cpu() * tri, M64.detach().float() * tri) <= 1e-5 * scale
+    assert maxerr(Wd, W64.float()) <= TOL
+    print("fused pair stage %s: |Wds - fp64| %.2e (fp32 oracle %.2e)" % (sizes, maxerr(Wd, W64.float()), maxerr(W32, W64.float())))
+    if G > 1:
+        dM = ops.pair_stage_bwd(aff, bd, pot, (Rw * mask).to(dev), gr, 0.05, 20)
+        derived_gate("fused pair stage bwd %s" % (sizes,), dM.cpu() * low, M32.grad * low, M64.grad * low)
+    # against the two-launch form on the same inputs (different summation order: ~1e-6)
+    part = ops.affinity_pairwise_fwd(Pd, Qd, wd, gr, 2)
+    W2, pot2 = ops.sinkhorn_pairs_fwd(part, bd, gr, list(sizes), 0.05, 20)
+    assert maxerr(W2, Wd) <= 2e-5
+    assert maxerr(part.sum(0).cpu() * tri, aff[0].cpu() * tri) <= 1e-5 * scale
+    if G > 1:
+        dM2 = ops.sinkhorn_pairs_bwd(aff, bd, pot, (Rw * mask).to(dev), gr, 0.05, 20)        # the old backward reads the new plane + log
+        assert maxerr(dM2.cpu() * low, dM.cpu() * low) <= 1e-4 * max(1.0, float((M64.grad * low).abs().max()))
+    with pytest.raises(RuntimeError):
+        big = (70, 20)
+        ops.pair_stage_fwd(torch.zeros(90, H, device=dev), torch.zeros(90, H, device=dev), wd, bd, ops.graphs(big), list(big), 0.05, 20)
 
 
 # ------------------------------------------------------------------------------------------- A7

@@ -1,0 +1,60 @@
+"""A/B of the vendor-kernel side of a TTA step: ResNet-50-FPN forward + backward at the bench's shape
+(4 x 3 x 800 x 800, fp32, stem + res2 frozen) with (a) the product's NCHW path + fused epilogues, (b) NCHW with plain torch
+element-wise ops, (c) channels_last tensors end to end (plain ops), and the eval-mode forward of each.  MIOpen's find mode is
+selected from outside (MIOPEN_FIND_MODE=...).  usage: ab_backbone.py [reps]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def main():
+    from ttdg_mgm_amd.config import get_cfg
+    from ttdg_mgm_amd.modeling import backbone as bb
+    from ttdg_mgm_amd.modeling import build_model
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    dev = torch.device("cuda:0")
+    cfg = get_cfg()
+    cfg.MODEL.DEVICE = "cuda:0"
+    torch.manual_seed(0)
+    model = build_model(cfg)
+    net = model.backbone
+    x = torch.randn(4, 3, 800, 800, device=dev)
+    print("MIOPEN_FIND_MODE =", os.environ.get("MIOPEN_FIND_MODE"), " MIOPEN_FIND_ENFORCE =", os.environ.get("MIOPEN_FIND_ENFORCE"))
+
+    def run(label, fused, cl):
+        bb.FUSED_EPILOGUE = fused
+        n = net.to(memory_format=torch.channels_last) if cl else net.to(memory_format=torch.contiguous_format)
+        xi = x.contiguous(memory_format=torch.channels_last) if cl else x
+        for mode in ("train", "eval"):
+            n.train(mode == "train")
+
+            def step():
+                if mode == "train":
+                    out = n(xi)
+                    loss = sum(v.float().square().mean() for v in out.values())
+                    for p in n.parameters():
+                        p.grad = None
+                    loss.backward()
+                else:
+                    with torch.no_grad():
+                        n(xi)
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                step()
+            torch.cuda.synchronize()
+            print("%-34s %-5s %8.2f ms" % (label, mode, (time.perf_counter() - t0) / reps * 1e3), flush=True)
+
+    run("NCHW + fused epilogues (product)", True, False)
+    run("NCHW, plain torch epilogues", False, False)
+    run("channels_last, plain epilogues", False, True)
+
+
+if __name__ == "__main__":
+    main()

@@ -43,6 +43,15 @@ class SgdTensor(C.Structure):
                 ("first", C.c_int32)]
 
 
+class GemmDesc(C.Structure):
+    """ttdg_gemm_desc_t: one product of a grouped launch (strides in elements)."""
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("bias", C.c_void_p), ("A2", C.c_void_p), ("B2", C.c_void_p), ("C", C.c_void_p),
+                ("sam", C.c_int64), ("sak", C.c_int64), ("sbn", C.c_int64), ("sbk", C.c_int64), ("scm", C.c_int64), ("scn", C.c_int64),
+                ("sam2", C.c_int64), ("sak2", C.c_int64), ("sbn2", C.c_int64), ("sbk2", C.c_int64),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("K2", C.c_int32), ("alpha", C.c_float), ("beta", C.c_float)]
+
+
+GEMM_GROUP_MAX = 8
 _P, _I, _L, _F, _S = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_void_p
 
 # name -> (restype, argtypes); one entry per symbol declared in include/ttdg_mgm.h
@@ -52,12 +61,15 @@ SIGNATURES = {
     "ttdg_gemm_f32": (C.c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _F, _F, _S]),
     "ttdg_gemm_splitk_workspace_bytes": (C.c_size_t, [_I, _I, _I]),
     "ttdg_gemm_f32_splitk": (C.c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _F, _F, _I, _P, _S]),
+    "ttdg_gemm_f32_grouped": (C.c_int, [C.POINTER(GemmDesc), _I, _S]),
     "ttdg_colsum_f32": (C.c_int, [_P, _L, _P, _I, _I, _S]),
     "ttdg_affinity_pairwise_fwd": (C.c_int, [_P, _P, _P, _I, Graphs, _I, _P, _S]),
     "ttdg_affinity_bwd_workspace_bytes": (C.c_size_t, [_I, _I]),
     "ttdg_affinity_pairwise_bwd": (C.c_int, [_P, _P, _P, _P, _I, Graphs, _P, _P, _P, _P, _P, _S]),
     "ttdg_sinkhorn_pairs_fwd": (C.c_int, [_P, _I, _P, Graphs, _F, _I, _P, _P, _S]),
     "ttdg_sinkhorn_pairs_bwd": (C.c_int, [_P, _I, _P, _P, _P, Graphs, _F, _I, _P, _S]),
+    "ttdg_pair_stage_fwd": (C.c_int, [_P, _P, _P, _P, _I, Graphs, _F, _I, _P, _P, _P, _S]),
+    "ttdg_pair_stage_bwd": (C.c_int, [_P, _P, _P, _P, Graphs, _F, _I, _P, _S]),
     "ttdg_sinkhorn_batched_fwd": (C.c_int, [_P, _L, _L, _L, _I, _I, _I, _P, _P, _I, _F, _I, _P, _P, _S]),
     "ttdg_sinkhorn_batched_bwd": (C.c_int, [_P, _L, _L, _L, _I, _I, _I, _P, _P, _I, _F, _I, _P, _P, _P, _S]),
     "ttdg_mha_adjacency": (C.c_int, [_P, _P, _I, Graphs, _F, _F, C.c_uint64, _I, _P, _S]),

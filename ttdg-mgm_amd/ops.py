@@ -5,6 +5,8 @@ PyTorch only provides device memory, the current stream and the autograd tape.
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from . import _lib
@@ -50,6 +52,32 @@ def gemm(A, sam, sak, B, sbn, sbk, Cout, scm, scn, M, N, K, bias=None, alpha=1.0
     call("ttdg_gemm_f32", ptr(A) + 4 * a_off, sam, sak, ptr(B) + 4 * b_off, sbn, sbk, ptr(Cout) + 4 * c_off, scm, scn,
          ptr(bias), M, N, K, float(alpha), float(beta), stream())
     return Cout
+
+
+def gdesc(A, sam, sak, B, sbn, sbk, Cout, scm, scn, M, N, K, bias=None, alpha=1.0, beta=0.0, a_off=0, b_off=0, c_off=0, second=None):
+    """One product of a grouped launch (same argument meaning as ``gemm``); ``second`` = (A2, sam2, sak2, B2, sbn2, sbk2, K2
+    [, a2_off, b2_off]) adds a second K segment into the same accumulators."""
+    d = _lib.GemmDesc()
+    d.A, d.B, d.C, d.bias = ptr(A) + 4 * a_off, ptr(B) + 4 * b_off, ptr(Cout) + 4 * c_off, ptr(bias)
+    d.sam, d.sak, d.sbn, d.sbk, d.scm, d.scn = sam, sak, sbn, sbk, scm, scn
+    d.M, d.N, d.K, d.K2, d.alpha, d.beta = M, N, K, 0, float(alpha), float(beta)
+    if second is not None:
+        A2, sam2, sak2, B2, sbn2, sbk2, K2 = second[:7]
+        o2a, o2b = (second[7], second[8]) if len(second) > 7 else (0, 0)
+        d.A2, d.B2, d.sam2, d.sak2, d.sbn2, d.sbk2, d.K2 = ptr(A2) + 4 * o2a, ptr(B2) + 4 * o2b, sam2, sak2, sbn2, sbk2, K2
+    return d
+
+
+def gemm_grouped(descs):
+    """Up to 8 independent products in ONE launch (csrc/gemm_grouped.hip).  The tensors behind the descriptors must stay alive
+    until the launch is enqueued (they do: the callers hold them)."""
+    for i in range(0, len(descs), _lib.GEMM_GROUP_MAX):
+        chunk = descs[i:i + _lib.GEMM_GROUP_MAX]
+        arr = (_lib.GemmDesc * len(chunk))(*chunk)
+        call("ttdg_gemm_f32_grouped", arr, len(chunk), stream())
+
+
+GROUPED_GEMM = os.environ.get("TTDG_GROUPED_GEMM", "1") != "0"      # False = one launch per product (A/B)
 
 
 def linear_raw(x, W, b=None, w_col_off=0, w_ld=None, out=None):
@@ -132,6 +160,28 @@ def sinkhorn_pairs_fwd(part, b2, gr, sizes, tau, iters, want_pot=True):
         pot = torch.empty(G * (G + 1) // 2, iters, max(sizes) + 1, device=part.device, dtype=torch.float32)
     call("ttdg_sinkhorn_pairs_fwd", ptr(part), ks, ptr(b2), gr, float(tau), int(iters), ptr(Wds), ptr(pot), stream())
     return Wds, pot
+
+
+FUSED_PAIR_STAGE = os.environ.get("TTDG_FUSED_PAIR", "1") != "0"     # graphs of <= 64 nodes: affinity + pair Sinkhorn in one launch (csrc/pair_stage.hip); False = the two-launch form (A/B)
+PAIR_STAGE_MAX = 64
+
+
+def pair_stage_fwd(P, Q, w2, b2, gr, sizes, tau, iters, want_pot=True):
+    """-> (aff (1, M, M): the affinity without b2, Wds (M, M), pot) in ONE launch; graphs of at most 64 nodes."""
+    M = P.shape[0]
+    G = len(sizes)
+    aff = torch.empty(1, M, M, device=P.device, dtype=torch.float32)
+    Wds = torch.empty(M, M, device=P.device, dtype=torch.float32)
+    pot = torch.empty(G * (G + 1) // 2, iters, max(sizes) + 1, device=P.device, dtype=torch.float32) if want_pot else None
+    call("ttdg_pair_stage_fwd", ptr(P), ptr(Q), ptr(w2), ptr(b2), P.shape[1], gr, float(tau), int(iters), ptr(aff), ptr(Wds), ptr(pot), stream())
+    return aff, Wds, pot
+
+
+def pair_stage_bwd(aff, b2, pot, dWds, gr, tau, iters):
+    M = aff.shape[-1]
+    dM = torch.empty(M, M, device=aff.device, dtype=torch.float32)
+    call("ttdg_pair_stage_bwd", ptr(aff), ptr(b2), ptr(pot), ptr(dWds), gr, float(tau), int(iters), ptr(dM), stream())
+    return dM
 
 
 def sinkhorn_pairs_bwd(part, b2, pot, dWds, gr, tau, iters):
@@ -340,28 +390,46 @@ class MatchingLossFn(torch.autograd.Function):
         sizes = [int(s) for s in sizes]
         gr = graphs(sizes)
         G, M = len(sizes), sum(sizes)
-        Xs = linear_raw(X, Psr)
-        Xt = linear_raw(X, Ptg)
-        P = linear_raw(Xs, W1, None, 0, HID)
-        Q = linear_raw(Xt, W1, b1, DIM, HID)
+        if GROUPED_GEMM:
+            # seven projections in two launches: {Xs, Xt, q, k, U0} <- X, then {P, Q} <- {Xs, Xt}
+            dev = X.device
+            Xs, Xt, q, k = (torch.empty(M, DIM, device=dev, dtype=torch.float32) for _ in range(4))
+            U0 = torch.empty(M, U.shape[0], device=dev, dtype=torch.float32)
+            P, Q = (torch.empty(M, HID, device=dev, dtype=torch.float32) for _ in range(2))
+            gemm_grouped([gdesc(X, DIM, 1, Psr, DIM, 1, Xs, DIM, 1, M, DIM, DIM), gdesc(X, DIM, 1, Ptg, DIM, 1, Xt, DIM, 1, M, DIM, DIM),
+                          gdesc(X, DIM, 1, Wq, DIM, 1, q, DIM, 1, M, DIM, DIM, bias=bq), gdesc(X, DIM, 1, Wk, DIM, 1, k, DIM, 1, M, DIM, DIM, bias=bk),
+                          gdesc(X, DIM, 1, U, DIM, 1, U0, U.shape[0], 1, M, U.shape[0], DIM)])
+            gemm_grouped([gdesc(Xs, DIM, 1, W1, HID, 1, P, HID, 1, M, HID, DIM),
+                          gdesc(Xt, DIM, 1, W1, HID, 1, Q, HID, 1, M, HID, DIM, bias=b1, b_off=DIM)])
+        else:
+            Xs = linear_raw(X, Psr)
+            Xt = linear_raw(X, Ptg)
+            P = linear_raw(Xs, W1, None, 0, HID)
+            Q = linear_raw(Xt, W1, b1, DIM, HID)
         w2f = w2.reshape(-1)
-        ks = opts.get("ksplit") or pick_ksplit(M, HID, max(sizes))
-        with _timed("affinity_fwd", sizes):
-            part = affinity_pairwise_fwd(P, Q, w2f, gr, ks)
         tau, iters = opts.get("pair_tau", 0.05), opts.get("pair_iters", 20)
-        with _timed("sinkhorn_pairs_fwd", sizes):
-            Wds, pot = sinkhorn_pairs_fwd(part, b2, gr, sizes, tau, iters)
-        q = linear_raw(X, Wq, bq)
-        k = linear_raw(X, Wk, bk)
+        fused = FUSED_PAIR_STAGE and max(sizes) <= PAIR_STAGE_MAX and not opts.get("ksplit")
+        if fused:
+            with _timed("pair_stage_fwd", sizes):
+                part, Wds, pot = pair_stage_fwd(P, Q, w2f, b2, gr, sizes, tau, iters)
+        else:
+            ks = opts.get("ksplit") or pick_ksplit(M, HID, max(sizes))
+            with _timed("affinity_fwd", sizes):
+                part = affinity_pairwise_fwd(P, Q, w2f, gr, ks)
+            with _timed("sinkhorn_pairs_fwd", sizes):
+                Wds, pot = sinkhorn_pairs_fwd(part, b2, gr, sizes, tau, iters)
+        if not GROUPED_GEMM:
+            q = linear_raw(X, Wq, bq)
+            k = linear_raw(X, Wk, bk)
+            U0 = linear_raw(X, U)
         apack = mha_adjacency(q, k, gr, sizes, DIM ** -0.5, opts.get("drop_p", 0.0), opts.get("seed", 0))
-        U0 = linear_raw(X, U)
         if opts.get("forced_U") is not None:      # parity tests: pseudo-labels supplied by the caller
             Ub, info, V0 = opts["forced_U"].contiguous(), None, None
         else:
             Ub, info, V0 = gagm_solve(apack, Wds, U0, gr, sizes, opts.get("gagm_cfg"))
         loss, dWds, flag = perm_loss_fwd_bwd(Wds, Ub, gr, G)
         ctx.save_for_backward(X, Xs, Xt, P, Q, W1, w2f, b2, Psr, Ptg, part, pot, dWds)
-        ctx.meta = (sizes, tau, iters)
+        ctx.meta = (sizes, tau, iters, fused)
         trace = opts.get("trace")
         if trace is not None:
             trace.update(Wds=Wds, apack=apack, U0=U0, Ub=Ub, info=info, V0=V0, P=P, Q=Q, part=part)
@@ -371,14 +439,32 @@ class MatchingLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss, _gflag):
         X, Xs, Xt, P, Q, W1, w2f, b2, Psr, Ptg, part, pot, dWds = ctx.saved_tensors
-        sizes, tau, iters = ctx.meta
+        sizes, tau, iters, fused = ctx.meta
         gr = graphs(sizes)
         M = X.shape[0]
         # everything downstream is linear in dWds: apply the incoming loss scale (normally 1.0) once, here
-        with _timed("sinkhorn_pairs_bwd", sizes):
-            dM = sinkhorn_pairs_bwd(part, b2, pot, dWds * gloss, gr, tau, iters)
+        if fused:
+            with _timed("pair_stage_bwd", sizes):
+                dM = pair_stage_bwd(part, b2, pot, dWds * gloss, gr, tau, iters)
+        else:
+            with _timed("sinkhorn_pairs_bwd", sizes):
+                dM = sinkhorn_pairs_bwd(part, b2, pot, dWds * gloss, gr, tau, iters)
         with _timed("affinity_bwd", sizes):
             dP, dQ, dw2, db2 = affinity_pairwise_bwd(P, Q, w2f, dM, gr)
+        if GROUPED_GEMM:
+            # eight gradient products in two launches
+            dW1, dXs, dXt = torch.empty_like(W1), torch.empty_like(Xs), torch.empty_like(Xt)
+            gemm_grouped([gdesc(dP, 1, HID, Xs, 1, DIM, dW1, HID, 1, HID, DIM, M),                     # dW1[:, :256] = dP^T Xs
+                          gdesc(dQ, 1, HID, Xt, 1, DIM, dW1, HID, 1, HID, DIM, M, c_off=DIM),          # dW1[:, 256:] = dQ^T Xt
+                          gdesc(dP, HID, 1, W1, 1, HID, dXs, DIM, 1, M, DIM, HID),                     # dXs = dP W1[:, :256]
+                          gdesc(dQ, HID, 1, W1, 1, HID, dXt, DIM, 1, M, DIM, HID, b_off=DIM)])         # dXt = dQ W1[:, 256:]
+            db1 = colsum(dQ)
+            dPsr, dPtg, dX = torch.empty_like(Psr), torch.empty_like(Ptg), torch.empty_like(X)
+            gemm_grouped([gdesc(dXs, 1, DIM, X, 1, DIM, dPsr, DIM, 1, DIM, DIM, M),                    # dPsr = dXs^T X
+                          gdesc(dXt, 1, DIM, X, 1, DIM, dPtg, DIM, 1, DIM, DIM, M),
+                          gdesc(dXs, DIM, 1, Psr, 1, DIM, dX, DIM, 1, M, DIM, DIM,                     # dX = dXs Psr + dXt Ptg (two K segments)
+                                second=(dXt, DIM, 1, Ptg, 1, DIM, DIM))])
+            return (dX, dW1, db1, dw2.view(1, HID), db2, dPsr, dPtg, None, None, None, None, None, None, None)
         dW1 = torch.empty_like(W1)
         gemm(dP, 1, HID, Xs, 1, DIM, dW1, HID, 1, HID, DIM, M)                    # dW1[:, :256] = dP^T Xs
         gemm(dQ, 1, HID, Xt, 1, DIM, dW1, HID, 1, HID, DIM, M, c_off=DIM)         # dW1[:, 256:] = dQ^T Xt
