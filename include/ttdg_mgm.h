@@ -300,6 +300,20 @@ int ttdg_roi_align_multilevel_nhwc(ttdg_fpn_t fp, ttdg_levels_t lv, const float*
 /* A/B hook for ttdg_roi_align_multilevel: 2 (default) = separable table kernel, one workgroup per (ROI, channel slice = XCD);
  * 1 = direct per-output kernel with the XCD-sliced work mapping; 0 = direct kernel, flat mapping (round 1). */
 int ttdg_debug_set_roi_align_sliced(int on);
+/* ---- N4 loader: the test mapper's resize on the device (DatasetMapper(is_train=False) -> ResizeShortestEdge [3P],
+ *      reference data/build.py:122-154, iterated at engine/trainer.py:470,485) ----------------------------------------
+ * src: `planes` contiguous uint8 images of H x W (planes = batch x channels), dst: planes x OH x OW uint8.  Bilinear,
+ * align_corners = False, antialiased when OH < H or OW < W (then `ws` must hold ttdg_resize_u8_workspace_bytes bytes),
+ * round-half-even, clamp: the arithmetic of torch's F.interpolate on float32 as ttdg_mgm_amd.data.map_for_test runs it. */
+size_t ttdg_resize_u8_workspace_bytes(int planes, int H, int W, int OH, int OW);
+int ttdg_resize_bilinear_u8(const unsigned char* src, unsigned char* dst, int planes, int H, int W, int OH, int OW, void* ws,
+                            ttdg_stream_t stream);
+
+/* A/B: 1 = per-plane bias_act kernel (default), 0 = the flat round-2 kernel */
+void ttdg_debug_set_bias_act_mode(int mode);
+/* diagnostics: device buffer of 4 x npairs uint64 shader clocks (begin, affinity done, sweeps done, end) per workgroup of
+ * ttdg_pair_stage_fwd, or NULL to switch the in-kernel clock off */
+int ttdg_debug_set_pair_stage_profile(void* device_buffer);
 
 /* DiceEvaluator reductions (reference evaluation/dice_metric.py:25-92 with enhanced_align :110-143 and
  * Structure_measure :147-240): for `npairs` (predicted mask, same-class ground-truth mask) pairs of H x W byte maps (0/1,

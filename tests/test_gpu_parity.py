@@ -1328,6 +1328,30 @@ def test_mask_pair_counts_kernel_exact(dev, H, W):
         assert row == quadrant_counts(P[a], G[b], cy, cx), (a, b, cy, cx)
 
 
+# ------------------------------------------------------------------------------------------- N4: loader on the device
+@pytest.mark.parametrize("shape,min_size,max_size", [((3, 512, 512), 800, 1333), ((3, 384, 384), 384, 1333), ((3, 640, 480), 320, 1333),
+                                                     ((3, 300, 500), 800, 1333), ((1, 97, 131), 211, 260), ((3, 800, 800), 511, 1333)])
+def test_device_resize_matches_host_mapper(dev, shape, min_size, max_size):
+    """csrc/resize.hip against the host mapper (data.map_for_test = F.interpolate on float32, antialiased when shrinking, round,
+    uint8): never more than 1 LSB apart, and equal on all but a sliver of pixels (the taps are summed in another order, so a
+    value that lands within rounding of x.5 may go the other way)."""
+    from ttdg_mgm_amd import data, ops
+    g = synth.gen(shape[1] * 7 + shape[2])
+    img = torch.from_numpy(g.integers(0, 256, size=(2,) + shape, dtype=np.uint8))
+    # smooth content too: half of the batch is a blurred ramp (x.5 cases are common on flat gradients)
+    yy, xx = np.mgrid[0:shape[1], 0:shape[2]]
+    img[1] = torch.from_numpy(((yy * 3 + xx * 2) % 256).astype(np.uint8))[None].expand(shape[0], -1, -1)
+    h, w = shape[1], shape[2]
+    nh, nw = data.mapped_size(h, w, min_size, max_size)
+    host = torch.stack([data.map_for_test(dict(image=img[k], height=h, width=w, image_id=k, annotations=[]), min_size, max_size)["image"] for k in range(2)])
+    got = ops.resize_u8(img.to(dev), nh, nw).cpu()
+    assert got.shape == host.shape and got.dtype == torch.uint8
+    d = (got.int() - host.int()).abs()
+    frac = float((d > 0).float().mean())
+    print("resize %s -> %s: max |d| %d LSB, %.2e of the pixels differ" % (shape, (nh, nw), int(d.max()), frac))
+    assert int(d.max()) <= 1 and frac <= 2e-3
+
+
 # ------------------------------------------------------------------------------------------- what was actually asserted
 def test_statement_ledger():
     """Must run last.  Asserts how often the strong branch of every data-dependent test fired (full-file runs only: a
@@ -1355,4 +1379,4 @@ def test_statement_ledger():
     assert LEDGER["large_solver.hungarian_step_identical"] >= 1
 
 
-LARGE_MIN_STAGE_COUNTS, LARGE_MIN_IDENTICAL = 6, 0        # set from the recorded ledger (profiles/r03_parity_ledger.json)
+LARGE_MIN_STAGE_COUNTS, LARGE_MIN_IDENTICAL = 18, 1       # recorded: 21 stage counts compared, 1 case free of capped stages and identical (profiles/r03_parity_ledger.json)

@@ -158,7 +158,8 @@ def test_cfg2_full_size_tta_step_matches_host_pipeline(trained):
 
 
 CENSUS_STEPS = 16
-CENSUS_MIN_STRONG = 0          # set from the recorded census (profiles/r03_trained_census.json), see the test's docstring
+CENSUS_MIN_STRONG = 0          # recorded (profiles/r03_trained_census.json): 0 of 16 - under per-projection rounding noise the reference's own
+                               # answer is not well defined on ANY batch of this regime; all 16 take the spread statement
 
 
 def test_trained_regime_solver_census(trained):
@@ -203,8 +204,13 @@ def test_trained_regime_solver_census(trained):
         rec.append(dict(step=step, sizes=sizes, strong=bool(c["stable"]), device_iters=it, oracle_iters=c["iters32"], objective_device=obj,
                         objective_oracle_runs=c["objectives"], loss_device=ld, loss_oracle_runs=c["losses"],
                         device_equals_oracle32=bool(torch.equal(Ud @ Ud.t(), c["U32"] @ c["U32"].t()))))
+    # the reproducible part of the trajectory holds in the live regime too: the stages at tau = 0.1, 0.05, 0.025 take the
+    # reference's iteration counts on EVERY step, the tau = 0.0125 stage on most (recorded: 15 of 16)
+    assert all(r["device_iters"][:3] == r["oracle_iters"][:3] for r in rec), [(r["device_iters"], r["oracle_iters"]) for r in rec]
+    n4 = sum(r["device_iters"][:4] == r["oracle_iters"][:4] for r in rec)
+    assert n4 >= CENSUS_STEPS - 4, n4
     nstrong = sum(r["strong"] for r in rec)
-    summary = dict(steps=len(rec), strong=nstrong, weak=len(rec) - nstrong, device_equals_oracle32=sum(r["device_equals_oracle32"] for r in rec),
+    summary = dict(steps=len(rec), strong=nstrong, weak=len(rec) - nstrong, first_three_stage_counts_identical=len(rec), first_four_stage_counts_identical=n4, device_equals_oracle32=sum(r["device_equals_oracle32"] for r in rec),
                    mean_iterations=sum(sum(r["device_iters"]) for r in rec) / len(rec), records=rec)
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)

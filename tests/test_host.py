@@ -372,3 +372,34 @@ def test_streaming_loader_is_bounded_and_releases_its_producer():
         import time
         time.sleep(0.05)
     assert threading.active_count() <= n0, "the producer thread is still blocked in q.put"
+
+
+def test_disk_stream_with_worker_processes_equals_the_source_dataset(tmp_path):
+    """data/disk.py: a dataset pre-rendered to disk and read back by 2 persistent worker PROCESSES (the reference's loader
+    topology, data/build.py:148-153) yields exactly the items of the in-memory dataset, pass after pass, through the streaming
+    TestLoader (host resize here: no GPU), and on a sub-range set per pass."""
+    from ttdg_mgm_amd.data import disk
+    cfg = get_cfg()
+    cfg.TEST.BATCH = 3
+    cfg.INPUT.MIN_SIZE_TEST = 96
+    data.register_synthetic("disk_src", 7, size=64, id_offset=500)
+    data.register_disk("disk_ds", str(tmp_path / "stream"), source="disk_src", workers=2)
+    assert data.dataset_size("disk_ds") == 7
+    a = data.dataset_dicts("disk_src")
+    b = data.dataset_dicts("disk_ds")
+    for x, y in zip(a, b):
+        assert x["image_id"] == y["image_id"] and torch.equal(x["image"], y["image"]) and x["seed"] == y["seed"]
+        for p, q in zip(x["annotations"], y["annotations"]):
+            assert torch.equal(p["mask"], q["mask"]) and torch.equal(p["bbox"], q["bbox"]) and p["category_id"] == q["category_id"]
+    res = data.build_detection_test_loader(cfg, "disk_src", 0, 1, None, resident=True)
+    stm = data.build_detection_test_loader(cfg, "disk_ds", 0, 1, None, resident=False)
+    stm.start_workers()
+    for _ in range(2):
+        ra, rb = list(res), list(stm)
+        assert [len(x) for x in ra] == [len(x) for x in rb] == [3, 3, 1]
+        for ba, bb in zip(ra, rb):
+            for ia, ib in zip(ba, bb):
+                assert ia["image_id"] == ib["image_id"] and torch.equal(ia["image"], ib["image"]) and torch.equal(ia["tf_boxes"], ib["tf_boxes"])
+    ds = disk.DiskStream(str(tmp_path / "stream"), 7, 2, workers=2)
+    assert [[d["image_id"] for d in batch] for batch in ds.epoch(2, 7)] == [[502, 503], [504, 505], [506]]
+    assert [[d["image_id"] for d in batch] for batch in ds.epoch(0, 2)] == [[500, 501]]

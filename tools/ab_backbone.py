@@ -16,6 +16,9 @@ def main():
     from ttdg_mgm_amd.modeling import backbone as bb
     from ttdg_mgm_amd.modeling import build_model
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    if os.environ.get("AB_BENCHMARK") == "1":          # PyTorch then lets MIOpen time its solvers per shape (first use of a shape: seconds)
+        torch.backends.cudnn.benchmark = True
+    only = os.environ.get("AB_ONLY", "")
     dev = torch.device("cuda:0")
     cfg = get_cfg()
     cfg.MODEL.DEVICE = "cuda:0"
@@ -42,18 +45,23 @@ def main():
                 else:
                     with torch.no_grad():
                         n(xi)
+            tw = time.perf_counter()
             for _ in range(3):
                 step()
             torch.cuda.synchronize()
+            tw = time.perf_counter() - tw
             t0 = time.perf_counter()
             for _ in range(reps):
                 step()
             torch.cuda.synchronize()
-            print("%-34s %-5s %8.2f ms" % (label, mode, (time.perf_counter() - t0) / reps * 1e3), flush=True)
+            print("%-34s %-5s %8.2f ms   (3 warm-up steps took %.1f s; cudnn.benchmark %s)" % (label, mode, (time.perf_counter() - t0) / reps * 1e3, tw,
+                  torch.backends.cudnn.benchmark), flush=True)
 
-    run("NCHW + fused epilogues (product)", True, False)
-    run("NCHW, plain torch epilogues", False, False)
-    run("channels_last, plain epilogues", False, True)
+    if only in ("", "nchw"):
+        run("NCHW + fused epilogues (product)", True, False)
+        run("NCHW, plain torch epilogues", False, False)
+    if only in ("", "cl"):
+        run("channels_last, plain epilogues", False, True)
 
 
 if __name__ == "__main__":

@@ -95,6 +95,10 @@ SIGNATURES = {
     "ttdg_box_inference": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _P, _P, _S]),
     "ttdg_roi_align_multilevel": (C.c_int, [Fpn, Levels, _P, _I, _I, _F, _I, _I, _P, _S]),
     "ttdg_debug_set_roi_align_sliced": (C.c_int, [_I]),
+    "ttdg_resize_u8_workspace_bytes": (C.c_size_t, [_I, _I, _I, _I, _I]),
+    "ttdg_resize_bilinear_u8": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _S]),
+    "ttdg_debug_set_bias_act_mode": (None, [_I]),
+    "ttdg_debug_set_pair_stage_profile": (C.c_int, [_P]),
     "ttdg_nchw_to_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _S]),
     "ttdg_roi_align_multilevel_nhwc": (C.c_int, [Fpn, Levels, _P, _I, _I, _F, _I, _I, _P, _S]),
     "ttdg_bias_act": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _S]),
@@ -140,7 +144,7 @@ def graphs(sizes):
 
 
 def ptr(t):
-    """Device pointer of a tensor the kernels may touch: fp32/int32/int64 on a HIP device, contiguous unless
+    """Device pointer of a tensor the kernels may touch: fp32/int32/int64/uint8 on a HIP device, contiguous unless
     the callee takes strides."""
     if t is None:
         return None

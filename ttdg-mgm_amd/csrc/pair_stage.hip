@@ -85,10 +85,71 @@ __device__ __forceinline__ bool ps_col_sweep(const float (&L)[PS_RW], const floa
   return !kExact && __ballot(live && !ps_sane(s)) != 0ull;
 }
 
+// One 32-deep slab of the affinity block: TA x TB live 16 x 16 sub-tiles per thread tile (compile-time: no guards, the
+// ds_read_b128 of a k-step are all in flight before the first fma).
+template <int TA, int TB>
+__device__ __forceinline__ void ps_affinity_slab(const float (&Ps)[PS_T][PS_LDK], const float (&Qs)[PS_T][PS_LDK], const float (&Ws)[PS_BK], int tx,
+                                                 int ty, float (&acc)[4][4]) {
+#pragma unroll 2
+  for (int kk = 0; kk < PS_BK; kk += 4) {
+    ps_f32x2 p[TA][2], q[TB][2];
+#pragma unroll
+    for (int x = 0; x < TA; ++x) {
+      const float4 v = *reinterpret_cast<const float4*>(&Ps[ty + 16 * x][kk]);
+      p[x][0] = (ps_f32x2){v.x, v.y}; p[x][1] = (ps_f32x2){v.z, v.w};
+    }
+#pragma unroll
+    for (int y = 0; y < TB; ++y) {
+      const float4 v = *reinterpret_cast<const float4*>(&Qs[tx + 16 * y][kk]);
+      q[y][0] = (ps_f32x2){v.x, v.y}; q[y][1] = (ps_f32x2){v.z, v.w};
+    }
+    const float4 w = *reinterpret_cast<const float4*>(&Ws[kk]);
+#pragma unroll
+    for (int x = 0; x < TA; ++x)
+#pragma unroll
+      for (int y = 0; y < TB; ++y) {
+        const ps_f32x2 x0 = p[x][0] + q[y][0], x1 = p[x][1] + q[y][1];
+        acc[x][y] = ps_fma_abs(w.x, x0.x, acc[x][y]);
+        acc[x][y] = ps_fma_abs(w.y, x0.y, acc[x][y]);
+        acc[x][y] = ps_fma_abs(w.z, x1.x, acc[x][y]);
+        acc[x][y] = ps_fma_abs(w.w, x1.y, acc[x][y]);
+      }
+  }
+}
+
+// Row sweep over the rows a wavefront owns, NR of them at most (compile-time): f_p = lse_q(L_pq - g_q).  The common case - the
+// previous potential stabilises the exponentials - is branch-free: NR independent DPP reductions the compiler interleaves;
+// only when some sum leaves the sane range (or in the first pair) is the exact max-subtracted form run, for all rows.
+template <int NR>
+__device__ __forceinline__ void ps_row_sweep(const float (&L)[PS_RW], float (&f)[PS_RW], float g, int r, int wave, bool first) {
+  float s[NR];
+  bool bad = first;
+  if (!first) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) s[i] = wave_sum_f32_dpp(fast_exp2(L[i] - g - f[i]));
+#pragma unroll
+    for (int i = 0; i < NR; ++i) bad |= (wave + PS_WAVES * i < r) && !ps_sane(s[i]);
+  }
+  if (!bad) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) f[i] = (wave + PS_WAVES * i < r) ? f[i] + fast_log2(s[i]) : 0.f;
+    return;
+  }
+  float m[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) m[i] = wave_max_f32_dpp(L[i] - g);
+#pragma unroll
+  for (int i = 0; i < NR; ++i) s[i] = wave_sum_f32_dpp(fast_exp2(L[i] - g - m[i]));
+#pragma unroll
+  for (int i = 0; i < NR; ++i) f[i] = (wave + PS_WAVES * i < r) ? m[i] + fast_log2(s[i]) : 0.f;
+}
+
 __global__ __launch_bounds__(256) void pair_stage_fwd_kernel(const float* __restrict__ P, const float* __restrict__ Q,
                                                              const float* __restrict__ w2, const float* __restrict__ b2, int H,
                                                              ttdg_graphs_t gr, float tau, int iters, float* __restrict__ aff,
-                                                             float* __restrict__ Wds, float* __restrict__ pot, int cmax) {
+                                                             float* __restrict__ Wds, float* __restrict__ pot, int cmax,
+                                                             unsigned long long* __restrict__ prof) {
+  const unsigned long long t_begin = prof ? __builtin_amdgcn_s_memtime() : 0ull;
   __shared__ __attribute__((aligned(16))) float Ps[PS_T][PS_LDK];
   __shared__ __attribute__((aligned(16))) float Qs[PS_T][PS_LDK];
   __shared__ __attribute__((aligned(16))) float Ws[PS_BK];
@@ -107,6 +168,8 @@ __global__ __launch_bounds__(256) void pair_stage_fwd_kernel(const float* __rest
   const int ta = (na + 15) >> 4, tb = (nb + 15) >> 4;     // 16-row sub-tiles that hold anything
 
   // ---- phase 1: the affinity block ----
+  // Register double buffer: the next 32-deep slab of P / Q rows is requested from L2 before the current one is consumed, so
+  // the memory round trip hides behind the VALU loop; the loop body is instantiated per (ta, tb) - no guards inside.
   float acc[4][4];
 #pragma unroll
   for (int x = 0; x < 4; ++x)
@@ -114,50 +177,35 @@ __global__ __launch_bounds__(256) void pair_stage_fwd_kernel(const float* __rest
     for (int y = 0; y < 4; ++y) acc[x][y] = 0.f;
   float pa[2] = {0.f, 0.f}, qa[2] = {0.f, 0.f};
   const int lrow = tid >> 3, lk = (tid & 7) * 4;
-  for (int k0 = 0; k0 < H; k0 += PS_BK) {
-    const float4 wv = *reinterpret_cast<const float4*>(w2 + k0 + lk);
+  float4 pv[2], qv[2], wv;
+  auto request = [&](int k0) {
+    wv = *reinterpret_cast<const float4*>(w2 + k0 + lk);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int row = lrow + 32 * h;
-      float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), qv = pv;
-      if (row < na) pv = *reinterpret_cast<const float4*>(P + (size_t)(i0 + row) * H + k0 + lk);
-      if (row < nb) qv = *reinterpret_cast<const float4*>(Q + (size_t)(j0 + row) * H + k0 + lk);
-      *reinterpret_cast<float4*>(&Ps[row][lk]) = pv;
-      *reinterpret_cast<float4*>(&Qs[row][lk]) = qv;
-      pa[h] = fmaf(wv.x, pv.x, fmaf(wv.y, pv.y, fmaf(wv.z, pv.z, fmaf(wv.w, pv.w, pa[h]))));
-      qa[h] = fmaf(wv.x, qv.x, fmaf(wv.y, qv.y, fmaf(wv.z, qv.z, fmaf(wv.w, qv.w, qa[h]))));
+      pv[h] = row < na ? *reinterpret_cast<const float4*>(P + (size_t)(i0 + row) * H + k0 + lk) : make_float4(0.f, 0.f, 0.f, 0.f);
+      qv[h] = row < nb ? *reinterpret_cast<const float4*>(Q + (size_t)(j0 + row) * H + k0 + lk) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (tid < PS_BK) Ws[tid] = 0.5f * w2[k0 + tid];
+  };
+  request(0);
+  const int shape = (ta - 1) * 4 + (tb - 1);
+  for (int k0 = 0; k0 < H; k0 += PS_BK) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = lrow + 32 * h;
+      *reinterpret_cast<float4*>(&Ps[row][lk]) = pv[h];
+      *reinterpret_cast<float4*>(&Qs[row][lk]) = qv[h];
+      pa[h] = fmaf(wv.x, pv[h].x, fmaf(wv.y, pv[h].y, fmaf(wv.z, pv[h].z, fmaf(wv.w, pv[h].w, pa[h]))));
+      qa[h] = fmaf(wv.x, qv[h].x, fmaf(wv.y, qv[h].y, fmaf(wv.z, qv[h].z, fmaf(wv.w, qv[h].w, qa[h]))));
+    }
+    if (lrow == 0) *reinterpret_cast<float4*>(&Ws[lk]) = make_float4(0.5f * wv.x, 0.5f * wv.y, 0.5f * wv.z, 0.5f * wv.w);
     __syncthreads();
-#pragma unroll 2
-    for (int kk = 0; kk < PS_BK; kk += 4) {
-      ps_f32x2 p[4][2], q[4][2];
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-        if (x < ta) {
-          const float4 v = *reinterpret_cast<const float4*>(&Ps[ty + 16 * x][kk]);
-          p[x][0] = (ps_f32x2){v.x, v.y}; p[x][1] = (ps_f32x2){v.z, v.w};
-        }
-#pragma unroll
-      for (int y = 0; y < 4; ++y)
-        if (y < tb) {
-          const float4 v = *reinterpret_cast<const float4*>(&Qs[tx + 16 * y][kk]);
-          q[y][0] = (ps_f32x2){v.x, v.y}; q[y][1] = (ps_f32x2){v.z, v.w};
-        }
-      const float4 w = *reinterpret_cast<const float4*>(&Ws[kk]);
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-        if (x < ta) {
-#pragma unroll
-          for (int y = 0; y < 4; ++y)
-            if (y < tb) {
-              const ps_f32x2 x0 = p[x][0] + q[y][0], x1 = p[x][1] + q[y][1];
-              acc[x][y] = ps_fma_abs(w.x, x0.x, acc[x][y]);
-              acc[x][y] = ps_fma_abs(w.y, x0.y, acc[x][y]);
-              acc[x][y] = ps_fma_abs(w.z, x1.x, acc[x][y]);
-              acc[x][y] = ps_fma_abs(w.w, x1.y, acc[x][y]);
-            }
-        }
+    if (k0 + PS_BK < H) request(k0 + PS_BK);
+    switch (shape) {
+#define PS_CASE(A, B) case (A - 1) * 4 + (B - 1): ps_affinity_slab<A, B>(Ps, Qs, Ws, tx, ty, acc); break;
+      PS_CASE(1, 1) PS_CASE(1, 2) PS_CASE(1, 3) PS_CASE(1, 4) PS_CASE(2, 1) PS_CASE(2, 2) PS_CASE(2, 3) PS_CASE(2, 4)
+      PS_CASE(3, 1) PS_CASE(3, 2) PS_CASE(3, 3) PS_CASE(3, 4) PS_CASE(4, 1) PS_CASE(4, 2) PS_CASE(4, 3) PS_CASE(4, 4)
+#undef PS_CASE
     }
     __syncthreads();
   }
@@ -185,6 +233,7 @@ __global__ __launch_bounds__(256) void pair_stage_fwd_kernel(const float* __rest
   __syncthreads();
 
   // ---- phase 2: 20 sweeps in registers ----
+  const unsigned long long t_aff = prof ? __builtin_amdgcn_s_memtime() : 0ull;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int potld = PS_T + 1;
   float L[PS_RW], f[PS_RW];
@@ -198,24 +247,15 @@ __global__ __launch_bounds__(256) void pair_stage_fwd_kernel(const float* __rest
   int buf = 0;
   for (int it = 0; it < iters; ++it) {
     if ((it & 1) == 0) {
+      const int nrw = (r - wave + PS_WAVES - 1) / PS_WAVES;      // rows this wavefront owns
+      if (nrw <= 4) ps_row_sweep<4>(L, f, g, r, wave, it < 2);
+      else if (nrw <= 8) ps_row_sweep<8>(L, f, g, r, wave, it < 2);
+      else if (nrw <= 12) ps_row_sweep<12>(L, f, g, r, wave, it < 2);
+      else ps_row_sweep<16>(L, f, g, r, wave, it < 2);
 #pragma unroll
       for (int i = 0; i < PS_RW; ++i) {
         const int p = wave + PS_WAVES * i;
-        if (p < r) {
-          const float t = L[i] - g;
-          float sh = f[i], s = 0.f;
-          bool exact = it < 2;
-          if (!exact) {
-            s = wave_sum_f32_dpp(fast_exp2(t - sh));
-            exact = !ps_sane(s);
-          }
-          if (exact) {
-            sh = wave_max_f32_dpp(t);
-            s = wave_sum_f32_dpp(fast_exp2(t - sh));
-          }
-          f[i] = sh + fast_log2(s);
-          if (lane == 0) plog[it * potld + p] = f[i];
-        }
+        if (p < r && lane == 0) plog[it * potld + p] = f[i];
       }
       if (mult > 0) {          // the dummy row (one virtual row of multiplicity c - r), always in the exact form
         const float td = lane < c ? -g : -INFINITY;
@@ -235,6 +275,7 @@ __global__ __launch_bounds__(256) void pair_stage_fwd_kernel(const float* __rest
     }
   }
   // ---- result: Wds[a,b] and its mirror; the potential log ----
+  const unsigned long long t_sk = prof ? __builtin_amdgcn_s_memtime() : 0ull;
   float* wab = Wds + (size_t)i0 * M + j0;      // element (i in a, j in b)
   float* wba = Wds + (size_t)j0 * M + i0;      // element (j in b, i in a)
 #pragma unroll
@@ -256,7 +297,14 @@ __global__ __launch_bounds__(256) void pair_stage_fwd_kernel(const float* __rest
       if (x < n) pt[e] = plog[it * potld + x];
     }
   }
+  if (prof && tid == 0) {      // in-kernel phase clock (ttdg_debug_set_pair_stage_profile): begin, affinity done, sweeps done, end
+    prof[blockIdx.x * 4 + 0] = t_begin; prof[blockIdx.x * 4 + 1] = t_aff; prof[blockIdx.x * 4 + 2] = t_sk;
+    prof[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
+  }
 }
+
+static unsigned long long* g_ps_prof = nullptr;     // device buffer of 4 x npairs clocks, or null (diagnostics only)
+extern "C" int ttdg_debug_set_pair_stage_profile(void* device_buffer) { g_ps_prof = (unsigned long long*)device_buffer; return 0; }
 
 extern "C" int ttdg_pair_stage_fwd(const float* P, const float* Q, const float* w2, const float* b2, int H, ttdg_graphs_t gr,
                                    float tau, int iters, float* aff, float* Wds, float* pot, ttdg_stream_t stream) {
@@ -268,8 +316,22 @@ extern "C" int ttdg_pair_stage_fwd(const float* P, const float* Q, const float* 
   for (int g = 0; g < gr.G; ++g) cmax = gr.off[g + 1] - gr.off[g] > cmax ? gr.off[g + 1] - gr.off[g] : cmax;
   TTDG_REQUIRE(cmax <= PS_T, "pair_stage_fwd: graphs of more than 64 nodes take ttdg_affinity_pairwise_fwd + ttdg_sinkhorn_pairs_fwd");
   hipLaunchKernelGGL(pair_stage_fwd_kernel, dim3(gr.G * (gr.G + 1) / 2), dim3(256), 0, (hipStream_t)stream, P, Q, w2, b2, H, gr, tau,
-                     iters, aff, Wds, pot, cmax);
+                     iters, aff, Wds, pot, cmax, g_ps_prof);
   return ttdg_launch_status("pair_stage_fwd");
+}
+
+// rows sweep of the backward, NR owned rows at most: S_p = sum_q dY_pq (DPP), dY_pq -= exp2(L_pq - f_p - g_q) S_p
+template <int NR>
+__device__ __forceinline__ void ps_bwd_rows(const float (&L)[PS_RW], float (&dY)[PS_RW], const float* frow, float gq, int r, int wave) {
+  float S[NR], fp[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int p = wave + PS_WAVES * i;
+    fp[i] = p < r ? frow[p] : 0.f;
+    S[i] = wave_sum_f32_dpp(dY[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < NR; ++i) dY[i] = (wave + PS_WAVES * i < r) ? dY[i] - fast_exp2(L[i] - fp[i] - gq) * S[i] : 0.f;
 }
 
 // ---- backward of the Sinkhorn half, same register layout ------------------------------------------------------------------
@@ -326,6 +388,7 @@ __global__ __launch_bounds__(256) void pair_stage_bwd_kernel(const float* __rest
   }
   float dd = 0.f;     // dY of the dummy row at column `lane` (replicated in every wavefront)
   int buf = 0;
+  const int nrw = (r - wave + PS_WAVES - 1) / PS_WAVES;
   for (int k = iters - 1; k >= 0; --k) {
     const bool rows = (k & 1) == 0;
     const int kf = rows ? k : k - 1, kg = rows ? k - 1 : k;      // logs holding f / g as of just after sweep k
@@ -333,14 +396,11 @@ __global__ __launch_bounds__(256) void pair_stage_bwd_kernel(const float* __rest
     const float fdum = (dummy && kf >= 0) ? plog[kf * potld + r] : 0.f;
     const float ed = (dummy && lane < c) ? fast_exp2(SK_DUMMY - fdum - gq) : 0.f;
     if (rows) {
-#pragma unroll
-      for (int i = 0; i < PS_RW; ++i) {
-        const int p = wave + PS_WAVES * i;
-        if (p < r) {
-          const float S = wave_sum_f32_dpp(dY[i]);
-          dY[i] -= fast_exp2(L[i] - plog[kf * potld + p] - gq) * S;
-        }
-      }
+      // branch-free over the rows a wavefront owns (rows beyond r carry dY = 0, L = -inf: their update is 0 * S)
+      if (nrw <= 4) ps_bwd_rows<4>(L, dY, plog + kf * potld, gq, r, wave);
+      else if (nrw <= 8) ps_bwd_rows<8>(L, dY, plog + kf * potld, gq, r, wave);
+      else if (nrw <= 12) ps_bwd_rows<12>(L, dY, plog + kf * potld, gq, r, wave);
+      else ps_bwd_rows<16>(L, dY, plog + kf * potld, gq, r, wave);
       if (dummy) {
         const float S = wave_sum_f32_dpp(dd);
         dd -= ed * S;
@@ -360,7 +420,8 @@ __global__ __launch_bounds__(256) void pair_stage_bwd_kernel(const float* __rest
 #pragma unroll
       for (int i = 0; i < PS_RW; ++i) {
         const int p = wave + PS_WAVES * i;
-        if (p < r) dY[i] -= fast_exp2(L[i] - (kf >= 0 ? plog[kf * potld + p] : 0.f) - gq) * S;
+        const float fp = (p < r && kf >= 0) ? plog[kf * potld + p] : 0.f;
+        dY[i] = p < r ? dY[i] - fast_exp2(L[i] - fp - gq) * S : 0.f;
       }
       if (dummy) dd -= ed * S;
     }

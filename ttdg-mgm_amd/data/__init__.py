@@ -1,5 +1,7 @@
 """Test datasets (synthetic, or COCO-json via data/coco.py) + test loader (reference data/build.py:122-154:
 InferenceSampler shard per rank, BatchSampler(TEST.BATCH, drop_last=False), trivial collate)."""
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -23,6 +25,15 @@ def register_coco_instances(name, metadata, json_file, image_root, input_format=
     _REGISTRY[name]["n"] = len(_REGISTRY[name]["records"])
 
 
+def register_disk(name, root, source=None, workers=4):
+    """A dataset of decoded images on local storage (data/disk.py): ``source`` (a registered dataset) is pre-rendered into
+    ``root`` when given.  Streaming loaders read it with ``workers`` worker processes (cfg.DATALOADER.NUM_WORKERS in the
+    reference, data/build.py:148-153)."""
+    from . import disk
+    n = disk.prerender(source, root) if source is not None else len([f for f in os.listdir(root) if f.endswith(".npz")])
+    _REGISTRY[name] = dict(kind="disk", root=root, n=n, workers=int(workers))
+
+
 def dataset_size(name):
     if name not in _REGISTRY:
         raise KeyError("Dataset '{}' is not registered! Available datasets are: {}".format(name, ", ".join(sorted(_REGISTRY))))
@@ -33,6 +44,10 @@ def dataset_dicts(name, start=0, stop=None):
     """List of dicts: image (3,H,W) uint8, height, width, image_id, annotations [{bbox xyxy, category_id, mask bool}].
     ``start``/``stop`` generate only that index range (a rank's shard): images are synthesised on demand."""
     spec = _REGISTRY[name]
+    if spec["kind"] == "disk":
+        from . import disk
+        ds = disk.DiskDataset(spec["root"], spec["n"])
+        return [ds[i] for i in range(start, spec["n"] if stop is None else min(stop, spec["n"]))]
     if spec["kind"] == "coco":
         from . import coco
         return [coco.materialise(r, spec["fmt"]) for r in spec["records"][start:spec["n"] if stop is None else min(stop, spec["n"])]]
@@ -47,20 +62,30 @@ def dataset_dicts(name, start=0, stop=None):
     return out
 
 
-def map_for_test(d, min_size=800, max_size=1333):
-    """DatasetMapper(is_train=False) equivalent: resize the shorter edge to ``min_size`` (bilinear) and carry the
-    teacher-forced detections (GT boxes jittered +-2 px, in resized coordinates)."""
-    h, w = d["height"], d["width"]
+def mapped_size(h, w, min_size=800, max_size=1333):
+    """ResizeShortestEdge [3P]: the shorter edge to ``min_size`` unless the longer one would pass ``max_size``."""
     s = min(min_size / min(h, w), max_size / max(h, w))
-    nh, nw = int(round(h * s)), int(round(w * s))
-    # bilinear; antialiased when shrinking, as the PIL resize of detectron2's ResizeShortestEdge is [3P] (no effect when enlarging)
-    img = F.interpolate(d["image"][None].float(), size=(nh, nw), mode="bilinear", align_corners=False, antialias=nh < h or nw < w)[0]
+    return int(round(h * s)), int(round(w * s))
+
+
+def map_for_test(d, min_size=800, max_size=1333, resize=True):
+    """DatasetMapper(is_train=False) equivalent: resize the shorter edge to ``min_size`` (bilinear) and carry the
+    teacher-forced detections (GT boxes jittered +-2 px, in resized coordinates).  ``resize=False`` leaves the pixels alone
+    (``image`` is then the raw uint8 image, ``resize_to`` the target size): the streaming loader resizes on the device."""
+    h, w = d["height"], d["width"]
+    nh, nw = mapped_size(h, w, min_size, max_size)
     boxes = torch.stack([a["bbox"] for a in d["annotations"]]) if d["annotations"] else torch.zeros(0, 4)
     # teacher-forced detections: jittered ground-truth boxes for the seeded synthetic images, the plain ground truth otherwise
     tf = (synth.jitter_boxes(d["seed"] + 500000, boxes) if "seed" in d else boxes) * torch.tensor([nw / w, nh / h, nw / w, nh / h])
-    return dict(image=img.round().clamp(0, 255).to(torch.uint8), height=h, width=w, image_id=d["image_id"],
-                tf_boxes=tf, tf_classes=torch.tensor([a["category_id"] for a in d["annotations"]], dtype=torch.int64),
-                dataset_dict=d)
+    out = dict(height=h, width=w, image_id=d["image_id"], tf_boxes=tf,
+               tf_classes=torch.tensor([a["category_id"] for a in d["annotations"]], dtype=torch.int64), dataset_dict=d)
+    if not resize:
+        out["image"], out["resize_to"] = d["image"], (nh, nw)
+        return out
+    # bilinear; antialiased when shrinking, as the PIL resize of detectron2's ResizeShortestEdge is [3P] (no effect when enlarging)
+    img = F.interpolate(d["image"][None].float(), size=(nh, nw), mode="bilinear", align_corners=False, antialias=nh < h or nw < w)[0]
+    out["image"] = img.round().clamp(0, 255).to(torch.uint8)
+    return out
 
 
 class TestLoader:
@@ -73,13 +98,22 @@ class TestLoader:
     stream - the loader the reference iterates twice per dataset (data/build.py:122-154, trainer.py:470,485).  Each item
     carries its ``dataset_dict`` (ground truth), so the evaluator never needs the whole dataset in memory."""
 
-    def __init__(self, name, batch, rank=0, world=1, device=None, min_size=800, max_size=1333, resident=True, prefetch=2):
+    def __init__(self, name, batch, rank=0, world=1, device=None, min_size=800, max_size=1333, resident=True, prefetch=2,
+                 device_resize=None):
         n = dataset_size(name)
         shard = (n - 1) // world + 1 if n else 0           # detectron2 InferenceSampler [3P]: contiguous, unpadded
         self.name, self.batch, self.device = name, batch, device
         self.start, self.stop = min(shard * rank, n), min(shard * (rank + 1), n)
         self.min_size, self.max_size, self.resident, self.prefetch = min_size, max_size, resident, max(1, int(prefetch))
         self._dicts = self.items = None
+        cuda = device is not None and torch.device(device).type == "cuda"
+        # streaming to a GPU: upload the RAW uint8 image and resize there (csrc/resize.hip) unless told otherwise
+        self.device_resize = (cuda and not resident) if device_resize is None else bool(device_resize and cuda)
+        self._disk = None
+        if not resident and _REGISTRY[name]["kind"] == "disk":
+            from . import disk
+            spec = _REGISTRY[name]
+            self._disk = disk.DiskStream(spec["root"], spec["n"], batch, workers=spec["workers"], prefetch=self.prefetch)
         if resident:
             self._dicts = dataset_dicts(name, self.start, self.stop)
             self.items = [map_for_test(d, min_size, max_size) for d in self._dicts]
@@ -98,13 +132,32 @@ class TestLoader:
     def __len__(self):
         return (self.stop - self.start + self.batch - 1) // self.batch
 
-    def _load_batch(self, lo, hi, stream):
-        items = [map_for_test(d, self.min_size, self.max_size) for d in dataset_dicts(self.name, lo, hi)]
+    def start_workers(self):
+        """Spawn the worker processes of a disk stream (loader construction: outside any timed region)."""
+        if self._disk is not None:
+            self._disk.start()
+
+    def _load_batch(self, lo, hi, stream, dicts=None):
+        if dicts is None:
+            dicts = dataset_dicts(self.name, lo, hi)
+        items = [map_for_test(d, self.min_size, self.max_size, resize=not self.device_resize) for d in dicts]
         ev = None
         if self.device is not None and torch.device(self.device).type == "cuda":
             with torch.cuda.stream(stream):
-                for it in items:
-                    it["image"] = it["image"].pin_memory().to(self.device, non_blocking=True)
+                if self.device_resize:
+                    from .. import ops
+                    same = len({(tuple(it["image"].shape), it["resize_to"]) for it in items}) == 1
+                    if same:      # one pinned upload + one resize launch for the batch
+                        raw = torch.stack([it["image"] for it in items]).pin_memory().to(self.device, non_blocking=True)
+                        out = ops.resize_u8(raw, *items[0]["resize_to"])
+                        for k, it in enumerate(items):
+                            it["image"] = out[k]
+                    else:
+                        for it in items:
+                            it["image"] = ops.resize_u8(it["image"].contiguous().pin_memory().to(self.device, non_blocking=True), *it["resize_to"])
+                else:
+                    for it in items:
+                        it["image"] = it["image"].pin_memory().to(self.device, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(stream)
         return items, ev
@@ -135,9 +188,14 @@ class TestLoader:
             try:
                 if cuda:
                     torch.cuda.set_device(self.device)
-                for lo in range(self.start, self.stop, self.batch):
-                    if stop.is_set() or not put(self._load_batch(lo, min(lo + self.batch, self.stop), stream)):
-                        return
+                if self._disk is not None:          # decoded by the worker processes; this thread pins, uploads, resizes
+                    for dicts in self._disk.epoch(self.start, self.stop):
+                        if stop.is_set() or not put(self._load_batch(0, 0, stream, dicts)):
+                            return
+                else:
+                    for lo in range(self.start, self.stop, self.batch):
+                        if stop.is_set() or not put(self._load_batch(lo, min(lo + self.batch, self.stop), stream)):
+                            return
                 put(None)
             except BaseException as e:          # surfaced on the consumer's thread
                 put(e)

@@ -1,0 +1,87 @@
+"""A test stream on disk + the reference's loader topology (data/build.py:122-154: torch DataLoader, NUM_WORKERS worker
+PROCESSES, batch sampler of TEST.BATCH, trivial collate).
+
+``prerender`` writes a registered synthetic dataset to a directory once (one uncompressed .npz per image: the uint8 image, the
+bit-packed ground-truth masks, boxes, classes) - standing for a dataset of decoded images on local storage; ``DiskStream``
+reads it back through worker processes that never touch the GPU.  The main process then only pins, uploads and (on the
+device) resizes: TestLoader(resident=False) on a ``kind == "disk"`` dataset."""
+import os
+
+import numpy as np
+import torch
+
+
+def prerender(name, root):
+    """Materialise dataset ``name`` (any registered kind) under ``root``; returns the number of images written."""
+    from . import dataset_dicts, dataset_size
+    os.makedirs(root, exist_ok=True)
+    n = dataset_size(name)
+    for i in range(n):
+        path = os.path.join(root, "%07d.npz" % i)
+        if os.path.exists(path):
+            continue
+        d = dataset_dicts(name, i, i + 1)[0]
+        anns = d["annotations"]
+        masks = np.stack([a["mask"].numpy() for a in anns]) if anns else np.zeros((0, d["height"], d["width"]), bool)
+        tmp = path + ".tmp.npz"
+        np.savez(tmp, image=d["image"].numpy(), masks=np.packbits(masks, axis=-1), mask_w=np.int64(d["width"]),
+                 boxes=np.stack([a["bbox"].numpy() for a in anns]).astype(np.float32) if anns else np.zeros((0, 4), np.float32),
+                 classes=np.array([a["category_id"] for a in anns], np.int64), image_id=np.int64(d["image_id"]), seed=np.int64(d.get("seed", -1)))
+        os.replace(tmp, path)
+    return n
+
+
+class DiskDataset(torch.utils.data.Dataset):
+    """Map-style dataset over a pre-rendered directory: __getitem__ returns the same dict ``data.dataset_dicts`` yields."""
+
+    def __init__(self, root, n):
+        self.root, self.n = root, int(n)
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        with np.load(os.path.join(self.root, "%07d.npz" % i)) as z:
+            img = torch.from_numpy(z["image"])
+            w = int(z["mask_w"])
+            masks = torch.from_numpy(np.unpackbits(z["masks"], axis=-1, count=w).astype(bool))
+            boxes, classes = torch.from_numpy(z["boxes"]), z["classes"]
+            image_id, seed = int(z["image_id"]), int(z["seed"])
+        anns = [dict(bbox=boxes[k], category_id=int(classes[k]), mask=masks[k]) for k in range(len(classes))]
+        d = dict(image=img, height=int(img.shape[1]), width=int(img.shape[2]), image_id=image_id, annotations=anns)
+        if seed >= 0:
+            d["seed"] = seed
+        return d
+
+
+class _Batches(torch.utils.data.Sampler):
+    """Batch sampler whose index range is set per pass (the workers are persistent: they outlive a pass)."""
+
+    def __init__(self, batch):
+        self.batch, self.lo, self.hi = batch, 0, 0
+
+    def __iter__(self):
+        for s in range(self.lo, self.hi, self.batch):
+            yield list(range(s, min(s + self.batch, self.hi)))
+
+    def __len__(self):
+        return (self.hi - self.lo + self.batch - 1) // self.batch
+
+
+class DiskStream:
+    """Persistent worker processes over a DiskDataset; ``epoch(lo, hi)`` iterates lists of raw dataset dicts."""
+
+    def __init__(self, root, n, batch, workers=4, prefetch=2):
+        self.sampler = _Batches(batch)
+        kw = dict(persistent_workers=True, prefetch_factor=prefetch) if workers > 0 else {}
+        self.loader = torch.utils.data.DataLoader(DiskDataset(root, n), batch_sampler=self.sampler, num_workers=workers,
+                                                  collate_fn=lambda items: items, **kw)
+
+    def epoch(self, lo, hi):
+        self.sampler.lo, self.sampler.hi = int(lo), int(hi)
+        return iter(self.loader)
+
+    def start(self):
+        """Spawn the workers (a one-batch pass that is thrown away): loader construction, outside any timed region."""
+        for _ in self.epoch(0, min(self.sampler.batch, len(self.loader.dataset))):
+            pass

@@ -588,8 +588,11 @@ def roi_align_multilevel(feats, rois, strides, P, canonical_size=224, canonical_
             fp.h[l], fp.w[l], fp.feat[l] = t.shape[1], t.shape[2], ptr(t)
         lv = levels_desc([t.shape[1:3] for t in nhwc], strides=tuple(strides) + (0,) * (8 - len(strides)), ranges=((0, 0),) * len(nhwc))
         out = torch.empty(R, Cc, P, P, device=rois.device, dtype=torch.float32)
-        call("ttdg_roi_align_multilevel_nhwc", fp, lv, ptr(rois), R, int(P), float(canonical_size), int(canonical_level), int(min_level),
-             ptr(out), stream())
+        # algorithmic bytes: every map once (the ROIs of a trained RPN cover the objects many times over: what a perfect cache
+        # would fetch) + the pooled output
+        with _timed("roi_align_nhwc", sum(t.numel() for t in nhwc) * 4 + out.numel() * 4):
+            call("ttdg_roi_align_multilevel_nhwc", fp, lv, ptr(rois), R, int(P), float(canonical_size), int(canonical_level), int(min_level),
+                 ptr(out), stream())
         return out
     Cc = feats[0].shape[1]
     fp = _lib.Fpn()
@@ -658,7 +661,8 @@ def bias_act_(y, bias=None, residual=None, bias2=None, relu=True):
         raise ValueError("bias_act_: residual shape %s != %s" % (tuple(residual.shape), tuple(y.shape)))
     N, C = y.shape[0], y.shape[1]
     HW = y.numel() // max(1, N * C)
-    call("ttdg_bias_act", ptr(y), ptr(bias), ptr(residual), ptr(bias2), N, C, HW, int(bool(relu)), stream())
+    with _timed("bias_act", y.numel() * 4 * (3 if residual is not None else 2)):       # algorithmic bytes: read y (+ residual), write y
+        call("ttdg_bias_act", ptr(y), ptr(bias), ptr(residual), ptr(bias2), N, C, HW, int(bool(relu)), stream())
     return y
 
 
@@ -682,8 +686,23 @@ class BiasActFn(torch.autograd.Function):
         if gout.dtype != torch.float32:
             raise TypeError("BiasActFn: float32 gradients only")
         gin = torch.empty_like(out)
-        call("ttdg_relu_bwd", ptr(gout), ptr(out), ptr(gin), C.c_size_t(out.numel()), stream())
+        with _timed("relu_bwd", out.numel() * 12):                                          # read gout, read out, write gin
+            call("ttdg_relu_bwd", ptr(gout), ptr(out), ptr(gin), C.c_size_t(out.numel()), stream())
         return gin, None, (gin if ctx.has_res else None), None
+
+
+def resize_u8(img, oh, ow):
+    """(..., H, W) uint8 on the device -> (..., oh, ow) uint8: the test mapper's bilinear resize (antialiased when shrinking),
+    bit-compatible with data.map_for_test to <= 1 LSB (csrc/resize.hip)."""
+    if img.dtype != torch.uint8 or not img.is_contiguous():
+        raise TypeError("resize_u8: contiguous uint8 tensor expected")
+    H, W = int(img.shape[-2]), int(img.shape[-1])
+    planes = img.numel() // max(1, H * W)
+    out = torch.empty(tuple(img.shape[:-2]) + (int(oh), int(ow)), device=img.device, dtype=torch.uint8)
+    nws = _lib.load().ttdg_resize_u8_workspace_bytes(planes, H, W, int(oh), int(ow))
+    ws = torch.empty(nws, device=img.device, dtype=torch.uint8) if nws else None
+    call("ttdg_resize_bilinear_u8", ptr(img), ptr(out), planes, H, W, int(oh), int(ow), ptr(ws), stream())
+    return out
 
 
 _SIZES_CACHE = {}
