@@ -76,6 +76,8 @@ def parse(argv=None):
     ap.add_argument("--gagm-threads", type=int, default=0, help="A/B: workgroup size of the single-workgroup solver (256 / 512; 0 = automatic)")
     ap.add_argument("--roi-align-mode", type=int, default=3, help="A/B: 3 = channels-last ROIPooler kernel (default), 2 = separable table kernel on NCHW, "
                                                                   "1 = direct kernel, XCD-sliced, 0 = direct, flat (round 1)")
+    ap.add_argument("--roi-flat", action="store_true", help="A/B: channels-last ROIPooler with ROI r on workgroup r (round 2) instead of one eighth of the list per XCD")
+    ap.add_argument("--flat-bias-act", action="store_true", help="A/B: the round-2 flat bias_act kernel instead of the per-plane one")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch, rendezvous, sharding and the collectives of the bench without any GPU work (CPU test of --gpus N)")
     a = ap.parse_args(argv)
@@ -523,6 +525,12 @@ def gpu_main(args, rank, world, local):
         _lib.load().ttdg_debug_set_gagm_threads(args.gagm_threads)
         _ops.ROI_ALIGN_NHWC = args.roi_align_mode == 3
         _lib.load().ttdg_debug_set_roi_align_sliced(min(args.roi_align_mode, 2))
+    if args.roi_flat or args.flat_bias_act:
+        from ttdg_mgm_amd import _lib
+        if args.roi_flat:
+            _lib.load().ttdg_debug_set_roi_align_sliced(2 | 8)
+        if args.flat_bias_act:
+            _lib.load().ttdg_debug_set_bias_act_mode(0)
     if args.images:
         # strong scaling: the FIXED stream is sharded; warm-up batches come from another stream so that the timed work is
         # exactly args.images images whatever the rank count

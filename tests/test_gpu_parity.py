@@ -411,7 +411,7 @@ def test_fused_pair_stage_forward_backward(dev, sizes):
     print("fused pair stage %s: |Wds - fp64| %.2e (fp32 oracle %.2e)" % (sizes, maxerr(Wd, W64.float()), maxerr(W32, W64.float())))
     if G > 1:
         dM = ops.pair_stage_bwd(aff, bd, pot, (Rw * mask).to(dev), gr, 0.05, 20)
-        derived_gate("fused pair stage bwd %s" % (sizes,), dM.cpu() * low, M32.grad * low, M64.grad * low)
+        derived_gate("fused pair stage bwd %s" % (sizes,), torch.where(low > 0, dM.cpu(), torch.zeros(())), M32.grad * low, M64.grad * low)
     # against the two-launch form on the same inputs (different summation order: ~1e-6)
     part = ops.affinity_pairwise_fwd(Pd, Qd, wd, gr, 2)
     W2, pot2 = ops.sinkhorn_pairs_fwd(part, bd, gr, list(sizes), 0.05, 20)
@@ -419,7 +419,8 @@ def test_fused_pair_stage_forward_backward(dev, sizes):
     assert maxerr(part.sum(0).cpu() * tri, aff[0].cpu() * tri) <= 1e-5 * scale
     if G > 1:
         dM2 = ops.sinkhorn_pairs_bwd(aff, bd, pot, (Rw * mask).to(dev), gr, 0.05, 20)        # the old backward reads the new plane + log
-        assert maxerr(dM2.cpu() * low, dM.cpu() * low) <= 1e-4 * max(1.0, float((M64.grad * low).abs().max()))
+        zero = torch.zeros(())                                  # (dM is only written where g(i) > g(j): mask by selection, not by 0 * garbage)
+        assert maxerr(torch.where(low > 0, dM2.cpu(), zero), torch.where(low > 0, dM.cpu(), zero)) <= 1e-4 * max(1.0, float((M64.grad * low).abs().max()))
     with pytest.raises(RuntimeError):
         big = (70, 20)
         ops.pair_stage_fwd(torch.zeros(90, H, device=dev), torch.zeros(90, H, device=dev), wd, bd, ops.graphs(big), list(big), 0.05, 20)
@@ -989,6 +990,76 @@ def test_cfg3_scale_front_end_and_large_solver(dev):
         assert float(blk.sum()) == 32 and float(blk.sum(0).max()) <= 1 and float(blk.sum(1).max()) <= 1
     assert torch.isfinite(loss) and all(torch.isfinite(x.grad).all() for x in dn)
     assert all(torch.isfinite(p.grad).all() for k, p in m.named_parameters() if k.startswith("node_affinity"))
+
+
+def test_cfg3_full_size_forward_backward_against_the_oracle(dev):
+    """BASELINE cfg-3 at FULL size - 8 graphs x 256 nodes - against the oracle itself, not only through
+    size-independent properties: every block of Wds (36 pairs incl. the diagonal), A, U0, the first V, the loss and ALL
+    gradients (d nodes, the six affinity tensors), with the device's own pseudo-labels supplied to both sides (the free-running
+    solve of random weights is rounding noise in the reference too).  The oracle's formulation is the reference's: materialised
+    (256, 256, 1024) affinity MLP per pair and a per-pair Sinkhorn; pairs are differentiated one at a time (the reference keeps
+    two 256 x 256 x 512 tensors per pair alive: 9.7 GB for the 36 pairs)."""
+    import itertools
+    from oracle import gmodule as og
+    from ttdg_mgm_amd.GModule import MGM3_unsup
+    import os
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(min(64, os.cpu_count() or 1))          # beyond 64 intra-op threads torch's CPU kernels stop scaling here
+    G, n = 8, 256
+    sizes = (n,) * G
+    off = [g * n for g in range(G + 1)]
+    M = G * n
+    params = synth.mgm3_params(3003)
+    U = synth.universe(3004)
+    nodes, labels = synth.node_sets(3001, sizes, scale=0.1)
+    m = MGM3_unsup(2, 32).to(dev).eval()
+    m.load_state_dict(params, strict=True)
+    dn = [x.to(dev).requires_grad_() for x in nodes]
+    tr = {}
+    loss = m(dn, [l.to(dev) for l in labels], U.to(dev), trace=tr)
+    loss.backward()
+    Ub = tr["Ub"].cpu()
+    # ---- oracle, pair by pair
+    p = {k: v.clone().requires_grad_() for k, v in params.items()}
+    rn = [x.clone().requires_grad_() for x in nodes]
+    Wds = torch.zeros(M, M)
+    npairs = G * (G - 1) // 2
+    ref_loss = 0.0
+    for a in range(G):
+        for b in range(a + 1):
+            if a == b:
+                with torch.no_grad():
+                    Wds[off[a]:off[a + 1], off[a]:off[a + 1]] = og.sinkhorn_pair(og.affinity(p, rn[a], rn[a]))
+                continue
+            ds = og.sinkhorn_pair(og.affinity(p, rn[a], rn[b]))             # equal sizes: no transposition (:518-522)
+            Wds[off[a]:off[a + 1], off[b]:off[b + 1]] = ds.detach()
+            Wds[off[b]:off[b + 1], off[a]:off[a + 1]] = ds.detach().t()
+            # the loss reads Wds[i-rows, j-cols] for i < j: i = b, j = a -> ds^T, pseudo-label U_i U_j^T (:615-631)
+            lp = og.permutation_loss(ds.t().unsqueeze(0), (Ub[off[b]:off[b + 1]] @ Ub[off[a]:off[a + 1]].t()).unsqueeze(0)) / npairs
+            lp.backward()
+            ref_loss += float(lp.detach())
+    A = torch.zeros(M, M)
+    with torch.no_grad():
+        for g in range(G):
+            A[off[g]:off[g + 1], off[g]:off[g + 1]] = og.mha_adjacency(p, rn[g])
+        A.fill_diagonal_(0)
+        U0 = torch.cat([x @ U.t() for x in rn])
+        V0 = (torch.linalg.multi_dot([A, U0 @ U0.t(), A, U0]) + Wds @ U0) / G
+    print("cfg-3 full size: |Wds| %.2e  |A| %.2e  |U0| rel %.2e  |V0| rel %.2e  loss %.6f vs %.6f" % (
+        maxerr(tr["Wds"], Wds), maxerr(tr["apack"], _pack(A, sizes)), maxerr(tr["U0"], U0) / max(1.0, float(U0.abs().max())),
+        maxerr(tr["V0"], V0) / max(1.0, float(V0.abs().max())), float(loss), ref_loss))
+    assert maxerr(tr["Wds"], Wds) <= TOL
+    assert maxerr(tr["apack"], _pack(A, sizes)) <= 1e-5
+    assert maxerr(tr["U0"], U0) <= TOL * max(1.0, float(U0.abs().max()))
+    assert maxerr(tr["V0"], V0) <= TOL * max(1.0, float(V0.abs().max()))
+    assert abs(float(loss) - ref_loss) <= TOL
+    for a, b in zip(dn, rn):
+        assert maxerr(a.grad, b.grad) <= TOL * max(1.0, float(b.grad.abs().max()))
+    for k, q in m.named_parameters():
+        if k.startswith("node_affinity."):
+            g_ref = p[k].grad
+            assert maxerr(q.grad, g_ref) <= TOL * max(1.0, float(g_ref.abs().max())), k
+    torch.set_num_threads(nthreads)
 
 
 # ------------------------------------------------------------------------------------------- N1: fused box pipelines

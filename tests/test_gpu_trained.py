@@ -415,3 +415,81 @@ def test_cfg5_bf16_backbone_vs_fp32_on_trained_checkpoint(trained):
     # bit-reproducible: vendor convolutions), 0.30 on random init
     assert rel <= 0.4, rel
     assert abs(l16f - l32) <= 0.5 * abs(l32) + 1e-3
+
+
+def test_cfg5_own_checkpoint_bf16_backbone_vs_fp32(trained):
+    """cfg-5 on ITS OWN workload and checkpoint - the 384 x 384 3-class polyp stream, a checkpoint fitted on
+    that stream (tools/synth_checkpoint.py kind = "polyp") - instead of the cfg-2 stream or random weights.
+      (1) eval-mode Dice / E / S over 16 held-out images with the bf16-autocast backbone against the fp32 backbone, same
+          weights: reported, and bounded by CFG5_DICE_TOL (measured: see profiles/r03_cfg5_precision.json; the north_star's
+          1e-3 is a statement about the fp32 path - bf16 keeps 8 significant bits through ~50 convolutions);
+      (2) the matching operators stay fp32: on the node features the bf16 backbone produced, Wds / U0 / loss / gradients
+          against the oracle within 1e-4, with the device's pseudo-labels supplied to both sides."""
+    import json
+    import synth_checkpoint as sc
+    from oracle import gmodule as og
+    from ttdg_mgm_amd import data
+    from ttdg_mgm_amd.config import get_cfg
+    from ttdg_mgm_amd.engine import BaselineTrainer, inference_on_dataset
+    from ttdg_mgm_amd.engine.checkpoint import load_weights
+    from ttdg_mgm_amd.evaluation import DiceEvaluator
+    dev = torch.device("cuda:0")
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "test_segment.yaml"))
+    cfg.MODEL.DEVICE, cfg.MODEL.ROI_HEADS.NUM_CLASSES, cfg.INPUT.MIN_SIZE_TEST = "cuda:0", 3, 384
+    path, rep = sc.get_or_make(cfg, dev, log=lambda m: None, kind="polyp", size=384)
+    data.register_synthetic("cfg5_own", 16, size=384, cfg_id=5, kind="polyp", num_cls=3)
+    BaselineTrainer.rank, BaselineTrainer.world, BaselineTrainer.device = 0, 1, dev
+    loader = BaselineTrainer.build_test_loader(cfg, "cfg5_own")
+    out = {}
+    models = {}
+    for name in ("f32", "bf16"):
+        m = BaselineTrainer.build_model(cfg)
+        load_weights(m, path)
+        m.autocast_backbone = name == "bf16"
+        ev = DiceEvaluator("cfg5_own", cfg.TEST.DICE_THRES, dataset_dicts=loader.dataset_dicts)
+        res, _ = inference_on_dataset(m, loader, ev, cfg)
+        out[name] = dict(res, kept=len(ev.dice_scores))
+        models[name] = m
+    rel = {k: abs(out["bf16"][k] - out["f32"][k]) / abs(out["f32"][k]) for k in ("Dice Coefficient", "Enhanced Alignment Metric", "Structural Similarity Metric")}
+    print("cfg-5 own checkpoint: fp32 backbone %s | bf16 backbone %s | relative differences %s" % (out["f32"], out["bf16"], rel))
+    assert out["f32"]["kept"] >= 8 and out["f32"]["Dice Coefficient"] > 50.0, "the polyp checkpoint must segment its own stream"
+    assert abs(out["bf16"]["kept"] - out["f32"]["kept"]) <= max(2, out["f32"]["kept"] // 8)
+    for k, v in rel.items():
+        assert v <= CFG5_DICE_TOL, (k, v)
+    # (2) fp32 matching on the bf16 backbone's node features
+    m16 = models["bf16"]
+    m16.train()
+    m16.teacher_forced = False
+    mm = m16.multi_matching_unsup
+    mm.eval()
+    mm.keep_trace = True
+    batch = list(loader)[0]
+    with torch.no_grad():
+        l16, _, _, _ = m16(batch, branch="TTT")
+    t = mm.last
+    assert l16 is not None and t["X"].dtype == torch.float32 and t["Wds"].dtype == torch.float32
+    sizes = list(t["sizes"])
+    nodes = [x.cpu() for x in torch.split(t["X"], sizes)]
+    labels = [torch.ones(n, dtype=torch.int64) for n in sizes]
+    p = {k: v.detach().cpu().clone().requires_grad_() for k, v in mm.named_parameters()}
+    rn = [x.clone().requires_grad_() for x in nodes]
+    otr = {}
+    ref = og.mgm3_unsup_forward(p, rn, labels, m16.multi_matching_sup.U.detach().cpu(), trace=otr, forced_U=t["Ub"].cpu())
+    ref.backward()
+    dn = [x.to(dev).requires_grad_() for x in nodes]
+    tr2 = {}
+    l2 = mm(dn, [l.to(dev) for l in labels], m16.multi_matching_sup.U, trace=tr2, forced_U=t["Ub"])
+    l2.backward()
+    mm.zero_grad()
+    assert float((tr2["Wds"].cpu() - otr["Wds"]).abs().max()) <= TOL
+    assert float((tr2["U0"].cpu() - otr["U0"]).abs().max()) <= TOL * max(1.0, float(otr["U0"].abs().max()))
+    assert abs(float(l2.detach()) - float(ref.detach())) <= TOL
+    for a, b in zip(dn, rn):
+        assert float((a.grad.cpu() - b.grad).abs().max()) <= TOL * max(1.0, float(b.grad.abs().max()))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "cfg5_precision.json"), "w") as f:
+        json.dump(dict(checkpoint=rep, f32=out["f32"], bf16=out["bf16"], relative_difference=rel, tolerance=CFG5_DICE_TOL), f, indent=1, default=str)
+
+
+CFG5_DICE_TOL = 5e-2        # tightened to the measured value + margin once recorded (profiles/r03_cfg5_precision.json)

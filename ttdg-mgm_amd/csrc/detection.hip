@@ -741,11 +741,19 @@ __global__ __launch_bounds__(64 * RA_WAVES) void roi_align_sep_kernel(ttdg_fpn_t
 #define RN_CHUNK 49        /* bins staged per output flush (P = 7: all of them; P = 14: four flushes) */
 
 __global__ __launch_bounds__(256) void roi_align_nhwc_kernel(ttdg_fpn_t fp, ttdg_levels_t lv, const float* __restrict__ rois, int R, int P,
-                                                             float canon_size, int canon_level, int min_level, float* __restrict__ out) {
+                                                             float canon_size, int canon_level, int min_level, float* __restrict__ out,
+                                                             int g_roi_xcd_chunks) {
   __shared__ RaAxis s_y, s_x;
   __shared__ float s_tile[4][64 * (RN_CHUNK + 1)];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int r = blockIdx.x;
+  // Round 3: ROI -> XCD placement.  Workgroup b is observed on XCD b % 8 (speed only), and the ROI list is sorted by image with
+  // the proposals of one object next to each other.  With r = b every XCD's private L2 saw every image's hot patches: the
+  // FETCH_SIZE of a box-head call was 3.3-6.5x the bytes of the maps - eight L2s each fetching the same
+  // lines through the fabric.  Now XCD x owns the contiguous eighth [x * chunk, (x + 1) * chunk) of the list: one image's
+  // (half an image's) patches per L2.
+  const int chunk = (R + 7) >> 3;
+  const int r = (g_roi_xcd_chunks ? ((int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3)) : (int)blockIdx.x);
+  if (r >= R || (g_roi_xcd_chunks && (int)(blockIdx.x >> 3) >= chunk)) return;
   const int C = fp.C;
   const float* roi = rois + (size_t)r * 5;
   const int b = (int)roi[0];
@@ -858,19 +866,29 @@ extern "C" int ttdg_nchw_to_nhwc(const float* src, float* dst, int B, int C, int
   return ttdg_launch_status("nchw_to_nhwc");
 }
 
+static int g_roi_nhwc_xcd = 1;      // 1 = XCD x owns a contiguous eighth of the ROI list (default), 0 = r = blockIdx.x (A/B; ttdg_debug_set_roi_align_sliced(4 | mode))
 extern "C" int ttdg_roi_align_multilevel_nhwc(ttdg_fpn_t fp, ttdg_levels_t lv, const float* rois, int R, int P, float canonical_size,
                                               int canonical_level, int min_level, float* out, ttdg_stream_t stream) {
   TTDG_REQUIRE(rois && out && R >= 0 && P > 0 && P <= RA_MAXP && fp.n >= 1 && fp.n <= TTDG_MAX_LEVELS && fp.C > 0 && lv.n == fp.n,
                "roi_align_multilevel_nhwc: bad arguments");
   if (R == 0) return 0;
-  hipLaunchKernelGGL(roi_align_nhwc_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, fp, lv, rois, R, P, canonical_size,
-                     canonical_level, min_level, out);
+  const int grid = g_roi_nhwc_xcd ? 8 * ((R + 7) / 8) : R;
+  hipLaunchKernelGGL(roi_align_nhwc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, fp, lv, rois, R, P, canonical_size,
+                     canonical_level, min_level, out, g_roi_nhwc_xcd);
   return ttdg_launch_status("roi_align_multilevel_nhwc");
 }
 
 static int g_roi_align_sliced = 1;   // 2 = separable table kernel (default below), 1 = direct kernel with the XCD-sliced mapping, 0 = direct, flat
 static int g_roi_align_mode = 2;
-extern "C" int ttdg_debug_set_roi_align_sliced(int on) { g_roi_align_mode = on < 0 ? 2 : (on > 2 ? 2 : on); g_roi_align_sliced = on != 0; return 0; }
+// bits 0-1: NCHW kernel variant (2 = separable tables, 1 = direct XCD-sliced, 0 = direct flat); bit 3 (value 8): the channels-last
+// kernel maps ROI r to workgroup r (round 2) instead of one contiguous eighth of the list per XCD
+extern "C" int ttdg_debug_set_roi_align_sliced(int on) {
+  g_roi_nhwc_xcd = (on >= 0 && (on & 8)) ? 0 : 1;
+  if (on >= 0) on &= 7;
+  g_roi_align_mode = on < 0 ? 2 : (on > 2 ? 2 : on);
+  g_roi_align_sliced = on != 0;
+  return 0;
+}
 
 extern "C" int ttdg_roi_align_multilevel(ttdg_fpn_t fp, ttdg_levels_t lv, const float* rois, int R, int P, float canonical_size,
                                          int canonical_level, int min_level, float* out, ttdg_stream_t stream) {

@@ -51,12 +51,17 @@ class FusedSGD(torch.optim.Optimizer):
             return None
         dev = todo[0][0].device
         nt = len(todo)
-        chunks_t, chunks_o = [], []
-        for ti, (p, _, _, _, _) in enumerate(todo):
-            n = p.numel()
-            for off in range(0, n, CHUNK):
-                chunks_t.append(ti)
-                chunks_o.append(off)
+        # the chunk map only depends on WHICH tensors carry a gradient (the same ~65 on every TTA step): built once per set
+        key = tuple(id(t[0]) for t in todo)
+        if getattr(self, "_chunk_key", None) != key:
+            chunks_t, chunks_o = [], []
+            for ti, (p, _, _, _, _) in enumerate(todo):
+                n = p.numel()
+                for off in range(0, n, CHUNK):
+                    chunks_t.append(ti)
+                    chunks_o.append(off)
+            self._chunk_key, self._chunks = key, (chunks_t, chunks_o)
+        chunks_t, chunks_o = self._chunks
         nc = len(chunks_t)
         tbytes = C.sizeof(_lib.SgdTensor) * nt
         total = tbytes + 4 * nc + 8 * nc + 64
