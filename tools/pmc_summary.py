@@ -4,7 +4,8 @@ usage: pmc_summary.py <FETCH counter_collection.csv> <WRITE counter_collection.c
 import csv, json, statistics, sys
 OURS = ("gagm_kernel", "sgd_multi_tensor", "affinity_fwd", "affinity_bwd_kernel", "sinkhorn_pairs_fwd", "sinkhorn_pairs_bwd",
         "perm_loss_pair", "node_gather", "node_labels", "roi_align_fwd", "gagm_large_mul", "gagm_large_project", "mask_pair_counts",
-        "roi_align_ml", "roi_align_nhwc", "roi_align_sep", "nchw_to_nhwc", "paste_masks", "bias_act", "relu_bwd", "mha_adjacency", "gemm_f32")
+        "roi_align_ml", "roi_align_nhwc", "roi_align_sep", "nchw_to_nhwc", "paste_masks", "bias_act", "relu_bwd", "mha_adjacency", "gemm_f32",
+        "pair_stage_fwd", "pair_stage_bwd", "gemm_grouped", "resize_")
 
 
 def collect(path, counter):
@@ -27,6 +28,10 @@ for k in sorted(set(rd) | set(wr)):
     res[k] = {"launches": len(rd.get(k, [])), "FETCH_SIZE_KB_median": f, "WRITE_SIZE_KB_median": w,
               "median_duration_us": statistics.median(d for _, d in rd.get(k, [(0, 0)])) / 1e3,
               "hbm_bytes_per_launch_raw": (f + w) * 1024.0,
-              "hbm_bytes_per_launch_streaming_corrected": (2 * f + w) * 1024.0}
+              "hbm_bytes_per_launch_streaming_corrected": (2 * f + w) * 1024.0,
+              # kernels launched at many sizes (bias_act, relu_bwd): the MEAN over the launches is what compares with the mean
+              # algorithmic bytes per launch of the bench line
+              "hbm_bytes_per_launch_mean_raw": (statistics.mean(v for v, _ in rd.get(k, [(0, 0)])) + statistics.mean(v for v, _ in wr.get(k, [(0, 0)]))) * 1024.0,
+              "hbm_bytes_per_launch_mean_streaming_corrected": (2 * statistics.mean(v for v, _ in rd.get(k, [(0, 0)])) + statistics.mean(v for v, _ in wr.get(k, [(0, 0)]))) * 1024.0}
 json.dump(res, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(res, indent=1))

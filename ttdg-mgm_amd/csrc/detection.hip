@@ -866,7 +866,8 @@ extern "C" int ttdg_nchw_to_nhwc(const float* src, float* dst, int B, int C, int
   return ttdg_launch_status("nchw_to_nhwc");
 }
 
-static int g_roi_nhwc_xcd = 1;      // 1 = XCD x owns a contiguous eighth of the ROI list (default), 0 = r = blockIdx.x (A/B; ttdg_debug_set_roi_align_sliced(4 | mode))
+static int g_roi_nhwc_xcd = 0;      // 1 = XCD x owns a contiguous eighth of the ROI list, 0 = ROI r on workgroup r (default: measured 427 vs 437 us per call,
+                                    // profiles/r03_roi_align_ab.txt - the pooler is not bound by fabric traffic); ttdg_debug_set_roi_align_sliced(mode | 16) selects 1
 extern "C" int ttdg_roi_align_multilevel_nhwc(ttdg_fpn_t fp, ttdg_levels_t lv, const float* rois, int R, int P, float canonical_size,
                                               int canonical_level, int min_level, float* out, ttdg_stream_t stream) {
   TTDG_REQUIRE(rois && out && R >= 0 && P > 0 && P <= RA_MAXP && fp.n >= 1 && fp.n <= TTDG_MAX_LEVELS && fp.C > 0 && lv.n == fp.n,
@@ -880,10 +881,10 @@ extern "C" int ttdg_roi_align_multilevel_nhwc(ttdg_fpn_t fp, ttdg_levels_t lv, c
 
 static int g_roi_align_sliced = 1;   // 2 = separable table kernel (default below), 1 = direct kernel with the XCD-sliced mapping, 0 = direct, flat
 static int g_roi_align_mode = 2;
-// bits 0-1: NCHW kernel variant (2 = separable tables, 1 = direct XCD-sliced, 0 = direct flat); bit 3 (value 8): the channels-last
-// kernel maps ROI r to workgroup r (round 2) instead of one contiguous eighth of the list per XCD
+// bits 0-1: NCHW kernel variant (2 = separable tables, 1 = direct XCD-sliced, 0 = direct flat); bit 4 (value 16): the channels-last
+// kernel gives every XCD one contiguous eighth of the ROI list instead of ROI r on workgroup r
 extern "C" int ttdg_debug_set_roi_align_sliced(int on) {
-  g_roi_nhwc_xcd = (on >= 0 && (on & 8)) ? 0 : 1;
+  g_roi_nhwc_xcd = (on >= 0 && (on & 16)) ? 1 : 0;
   if (on >= 0) on &= 7;
   g_roi_align_mode = on < 0 ? 2 : (on > 2 ? 2 : on);
   g_roi_align_sliced = on != 0;

@@ -158,6 +158,12 @@ class TestLoader:
                 else:
                     for it in items:
                         it["image"] = it["image"].pin_memory().to(self.device, non_blocking=True)
+                # the evaluator's inputs travel the same way: ground-truth masks pinned and uploaded on the side stream, so that
+                # the Dice pass never issues a pageable (= synchronous) copy on the compute stream
+                for it in items:
+                    anns = it["dataset_dict"]["annotations"]
+                    if anns and "device_masks" not in it["dataset_dict"]:
+                        it["dataset_dict"]["device_masks"] = torch.stack([a["mask"] for a in anns]).pin_memory().to(self.device, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(stream)
         return items, ev
@@ -215,6 +221,9 @@ class TestLoader:
                     cur.wait_event(ev)                           # the upload ran on the side stream
                     for it in items:                             # allocated on the side stream, consumed on this one: the
                         it["image"].record_stream(cur)           # caching allocator must not recycle it under queued kernels
+                        dm = it["dataset_dict"].get("device_masks")
+                        if dm is not None:
+                            dm.record_stream(cur)
                 yield items
                 del items, got
         finally:

@@ -47,7 +47,14 @@ class DiskDataset(torch.utils.data.Dataset):
             masks = torch.from_numpy(np.unpackbits(z["masks"], axis=-1, count=w).astype(bool))
             boxes, classes = torch.from_numpy(z["boxes"]), z["classes"]
             image_id, seed = int(z["image_id"]), int(z["seed"])
-        anns = [dict(bbox=boxes[k], category_id=int(classes[k]), mask=masks[k]) for k in range(len(classes))]
+        anns = []
+        for k in range(len(classes)):
+            m = masks[k]
+            rows, cols = m.sum(1, dtype=torch.int64), m.sum(0, dtype=torch.int64)          # centroid as DiceEvaluator._centroid (exact integer sums)
+            cnt = int(rows.sum())
+            cen = (float("nan"), float("nan")) if cnt == 0 else (float((rows * torch.arange(m.shape[0])).sum()) / cnt,
+                                                                  float((cols * torch.arange(m.shape[1])).sum()) / cnt)
+            anns.append(dict(bbox=boxes[k], category_id=int(classes[k]), mask=m, centroid=cen))
         d = dict(image=img, height=int(img.shape[1]), width=int(img.shape[2]), image_id=image_id, annotations=anns)
         if seed >= 0:
             d["seed"] = seed

@@ -182,8 +182,10 @@ class DiceEvaluator:
             while len(self._gt_cache) >= self.GT_CACHE_IMAGES:
                 self._gt_cache.pop(next(iter(self._gt_cache)))
             anns = record["annotations"]
-            cens = [self._centroid(a["mask"]) for a in anns]
-            dm = torch.stack([a["mask"] for a in anns]).to(dev, non_blocking=True) if anns else None      # one upload per image
+            cens = [a["centroid"] if "centroid" in a else self._centroid(a["mask"]) for a in anns]
+            dm = record.get("device_masks")              # a streaming loader uploads the masks with the image (pinned, side stream)
+            if dm is None or dm.device != torch.device(dev):
+                dm = torch.stack([a["mask"] for a in anns]).to(dev, non_blocking=True) if anns else None      # one upload per image
             self._gt_cache[key] = [(a["category_id"], dm[k], cens[k]) for k, a in enumerate(anns)]
         return self._gt_cache[key]
 
