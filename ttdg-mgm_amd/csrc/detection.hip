@@ -738,11 +738,16 @@ __global__ __launch_bounds__(64 * RA_WAVES) void roi_align_sep_kernel(ttdg_fpn_t
 // instructions per CHANNEL in the patch-staging kernel, which the profile showed to be VALU-issue bound (0.87 ms for
 // 4000 ROIs).  The (64 channels x 49 bins) result block is contiguous in the (R, C, P, P) output: it is transposed through
 // LDS and written coalesced.
-#define RN_CHUNK 49        /* bins staged per output flush (P = 7: all of them; P = 14: four flushes) */
+/* bins staged per output flush: template parameter RN_CH of roi_align_nhwc_kernel (P = 7: all 49 of them, or 25; P = 14: four / eight flushes) */
 
+// RN_CH: bins staged per output flush.  49 = the whole 7 x 7 block (one fully coalesced flush per 64 channels, 51 KB of LDS per
+// workgroup: 3 workgroups per CU); 25 halves the tile (26 KB: 6 workgroups per CU - the kernel waits on L2 round trips, so
+// occupancy is throughput) at the price of two 100-byte runs per channel instead of one 196-byte run.
+template <int RN_CH>
 __global__ __launch_bounds__(256) void roi_align_nhwc_kernel(ttdg_fpn_t fp, ttdg_levels_t lv, const float* __restrict__ rois, int R, int P,
                                                              float canon_size, int canon_level, int min_level, float* __restrict__ out,
                                                              int g_roi_xcd_chunks) {
+  constexpr int RN_CHUNK = RN_CH;
   __shared__ RaAxis s_y, s_x;
   __shared__ float s_tile[4][64 * (RN_CHUNK + 1)];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -866,6 +871,7 @@ extern "C" int ttdg_nchw_to_nhwc(const float* src, float* dst, int B, int C, int
   return ttdg_launch_status("nchw_to_nhwc");
 }
 
+static int g_roi_nhwc_chunk = 49;   // 49 / 25 bins per output flush (ttdg_debug_set_roi_align_sliced(mode | 32) selects 25)
 static int g_roi_nhwc_xcd = 0;      // 1 = XCD x owns a contiguous eighth of the ROI list, 0 = ROI r on workgroup r (default: measured 427 vs 437 us per call,
                                     // profiles/r03_roi_align_ab.txt - the pooler is not bound by fabric traffic); ttdg_debug_set_roi_align_sliced(mode | 16) selects 1
 extern "C" int ttdg_roi_align_multilevel_nhwc(ttdg_fpn_t fp, ttdg_levels_t lv, const float* rois, int R, int P, float canonical_size,
@@ -874,8 +880,12 @@ extern "C" int ttdg_roi_align_multilevel_nhwc(ttdg_fpn_t fp, ttdg_levels_t lv, c
                "roi_align_multilevel_nhwc: bad arguments");
   if (R == 0) return 0;
   const int grid = g_roi_nhwc_xcd ? 8 * ((R + 7) / 8) : R;
-  hipLaunchKernelGGL(roi_align_nhwc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, fp, lv, rois, R, P, canonical_size,
-                     canonical_level, min_level, out, g_roi_nhwc_xcd);
+  if (g_roi_nhwc_chunk == 25)
+    hipLaunchKernelGGL((roi_align_nhwc_kernel<25>), dim3(grid), dim3(256), 0, (hipStream_t)stream, fp, lv, rois, R, P, canonical_size,
+                       canonical_level, min_level, out, g_roi_nhwc_xcd);
+  else
+    hipLaunchKernelGGL((roi_align_nhwc_kernel<49>), dim3(grid), dim3(256), 0, (hipStream_t)stream, fp, lv, rois, R, P, canonical_size,
+                       canonical_level, min_level, out, g_roi_nhwc_xcd);
   return ttdg_launch_status("roi_align_multilevel_nhwc");
 }
 
@@ -885,6 +895,7 @@ static int g_roi_align_mode = 2;
 // kernel gives every XCD one contiguous eighth of the ROI list instead of ROI r on workgroup r
 extern "C" int ttdg_debug_set_roi_align_sliced(int on) {
   g_roi_nhwc_xcd = (on >= 0 && (on & 16)) ? 1 : 0;
+  g_roi_nhwc_chunk = (on >= 0 && (on & 32)) ? 25 : 49;
   if (on >= 0) on &= 7;
   g_roi_align_mode = on < 0 ? 2 : (on > 2 ? 2 : on);
   g_roi_align_sliced = on != 0;

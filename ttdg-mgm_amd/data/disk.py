@@ -75,14 +75,27 @@ class _Batches(torch.utils.data.Sampler):
         return (self.hi - self.lo + self.batch - 1) // self.batch
 
 
+def _collate(items):
+    """Runs in the WORKER process: the batch's images (and ground-truth masks) are stacked there, so that the main process
+    receives one shared-memory tensor per batch and can pin / upload it with a handful of calls."""
+    out = dict(items=items, images=None, masks=None)
+    if len({tuple(d["image"].shape) for d in items}) == 1:
+        out["images"] = torch.stack([d["image"] for d in items])
+        ms = [a["mask"] for d in items for a in d["annotations"]]
+        if ms and len({tuple(m.shape) for m in ms}) == 1:
+            out["masks"] = torch.stack(ms)
+    return out
+
+
 class DiskStream:
-    """Persistent worker processes over a DiskDataset; ``epoch(lo, hi)`` iterates lists of raw dataset dicts."""
+    """Persistent worker processes over a DiskDataset; ``epoch(lo, hi)`` iterates dicts {items: raw dataset dicts, images: the
+    stacked uint8 batch or None, masks: all ground-truth masks of the batch stacked or None}."""
 
     def __init__(self, root, n, batch, workers=4, prefetch=2):
         self.sampler = _Batches(batch)
         kw = dict(persistent_workers=True, prefetch_factor=prefetch) if workers > 0 else {}
         self.loader = torch.utils.data.DataLoader(DiskDataset(root, n), batch_sampler=self.sampler, num_workers=workers,
-                                                  collate_fn=lambda items: items, **kw)
+                                                  collate_fn=_collate, **kw)
 
     def epoch(self, lo, hi):
         self.sampler.lo, self.sampler.hi = int(lo), int(hi)

@@ -78,6 +78,8 @@ def gemm_grouped(descs):
 
 
 GROUPED_GEMM = os.environ.get("TTDG_GROUPED_GEMM", "1") != "0"      # False = one launch per product (A/B)
+GROUPED_GEMM_MAX_ROWS = 512      # stacked nodes up to which the 32 x 32-tile grouped kernel is used: it is built for M ~ 120 (launch-bound
+                                 # products); at cfg-3 (M = 2048) the 64 x 64-tile kernel is twice as fast per product (84 vs 2 x 22 us)
 
 
 def linear_raw(x, W, b=None, w_col_off=0, w_ld=None, out=None):
@@ -390,7 +392,8 @@ class MatchingLossFn(torch.autograd.Function):
         sizes = [int(s) for s in sizes]
         gr = graphs(sizes)
         G, M = len(sizes), sum(sizes)
-        if GROUPED_GEMM:
+        grouped = GROUPED_GEMM and M <= GROUPED_GEMM_MAX_ROWS
+        if grouped:
             # seven projections in two launches: {Xs, Xt, q, k, U0} <- X, then {P, Q} <- {Xs, Xt}
             dev = X.device
             Xs, Xt, q, k = (torch.empty(M, DIM, device=dev, dtype=torch.float32) for _ in range(4))
@@ -418,7 +421,7 @@ class MatchingLossFn(torch.autograd.Function):
                 part = affinity_pairwise_fwd(P, Q, w2f, gr, ks)
             with _timed("sinkhorn_pairs_fwd", sizes):
                 Wds, pot = sinkhorn_pairs_fwd(part, b2, gr, sizes, tau, iters)
-        if not GROUPED_GEMM:
+        if not grouped:
             q = linear_raw(X, Wq, bq)
             k = linear_raw(X, Wk, bk)
             U0 = linear_raw(X, U)
@@ -451,7 +454,7 @@ class MatchingLossFn(torch.autograd.Function):
                 dM = sinkhorn_pairs_bwd(part, b2, pot, dWds * gloss, gr, tau, iters)
         with _timed("affinity_bwd", sizes):
             dP, dQ, dw2, db2 = affinity_pairwise_bwd(P, Q, w2f, dM, gr)
-        if GROUPED_GEMM:
+        if GROUPED_GEMM and M <= GROUPED_GEMM_MAX_ROWS:
             # eight gradient products in two launches
             dW1, dXs, dXt = torch.empty_like(W1), torch.empty_like(Xs), torch.empty_like(Xt)
             gemm_grouped([gdesc(dP, 1, HID, Xs, 1, DIM, dW1, HID, 1, HID, DIM, M),                     # dW1[:, :256] = dP^T Xs
