@@ -77,7 +77,7 @@ def parse(argv=None):
     ap.add_argument("--roi-align-mode", type=int, default=3, help="A/B: 3 = channels-last ROIPooler kernel (default), 2 = separable table kernel on NCHW, "
                                                                   "1 = direct kernel, XCD-sliced, 0 = direct, flat (round 1)")
     ap.add_argument("--roi-xcd-chunks", action="store_true", help="A/B: channels-last ROIPooler with one contiguous eighth of the ROI list per XCD instead of ROI r on workgroup r")
-    ap.add_argument("--roi-chunk25", action="store_true", help="A/B: channels-last ROIPooler staging 25 bins per flush (half the LDS, twice the workgroups per CU)")
+    ap.add_argument("--roi-chunk", type=int, default=0, help="A/B: bins the channels-last ROIPooler stages per output flush: 49 (round 2), 25 (default) or 13")
     ap.add_argument("--flat-bias-act", action="store_true", help="A/B: the round-2 flat bias_act kernel instead of the per-plane one")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch, rendezvous, sharding and the collectives of the bench without any GPU work (CPU test of --gpus N)")
@@ -528,10 +528,10 @@ def gpu_main(args, rank, world, local):
         _lib.load().ttdg_debug_set_gagm_threads(args.gagm_threads)
         _ops.ROI_ALIGN_NHWC = args.roi_align_mode == 3
         _lib.load().ttdg_debug_set_roi_align_sliced(min(args.roi_align_mode, 2))
-    if args.roi_xcd_chunks or args.flat_bias_act or args.roi_chunk25:
+    if args.roi_xcd_chunks or args.flat_bias_act or args.roi_chunk:
         from ttdg_mgm_amd import _lib
-        if args.roi_xcd_chunks or args.roi_chunk25:
-            _lib.load().ttdg_debug_set_roi_align_sliced(2 | (16 if args.roi_xcd_chunks else 0) | (32 if args.roi_chunk25 else 0))
+        if args.roi_xcd_chunks or args.roi_chunk:
+            _lib.load().ttdg_debug_set_roi_align_sliced(2 | (16 if args.roi_xcd_chunks else 0) | {0: 0, 25: 0, 49: 32, 13: 64}[args.roi_chunk])
         if args.flat_bias_act:
             _lib.load().ttdg_debug_set_bias_act_mode(0)
     if args.images:

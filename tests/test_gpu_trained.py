@@ -492,4 +492,4 @@ def test_cfg5_own_checkpoint_bf16_backbone_vs_fp32(trained):
         json.dump(dict(checkpoint=rep, f32=out["f32"], bf16=out["bf16"], relative_difference=rel, tolerance=CFG5_DICE_TOL), f, indent=1, default=str)
 
 
-CFG5_DICE_TOL = 5e-2        # tightened to the measured value + margin once recorded (profiles/r03_cfg5_precision.json)
+CFG5_DICE_TOL = 5e-3        # measured 5.1e-4 (Dice), 1.5e-3 (E), 2.0e-3 (S) relative; 22 vs 21 kept masks (profiles/r03_cfg5_precision.json)

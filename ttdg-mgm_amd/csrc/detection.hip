@@ -871,7 +871,7 @@ extern "C" int ttdg_nchw_to_nhwc(const float* src, float* dst, int B, int C, int
   return ttdg_launch_status("nchw_to_nhwc");
 }
 
-static int g_roi_nhwc_chunk = 49;   // 49 / 25 bins per output flush (ttdg_debug_set_roi_align_sliced(mode | 32) selects 25)
+static int g_roi_nhwc_chunk = 25;   // bins per output flush: 25 (default: 355 vs 421 us per call, profiles/r03_roi_align_ab.txt); ttdg_debug_set_roi_align_sliced(mode | 32) = 49, | 64 = 13
 static int g_roi_nhwc_xcd = 0;      // 1 = XCD x owns a contiguous eighth of the ROI list, 0 = ROI r on workgroup r (default: measured 427 vs 437 us per call,
                                     // profiles/r03_roi_align_ab.txt - the pooler is not bound by fabric traffic); ttdg_debug_set_roi_align_sliced(mode | 16) selects 1
 extern "C" int ttdg_roi_align_multilevel_nhwc(ttdg_fpn_t fp, ttdg_levels_t lv, const float* rois, int R, int P, float canonical_size,
@@ -880,7 +880,10 @@ extern "C" int ttdg_roi_align_multilevel_nhwc(ttdg_fpn_t fp, ttdg_levels_t lv, c
                "roi_align_multilevel_nhwc: bad arguments");
   if (R == 0) return 0;
   const int grid = g_roi_nhwc_xcd ? 8 * ((R + 7) / 8) : R;
-  if (g_roi_nhwc_chunk == 25)
+  if (g_roi_nhwc_chunk == 13)
+    hipLaunchKernelGGL((roi_align_nhwc_kernel<13>), dim3(grid), dim3(256), 0, (hipStream_t)stream, fp, lv, rois, R, P, canonical_size,
+                       canonical_level, min_level, out, g_roi_nhwc_xcd);
+  else if (g_roi_nhwc_chunk == 25)
     hipLaunchKernelGGL((roi_align_nhwc_kernel<25>), dim3(grid), dim3(256), 0, (hipStream_t)stream, fp, lv, rois, R, P, canonical_size,
                        canonical_level, min_level, out, g_roi_nhwc_xcd);
   else
@@ -895,7 +898,7 @@ static int g_roi_align_mode = 2;
 // kernel gives every XCD one contiguous eighth of the ROI list instead of ROI r on workgroup r
 extern "C" int ttdg_debug_set_roi_align_sliced(int on) {
   g_roi_nhwc_xcd = (on >= 0 && (on & 16)) ? 1 : 0;
-  g_roi_nhwc_chunk = (on >= 0 && (on & 32)) ? 25 : 49;
+  g_roi_nhwc_chunk = (on >= 0 && (on & 64)) ? 13 : ((on >= 0 && (on & 32)) ? 49 : 25);
   if (on >= 0) on &= 7;
   g_roi_align_mode = on < 0 ? 2 : (on > 2 ? 2 : on);
   g_roi_align_sliced = on != 0;
