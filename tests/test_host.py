@@ -401,5 +401,5 @@ def test_disk_stream_with_worker_processes_equals_the_source_dataset(tmp_path):
             for ia, ib in zip(ba, bb):
                 assert ia["image_id"] == ib["image_id"] and torch.equal(ia["image"], ib["image"]) and torch.equal(ia["tf_boxes"], ib["tf_boxes"])
     ds = disk.DiskStream(str(tmp_path / "stream"), 7, 2, workers=2)
-    assert [[d["image_id"] for d in batch["items"]] for batch in ds.epoch(2, 7)] == [[502, 503], [504, 505], [506]]
-    assert [[d["image_id"] for d in batch["items"]] for batch in ds.epoch(0, 2)] == [[500, 501]]
+    assert [[d["image_id"] for d in disk.expand(batch)] for batch in ds.epoch(2, 7)] == [[502, 503], [504, 505], [506]]
+    assert [[d["image_id"] for d in disk.expand(batch)] for batch in ds.epoch(0, 2)] == [[500, 501]]

@@ -28,7 +28,7 @@ def main():
     print("worker start %.2f s" % (time.perf_counter() - t0))
     for rep in range(2):
         t0 = time.perf_counter()
-        k = sum(len(b["items"]) for b in st.epoch(0, n))
+        k = sum(len(b["meta"]) for b in st.epoch(0, n))
         print("disk epoch: %d images, %.1f images/s" % (k, k / (time.perf_counter() - t0)))
     ld = data.TestLoader("lp", B, 0, 1, dev, 800, 1333, resident=False)
     ld.start_workers()
@@ -40,7 +40,7 @@ def main():
         torch.cuda.synchronize()
         print("TestLoader (pin + H2D + device resize): %d images, %.1f images/s" % (k, k / (time.perf_counter() - t0)))
     # stages of one batch
-    dicts = [b for b in st.epoch(0, B)][0]["items"]
+    dicts = disk.expand([b for b in st.epoch(0, B)][0])
     s = torch.cuda.Stream()
     for rep in range(3):
         t0 = time.perf_counter()

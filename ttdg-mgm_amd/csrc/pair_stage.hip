@@ -24,7 +24,7 @@
 #include "sinkhorn_device.h"
 
 #define PS_T 64          /* nodes per graph on this path */
-#define PS_BK 32
+#define PS_BK 64         /* hidden units per slab */
 #define PS_LDK (PS_BK + 4)
 #define PS_LDM (PS_T + 1)
 #define PS_RW 16         /* rows per lane: 4 wavefronts x 16 */
@@ -150,9 +150,9 @@ __global__ __launch_bounds__(256) void pair_stage_fwd_kernel(const float* __rest
                                                              float* __restrict__ Wds, float* __restrict__ pot, int cmax,
                                                              unsigned long long* __restrict__ prof) {
   const unsigned long long t_begin = prof ? __builtin_amdgcn_s_memtime() : 0ull;
-  __shared__ __attribute__((aligned(16))) float Ps[PS_T][PS_LDK];
-  __shared__ __attribute__((aligned(16))) float Qs[PS_T][PS_LDK];
-  __shared__ __attribute__((aligned(16))) float Ws[PS_BK];
+  __shared__ __attribute__((aligned(16))) float Ps[2][PS_T][PS_LDK];
+  __shared__ __attribute__((aligned(16))) float Qs[2][PS_T][PS_LDK];
+  __shared__ __attribute__((aligned(16))) float Ws[2][PS_BK];
   __shared__ float Arow[PS_T], Brow[PS_T];
   __shared__ float mat[PS_T * PS_LDM];
   __shared__ float s_part[2][PS_WAVES * PS_T];
@@ -168,52 +168,59 @@ __global__ __launch_bounds__(256) void pair_stage_fwd_kernel(const float* __rest
   const int ta = (na + 15) >> 4, tb = (nb + 15) >> 4;     // 16-row sub-tiles that hold anything
 
   // ---- phase 1: the affinity block ----
-  // Register double buffer: the next 32-deep slab of P / Q rows is requested from L2 before the current one is consumed, so
-  // the memory round trip hides behind the VALU loop; the loop body is instantiated per (ta, tb) - no guards inside.
+  // 64-deep slabs, double buffered in LDS AND in registers: slab s + 1 is requested from L2 before slab s is consumed and
+  // stored into the other LDS buffer after it - one barrier per slab, the memory round trip hidden behind ~900 VALU
+  // instructions; the loop body is instantiated per (ta, tb): no guards inside.
   float acc[4][4];
 #pragma unroll
   for (int x = 0; x < 4; ++x)
 #pragma unroll
     for (int y = 0; y < 4; ++y) acc[x][y] = 0.f;
-  float pa[2] = {0.f, 0.f}, qa[2] = {0.f, 0.f};
-  const int lrow = tid >> 3, lk = (tid & 7) * 4;
-  float4 pv[2], qv[2], wv;
+  float pa[4] = {0.f, 0.f, 0.f, 0.f}, qa[4] = {0.f, 0.f, 0.f, 0.f};
+  const int lrow = tid >> 4, lk = (tid & 15) * 4;         // staging map: 16 lanes x float4 cover one 64-wide row, 16 rows per pass
+  float4 pv[4], qv[4], wv;
   auto request = [&](int k0) {
     wv = *reinterpret_cast<const float4*>(w2 + k0 + lk);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int row = lrow + 32 * h;
+    for (int h = 0; h < 4; ++h) {
+      const int row = lrow + 16 * h;
       pv[h] = row < na ? *reinterpret_cast<const float4*>(P + (size_t)(i0 + row) * H + k0 + lk) : make_float4(0.f, 0.f, 0.f, 0.f);
       qv[h] = row < nb ? *reinterpret_cast<const float4*>(Q + (size_t)(j0 + row) * H + k0 + lk) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  request(0);
-  const int shape = (ta - 1) * 4 + (tb - 1);
-  for (int k0 = 0; k0 < H; k0 += PS_BK) {
+  auto deposit = [&](int buf) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int row = lrow + 32 * h;
-      *reinterpret_cast<float4*>(&Ps[row][lk]) = pv[h];
-      *reinterpret_cast<float4*>(&Qs[row][lk]) = qv[h];
+    for (int h = 0; h < 4; ++h) {
+      const int row = lrow + 16 * h;
+      *reinterpret_cast<float4*>(&Ps[buf][row][lk]) = pv[h];
+      *reinterpret_cast<float4*>(&Qs[buf][row][lk]) = qv[h];
       pa[h] = fmaf(wv.x, pv[h].x, fmaf(wv.y, pv[h].y, fmaf(wv.z, pv[h].z, fmaf(wv.w, pv[h].w, pa[h]))));
       qa[h] = fmaf(wv.x, qv[h].x, fmaf(wv.y, qv[h].y, fmaf(wv.z, qv[h].z, fmaf(wv.w, qv[h].w, qa[h]))));
     }
-    if (lrow == 0) *reinterpret_cast<float4*>(&Ws[lk]) = make_float4(0.5f * wv.x, 0.5f * wv.y, 0.5f * wv.z, 0.5f * wv.w);
-    __syncthreads();
-    if (k0 + PS_BK < H) request(k0 + PS_BK);
+    if (lrow == 0) *reinterpret_cast<float4*>(&Ws[buf][lk]) = make_float4(0.5f * wv.x, 0.5f * wv.y, 0.5f * wv.z, 0.5f * wv.w);
+  };
+  request(0);
+  deposit(0);
+  __syncthreads();
+  const int shape = (ta - 1) * 4 + (tb - 1);
+  const int nslab = H / PS_BK;
+  for (int sl = 0; sl < nslab; ++sl) {
+    const int cur = sl & 1;
+    if (sl + 1 < nslab) request((sl + 1) * PS_BK);
     switch (shape) {
-#define PS_CASE(A, B) case (A - 1) * 4 + (B - 1): ps_affinity_slab<A, B>(Ps, Qs, Ws, tx, ty, acc); break;
+#define PS_CASE(A, B) case (A - 1) * 4 + (B - 1): ps_affinity_slab<A, B>(Ps[cur], Qs[cur], Ws[cur], tx, ty, acc); break;
       PS_CASE(1, 1) PS_CASE(1, 2) PS_CASE(1, 3) PS_CASE(1, 4) PS_CASE(2, 1) PS_CASE(2, 2) PS_CASE(2, 3) PS_CASE(2, 4)
       PS_CASE(3, 1) PS_CASE(3, 2) PS_CASE(3, 3) PS_CASE(3, 4) PS_CASE(4, 1) PS_CASE(4, 2) PS_CASE(4, 3) PS_CASE(4, 4)
 #undef PS_CASE
     }
+    if (sl + 1 < nslab) deposit(cur ^ 1);
     __syncthreads();
   }
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < 4; ++h) {
 #pragma unroll
-    for (int o = 4; o > 0; o >>= 1) { pa[h] += __shfl_xor(pa[h], o, 64); qa[h] += __shfl_xor(qa[h], o, 64); }
-    if ((tid & 7) == 0) { Arow[lrow + 32 * h] = 0.5f * pa[h]; Brow[lrow + 32 * h] = 0.5f * qa[h]; }
+    for (int o = 8; o > 0; o >>= 1) { pa[h] += __shfl_xor(pa[h], o, 64); qa[h] += __shfl_xor(qa[h], o, 64); }
+    if ((tid & 15) == 0) { Arow[lrow + 16 * h] = 0.5f * pa[h]; Brow[lrow + 16 * h] = 0.5f * qa[h]; }
   }
   __syncthreads();
   const float bias = b2 ? *b2 : 0.f, scale = TTDG_LOG2E / tau;
@@ -310,7 +317,7 @@ extern "C" int ttdg_pair_stage_fwd(const float* P, const float* Q, const float* 
                                    float tau, int iters, float* aff, float* Wds, float* pot, ttdg_stream_t stream) {
   TTDG_REQUIRE(P && Q && w2 && Wds && tau > 0.f, "pair_stage_fwd: bad arguments");
   TTDG_REQUIRE(iters >= 0 && iters <= SK_MAXK, "pair_stage_fwd: iters out of range");
-  TTDG_REQUIRE(H > 0 && H % PS_BK == 0, "pair_stage_fwd: H must be a multiple of 32");
+  TTDG_REQUIRE(H > 0 && H % PS_BK == 0, "pair_stage_fwd: H must be a multiple of 64");
   if (int e = ttdg_validate_graphs(gr)) return e;
   int cmax = 0;
   for (int g = 0; g < gr.G; ++g) cmax = gr.off[g + 1] - gr.off[g] > cmax ? gr.off[g + 1] - gr.off[g] : cmax;

@@ -76,20 +76,41 @@ class _Batches(torch.utils.data.Sampler):
 
 
 def _collate(items):
-    """Runs in the WORKER process: the batch's images (and ground-truth masks) are stacked there, so that the main process
-    receives one shared-memory tensor per batch and can pin / upload it with a handful of calls."""
-    out = dict(items=items, images=None, masks=None)
-    if len({tuple(d["image"].shape) for d in items}) == 1:
-        out["images"] = torch.stack([d["image"] for d in items])
-        ms = [a["mask"] for d in items for a in d["annotations"]]
-        if ms and len({tuple(m.shape) for m in ms}) == 1:
-            out["masks"] = torch.stack(ms)
+    """Runs in the WORKER process.  A batch crosses the process boundary as TWO shared-memory tensors - the stacked uint8 images
+    and the stacked ground-truth masks - plus plain Python metadata: every tensor costs the receiving process a connection to the
+    worker's resource sharer (~1 ms with its authentication handshake; 14 tensors per batch were 15 ms), Python numbers cost
+    nothing.  ``expand`` rebuilds the per-image dicts as views.  Images of different sizes travel as they are."""
+    if len({tuple(d["image"].shape) for d in items}) != 1 or len({tuple(a["mask"].shape) for d in items for a in d["annotations"]}) > 1:
+        return dict(items=items, images=None, masks=None)
+    ms = [a["mask"] for d in items for a in d["annotations"]]
+    meta = [dict(height=d["height"], width=d["width"], image_id=d["image_id"], seed=d.get("seed"),
+                 anns=[(a["bbox"].tolist(), a["category_id"], a.get("centroid")) for a in d["annotations"]]) for d in items]
+    return dict(items=None, images=torch.stack([d["image"] for d in items]), masks=torch.stack(ms) if ms else None, meta=meta)
+
+
+def expand(batch):
+    """Main process: the list of dataset dicts of a collated batch (tensors are views of the two stacked ones)."""
+    if batch["items"] is not None:
+        return batch["items"]
+    out, k = [], 0
+    for i, m in enumerate(batch["meta"]):
+        anns = []
+        for box, cat, cen in m["anns"]:
+            a = dict(bbox=torch.tensor(box, dtype=torch.float32), category_id=cat, mask=batch["masks"][k])
+            if cen is not None:
+                a["centroid"] = cen
+            anns.append(a)
+            k += 1
+        d = dict(image=batch["images"][i], height=m["height"], width=m["width"], image_id=m["image_id"], annotations=anns)
+        if m["seed"] is not None:
+            d["seed"] = m["seed"]
+        out.append(d)
     return out
 
 
 class DiskStream:
-    """Persistent worker processes over a DiskDataset; ``epoch(lo, hi)`` iterates dicts {items: raw dataset dicts, images: the
-    stacked uint8 batch or None, masks: all ground-truth masks of the batch stacked or None}."""
+    """Persistent worker processes over a DiskDataset; ``epoch(lo, hi)`` iterates collated batches (``_collate``): pass them to
+    ``expand`` for the list of dataset dicts; ``images`` / ``masks`` are the stacked tensors (None for ragged batches)."""
 
     def __init__(self, root, n, batch, workers=4, prefetch=2):
         self.sampler = _Batches(batch)
