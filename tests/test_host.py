@@ -401,5 +401,29 @@ def test_disk_stream_with_worker_processes_equals_the_source_dataset(tmp_path):
             for ia, ib in zip(ba, bb):
                 assert ia["image_id"] == ib["image_id"] and torch.equal(ia["image"], ib["image"]) and torch.equal(ia["tf_boxes"], ib["tf_boxes"])
     ds = disk.DiskStream(str(tmp_path / "stream"), 7, 2, workers=2)
-    assert [[d["image_id"] for d in disk.expand(batch)] for batch in ds.epoch(2, 7)] == [[502, 503], [504, 505], [506]]
-    assert [[d["image_id"] for d in disk.expand(batch)] for batch in ds.epoch(0, 2)] == [[500, 501]]
+    assert [[d["image_id"] for d in disk.expand(batch, ds.ring)] for batch in ds.epoch(2, 7)] == [[502, 503], [504, 505], [506]]
+    assert [[d["image_id"] for d in disk.expand(batch, ds.ring)] for batch in ds.epoch(0, 2)] == [[500, 501]]
+
+
+def test_disk_stream_ring_slots(tmp_path):
+    """The shared ring (data/disk.py::_Ring; page-locking switched off: no GPU here): worker processes write every batch into
+    its slot, the main process sees exactly the dataset's pixels and masks as views of the ring, slot after slot, over more
+    batches than there are slots (reuse), and on a ragged last batch."""
+    from ttdg_mgm_amd.data import disk
+    data.register_synthetic("ring_src", 23, size=32, id_offset=700)
+    root = str(tmp_path / "ring")
+    disk.prerender("ring_src", root)
+    src = data.dataset_dicts("ring_src")
+    ds = disk.DiskStream(root, 23, 2, workers=2, prefetch=1, ring=True, register=False)
+    assert ds.ring is not None and ds.ring.slots == 6 and not ds.ring.pinned
+    for _ in range(2):
+        seen = 0
+        for batch in ds.epoch(0, 23):
+            assert batch["slot"] is not None and batch["images"] is None            # nothing but metadata crossed the process boundary
+            for d in disk.expand(batch, ds.ring):
+                ref = src[d["image_id"] - 700]
+                assert torch.equal(d["image"], ref["image"]) and d["seed"] == ref["seed"]
+                for a, b in zip(d["annotations"], ref["annotations"]):
+                    assert torch.equal(a["mask"], b["mask"]) and torch.equal(a["bbox"], b["bbox"]) and a["category_id"] == b["category_id"]
+                seen += 1
+        assert seen == 23

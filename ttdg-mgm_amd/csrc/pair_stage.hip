@@ -50,16 +50,21 @@ __device__ __forceinline__ void ps_pair_of(int idx, int& a, int& b) {
 // One column sweep.  kExact: two-pass (column maxima through LDS first); otherwise the previous potential g is the stabiliser
 // and the return value says whether some column sum left the sane range - every wavefront sees the same sums, so all of them
 // take the exact path together.
-template <bool kExact>
+template <bool kExact, int NR>
 __device__ __forceinline__ bool ps_col_sweep(const float (&L)[PS_RW], const float (&f)[PS_RW], float g, float td0, int mult, int r, int c,
                                              int wave, int lane, float (&s_part)[2][PS_WAVES * PS_T], int& buf, float& gn) {
+  // rows beyond r (and lanes beyond c) carry L = -inf and f = 0: their terms are exp2(-inf) = 0 and max(-inf), so the loops
+  // below need no guards - NR independent transcendentals and a tree sum instead of a dependent add / select chain
   float sh;
   if (kExact) {
-    float mx = -INFINITY;
+    float t[NR];
 #pragma unroll
-    for (int i = 0; i < PS_RW; ++i)
-      if (wave + PS_WAVES * i < r) mx = fmaxf(mx, L[i] - f[i]);
-    s_part[buf][wave * PS_T + lane] = mx;
+    for (int i = 0; i < NR; ++i) t[i] = L[i] - f[i];
+#pragma unroll
+    for (int st = 1; st < NR; st <<= 1)
+#pragma unroll
+      for (int i = 0; i + st < NR; i += 2 * st) t[i] = fmaxf(t[i], t[i + st]);
+    s_part[buf][wave * PS_T + lane] = t[0];
     ps_barrier();
     sh = td0;
 #pragma unroll
@@ -69,15 +74,16 @@ __device__ __forceinline__ bool ps_col_sweep(const float (&L)[PS_RW], const floa
   } else {
     sh = g;
   }
-  float acc = 0.f;
+  float e[NR];
 #pragma unroll
-  for (int i = 0; i < PS_RW; ++i)
-    if (wave + PS_WAVES * i < r) acc += fast_exp2(L[i] - f[i] - sh);
-  s_part[buf][wave * PS_T + lane] = acc;
+  for (int i = 0; i < NR; ++i) e[i] = fast_exp2(L[i] - f[i] - sh);
+#pragma unroll
+  for (int st = 1; st < NR; st <<= 1)
+#pragma unroll
+    for (int i = 0; i + st < NR; i += 2 * st) e[i] += e[i + st];
+  s_part[buf][wave * PS_T + lane] = e[0];
   ps_barrier();
-  float s = 0.f;
-#pragma unroll
-  for (int w = 0; w < PS_WAVES; ++w) s += s_part[buf][w * PS_T + lane];
+  float s = (s_part[buf][0 * PS_T + lane] + s_part[buf][1 * PS_T + lane]) + (s_part[buf][2 * PS_T + lane] + s_part[buf][3 * PS_T + lane]);
   buf ^= 1;
   if (mult > 0) s += (float)mult * fast_exp2(td0 - sh);
   const bool live = lane < c;
@@ -85,35 +91,76 @@ __device__ __forceinline__ bool ps_col_sweep(const float (&L)[PS_RW], const floa
   return !kExact && __ballot(live && !ps_sane(s)) != 0ull;
 }
 
+template <int NR>
+__device__ __forceinline__ float ps_col_step(const float (&L)[PS_RW], const float (&f)[PS_RW], float g, float td0, int mult, int r, int c, int wave,
+                                             int lane, float (&s_part)[2][PS_WAVES * PS_T], int& buf, bool first) {
+  float gn;
+  bool exact = first;
+  if (!exact) exact = ps_col_sweep<false, NR>(L, f, g, td0, mult, r, c, wave, lane, s_part, buf, gn);
+  if (exact) ps_col_sweep<true, NR>(L, f, g, td0, mult, r, c, wave, lane, s_part, buf, gn);
+  return gn;
+}
+
 // One 32-deep slab of the affinity block: TA x TB live 16 x 16 sub-tiles per thread tile (compile-time: no guards, the
 // ds_read_b128 of a k-step are all in flight before the first fma).
 template <int TA, int TB>
-__device__ __forceinline__ void ps_affinity_slab(const float (&Ps)[PS_T][PS_LDK], const float (&Qs)[PS_T][PS_LDK], const float (&Ws)[PS_BK], int tx,
-                                                 int ty, float (&acc)[4][4]) {
-#pragma unroll 2
-  for (int kk = 0; kk < PS_BK; kk += 4) {
-    ps_f32x2 p[TA][2], q[TB][2];
+struct PsOperands {
+  float4 p[TA][2], q[TB][2], w[2];
+};
+
+template <int TA, int TB>
+__device__ __forceinline__ void ps_slab_load(PsOperands<TA, TB>& o, const float (&Ps)[PS_T][PS_LDK], const float (&Qs)[PS_T][PS_LDK],
+                                             const float (&Ws)[PS_BK], int tx, int ty, int kk) {
 #pragma unroll
-    for (int x = 0; x < TA; ++x) {
-      const float4 v = *reinterpret_cast<const float4*>(&Ps[ty + 16 * x][kk]);
-      p[x][0] = (ps_f32x2){v.x, v.y}; p[x][1] = (ps_f32x2){v.z, v.w};
-    }
+  for (int x = 0; x < TA; ++x) {
+    o.p[x][0] = *reinterpret_cast<const float4*>(&Ps[ty + 16 * x][kk]);
+    o.p[x][1] = *reinterpret_cast<const float4*>(&Ps[ty + 16 * x][kk + 4]);
+  }
 #pragma unroll
-    for (int y = 0; y < TB; ++y) {
-      const float4 v = *reinterpret_cast<const float4*>(&Qs[tx + 16 * y][kk]);
-      q[y][0] = (ps_f32x2){v.x, v.y}; q[y][1] = (ps_f32x2){v.z, v.w};
-    }
-    const float4 w = *reinterpret_cast<const float4*>(&Ws[kk]);
+  for (int y = 0; y < TB; ++y) {
+    o.q[y][0] = *reinterpret_cast<const float4*>(&Qs[tx + 16 * y][kk]);
+    o.q[y][1] = *reinterpret_cast<const float4*>(&Qs[tx + 16 * y][kk + 4]);
+  }
+  o.w[0] = *reinterpret_cast<const float4*>(&Ws[kk]);
+  o.w[1] = *reinterpret_cast<const float4*>(&Ws[kk + 4]);
+}
+
+template <int TA, int TB>
+__device__ __forceinline__ void ps_slab_fma(const PsOperands<TA, TB>& o, float (&acc)[4][4]) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int x = 0; x < TA; ++x)
 #pragma unroll
       for (int y = 0; y < TB; ++y) {
-        const ps_f32x2 x0 = p[x][0] + q[y][0], x1 = p[x][1] + q[y][1];
-        acc[x][y] = ps_fma_abs(w.x, x0.x, acc[x][y]);
-        acc[x][y] = ps_fma_abs(w.y, x0.y, acc[x][y]);
-        acc[x][y] = ps_fma_abs(w.z, x1.x, acc[x][y]);
-        acc[x][y] = ps_fma_abs(w.w, x1.y, acc[x][y]);
+        const ps_f32x2 x0 = (ps_f32x2){o.p[x][h].x, o.p[x][h].y} + (ps_f32x2){o.q[y][h].x, o.q[y][h].y};
+        const ps_f32x2 x1 = (ps_f32x2){o.p[x][h].z, o.p[x][h].w} + (ps_f32x2){o.q[y][h].z, o.q[y][h].w};
+        acc[x][y] = ps_fma_abs(o.w[h].x, x0.x, acc[x][y]);
+        acc[x][y] = ps_fma_abs(o.w[h].y, x0.y, acc[x][y]);
+        acc[x][y] = ps_fma_abs(o.w[h].z, x1.x, acc[x][y]);
+        acc[x][y] = ps_fma_abs(o.w[h].w, x1.y, acc[x][y]);
       }
+}
+
+// One 64-deep slab of the affinity block: TA x TB live 16 x 16 sub-tiles per thread tile (compile-time: no guards).  With one
+// wavefront per SIMD nothing hides an LDS round trip, so the reads are software-pipelined by hand: the operands of the NEXT
+// eight hidden units are requested (two register sets, ping-pong) before the 12 (TA TB) VALU instructions of the current
+// eight are issued; __builtin_amdgcn_sched_barrier keeps the compiler from sinking the requests behind the arithmetic.
+template <int TA, int TB>
+__device__ __forceinline__ void ps_affinity_slab(const float (&Ps)[PS_T][PS_LDK], const float (&Qs)[PS_T][PS_LDK], const float (&Ws)[PS_BK], int tx,
+                                                 int ty, float (&acc)[4][4]) {
+  PsOperands<TA, TB> a, b;
+  ps_slab_load<TA, TB>(a, Ps, Qs, Ws, tx, ty, 0);
+#pragma unroll
+  for (int kk = 0; kk < PS_BK; kk += 16) {
+    ps_slab_load<TA, TB>(b, Ps, Qs, Ws, tx, ty, kk + 8);
+    __builtin_amdgcn_sched_barrier(0);
+    ps_slab_fma<TA, TB>(a, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kk + 16 < PS_BK) ps_slab_load<TA, TB>(a, Ps, Qs, Ws, tx, ty, kk + 16);
+    __builtin_amdgcn_sched_barrier(0);
+    ps_slab_fma<TA, TB>(b, acc);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -273,11 +320,13 @@ __global__ __launch_bounds__(256) void pair_stage_fwd_kernel(const float* __rest
       }
     } else {
       const float td0 = (mult > 0) ? SK_DUMMY - fd : -INFINITY;
-      float gn;
-      bool exact = it < 2;
-      if (!exact) exact = ps_col_sweep<false>(L, f, g, td0, mult, r, c, wave, lane, s_part, buf, gn);
-      if (exact) ps_col_sweep<true>(L, f, g, td0, mult, r, c, wave, lane, s_part, buf, gn);
-      g = gn;
+      // NR is chosen from r alone (not from this wavefront's row count): all four wavefronts take the same instantiation and
+      // meet at the same barriers
+      const int nrm = (r + PS_WAVES - 1) / PS_WAVES;
+      if (nrm <= 4) g = ps_col_step<4>(L, f, g, td0, mult, r, c, wave, lane, s_part, buf, it < 2);
+      else if (nrm <= 8) g = ps_col_step<8>(L, f, g, td0, mult, r, c, wave, lane, s_part, buf, it < 2);
+      else if (nrm <= 12) g = ps_col_step<12>(L, f, g, td0, mult, r, c, wave, lane, s_part, buf, it < 2);
+      else g = ps_col_step<16>(L, f, g, td0, mult, r, c, wave, lane, s_part, buf, it < 2);
       if (wave == 0 && lane < c) plog[it * potld + lane] = g;
     }
   }

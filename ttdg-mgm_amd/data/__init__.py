@@ -114,7 +114,7 @@ class TestLoader:
         if not resident and _REGISTRY[name]["kind"] == "disk":
             from . import disk
             spec = _REGISTRY[name]
-            self._disk = disk.DiskStream(spec["root"], spec["n"], batch, workers=spec["workers"], prefetch=self.prefetch)
+            self._disk = disk.DiskStream(spec["root"], spec["n"], batch, workers=spec["workers"], prefetch=self.prefetch, ring=cuda)
         if resident:
             self._dicts = dataset_dicts(name, self.start, self.stop)
             self.items = [map_for_test(d, min_size, max_size) for d in self._dicts]
@@ -159,9 +159,13 @@ class TestLoader:
 
     def _load_batch(self, lo, hi, stream, dicts=None):
         stacked = masks = None
+        slot = None
         if isinstance(dicts, dict):                       # a batch collated by a disk-stream worker
             from . import disk
-            stacked, masks, dicts = dicts["images"], dicts["masks"], disk.expand(dicts)
+            slot = dicts.get("slot")
+            items_ = disk.expand(dicts, self._disk.ring)
+            stacked, masks, dicts = dicts["images"], dicts["masks"], items_
+        direct = slot is not None and self._disk.ring is not None and self._disk.ring.pinned      # the slot is page-locked: DMA straight from it
         if dicts is None:
             dicts = dataset_dicts(self.name, lo, hi)
         items = [map_for_test(d, self.min_size, self.max_size, resize=not self.device_resize) for d in dicts]
@@ -172,7 +176,8 @@ class TestLoader:
                     from .. import ops
                     same = len({(tuple(it["image"].shape), it["resize_to"]) for it in items}) == 1
                     if same:      # one pinned upload + one resize launch for the batch
-                        raw = self._upload(stacked if stacked is not None else torch.stack([it["image"] for it in items]), "img")
+                        raw = stacked.to(self.device, non_blocking=True) if direct else \
+                            self._upload(stacked if stacked is not None else torch.stack([it["image"] for it in items]), "img")
                         out = ops.resize_u8(raw, *items[0]["resize_to"])
                         for k, it in enumerate(items):
                             it["image"] = out[k]
@@ -185,7 +190,7 @@ class TestLoader:
                 # the evaluator's inputs travel the same way: ground-truth masks pinned and uploaded on the side stream, so that
                 # the Dice pass never issues a pageable (= synchronous) copy on the compute stream
                 if masks is not None:                    # one upload for the ground truth of the whole batch
-                    dm, k = self._upload(masks, "gt"), 0
+                    dm, k = (masks.to(self.device, non_blocking=True) if direct else self._upload(masks, "gt")), 0
                     for it in items:
                         n = len(it["dataset_dict"]["annotations"])
                         if n:
@@ -198,6 +203,8 @@ class TestLoader:
                             it["dataset_dict"]["device_masks"] = torch.stack([a["mask"] for a in anns]).pin_memory().to(self.device, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(stream)
+                if slot is not None and self._disk.ring is not None:
+                    self._disk.ring.events[slot] = ev          # the slot may be rewritten once its uploads have completed
         return items, ev
 
     def __iter__(self):

@@ -61,37 +61,100 @@ class DiskDataset(torch.utils.data.Dataset):
         return d
 
 
-class _Batches(torch.utils.data.Sampler):
-    """Batch sampler whose index range is set per pass (the workers are persistent: they outlive a pass)."""
+class _Ring:
+    """A ring of batch slots in SHARED memory, page-locked for the GPU: worker processes write a decoded batch straight into
+    its slot, the main process starts the DMA from there - no per-batch shared-memory segment, no staging memcpy (measured on
+    the GPU box: 2.4 ms memcpy + 2.1 ms upload call per 3 MB tensor through a staging buffer; ~10 ms per batch of host time).
+    Allocated before the workers are forked, so they inherit the mapping.  Slot s is handed to a worker again only after the
+    copy that read it has completed (``wait``)."""
 
-    def __init__(self, batch):
-        self.batch, self.lo, self.hi = batch, 0, 0
+    def __init__(self, slots, batch, image_shape, masks_per_image, mask_shape, register):
+        self.slots, self.batch, self.mpi = slots, batch, masks_per_image
+        self.images = torch.empty((slots, batch) + tuple(image_shape), dtype=torch.uint8).share_memory_()
+        self.masks = torch.empty((slots, batch * max(1, masks_per_image)) + tuple(mask_shape), dtype=torch.bool).share_memory_()
+        self.events = [None] * slots
+        self.pinned = False
+        if register and torch.cuda.is_available():
+            rt = torch.cuda.cudart()
+            ok = True
+            for t in (self.images, self.masks):
+                ok = ok and int(rt.cudaHostRegister(t.data_ptr(), t.numel() * t.element_size(), 0)) == 0
+            self.pinned = ok
+
+    def wait(self, slot):
+        if self.events[slot] is not None:
+            self.events[slot].synchronize()
+            self.events[slot] = None
+
+
+class _Batches(torch.utils.data.Sampler):
+    """Batch sampler whose index range is set per pass (the workers are persistent: they outlive a pass).  With a ring every
+    index travels as (image index, slot, position in the batch): the worker-side collate knows where to write."""
+
+    def __init__(self, batch, ring=None):
+        self.batch, self.lo, self.hi, self.ring, self.count = batch, 0, 0, ring, 0
 
     def __iter__(self):
         for s in range(self.lo, self.hi, self.batch):
-            yield list(range(s, min(s + self.batch, self.hi)))
+            idx = list(range(s, min(s + self.batch, self.hi)))
+            if self.ring is None:
+                yield idx
+            else:
+                slot = self.count % self.ring.slots
+                self.count += 1
+                self.ring.wait(slot)                 # main process: the slot's previous upload must have completed
+                yield [(i, slot, k) for k, i in enumerate(idx)]
 
     def __len__(self):
         return (self.hi - self.lo + self.batch - 1) // self.batch
 
 
+class _RingDataset(DiskDataset):
+    """DiskDataset whose items land in a ring slot (worker side)."""
+
+    def __init__(self, root, n, ring):
+        super().__init__(root, n)
+        self.ring = ring
+
+    def __getitem__(self, key):
+        i, slot, k = key
+        d = super().__getitem__(i)
+        r = self.ring
+        fits = tuple(d["image"].shape) == tuple(r.images.shape[2:]) and len(d["annotations"]) == r.mpi and \
+            all(tuple(a["mask"].shape) == tuple(r.masks.shape[2:]) for a in d["annotations"])
+        if fits:
+            r.images[slot, k].copy_(d["image"])
+            for j, a in enumerate(d["annotations"]):
+                r.masks[slot, k * r.mpi + j].copy_(a["mask"])
+        d["_ring"] = (slot, k, fits)
+        return d
+
+
 def _collate(items):
-    """Runs in the WORKER process.  A batch crosses the process boundary as TWO shared-memory tensors - the stacked uint8 images
-    and the stacked ground-truth masks - plus plain Python metadata: every tensor costs the receiving process a connection to the
-    worker's resource sharer (~1 ms with its authentication handshake; 14 tensors per batch were 15 ms), Python numbers cost
-    nothing.  ``expand`` rebuilds the per-image dicts as views.  Images of different sizes travel as they are."""
+    """Runs in the WORKER process.  A batch crosses the process boundary as plain Python metadata plus EITHER a ring slot
+    number (the pixels are already in shared page-locked memory) OR two shared-memory tensors - the stacked uint8 images and the
+    stacked ground-truth masks: every tensor costs the receiving process a connection to the worker's resource sharer (~1 ms with
+    its authentication handshake; 14 tensors per batch were 15 ms), Python numbers cost nothing.  ``expand`` rebuilds the
+    per-image dicts as views.  Images of different sizes travel as they are."""
+    ring = [d.pop("_ring", None) for d in items]
     if len({tuple(d["image"].shape) for d in items}) != 1 or len({tuple(a["mask"].shape) for d in items for a in d["annotations"]}) > 1:
-        return dict(items=items, images=None, masks=None)
+        return dict(items=items, images=None, masks=None, slot=None)
     ms = [a["mask"] for d in items for a in d["annotations"]]
     meta = [dict(height=d["height"], width=d["width"], image_id=d["image_id"], seed=d.get("seed"),
                  anns=[(a["bbox"].tolist(), a["category_id"], a.get("centroid")) for a in d["annotations"]]) for d in items]
-    return dict(items=None, images=torch.stack([d["image"] for d in items]), masks=torch.stack(ms) if ms else None, meta=meta)
+    if all(x is not None and x[2] for x in ring):
+        return dict(items=None, images=None, masks=None, meta=meta, slot=ring[0][0])
+    return dict(items=None, images=torch.stack([d["image"] for d in items]), masks=torch.stack(ms) if ms else None, meta=meta, slot=None)
 
 
-def expand(batch):
-    """Main process: the list of dataset dicts of a collated batch (tensors are views of the two stacked ones)."""
+def expand(batch, ring=None):
+    """Main process: the list of dataset dicts of a collated batch (tensors are views of the two stacked ones / of the ring slot)."""
     if batch["items"] is not None:
         return batch["items"]
+    if batch.get("slot") is not None and batch["images"] is None:
+        nb = len(batch["meta"])
+        batch["images"] = ring.images[batch["slot"], :nb]
+        batch["masks"] = ring.masks[batch["slot"], :nb * ring.mpi] if ring.mpi else None
     out, k = [], 0
     for i, m in enumerate(batch["meta"]):
         anns = []
@@ -110,13 +173,19 @@ def expand(batch):
 
 class DiskStream:
     """Persistent worker processes over a DiskDataset; ``epoch(lo, hi)`` iterates collated batches (``_collate``): pass them to
-    ``expand`` for the list of dataset dicts; ``images`` / ``masks`` are the stacked tensors (None for ragged batches)."""
+    ``expand(batch, stream.ring)`` for the list of dataset dicts; ``images`` / ``masks`` are then the stacked tensors (None for
+    ragged batches).  ``ring=True``: batches of the dataset's common shape travel through a shared page-locked ring."""
 
-    def __init__(self, root, n, batch, workers=4, prefetch=2):
-        self.sampler = _Batches(batch)
+    def __init__(self, root, n, batch, workers=4, prefetch=2, ring=False, register=True):
+        self.ring = None
+        if ring and workers > 0 and n > 0:
+            d0 = DiskDataset(root, n)[0]
+            if d0["annotations"]:
+                self.ring = _Ring(workers * prefetch + 4, batch, d0["image"].shape, len(d0["annotations"]), d0["annotations"][0]["mask"].shape, register)
+        self.sampler = _Batches(batch, self.ring)
         kw = dict(persistent_workers=True, prefetch_factor=prefetch) if workers > 0 else {}
-        self.loader = torch.utils.data.DataLoader(DiskDataset(root, n), batch_sampler=self.sampler, num_workers=workers,
-                                                  collate_fn=_collate, **kw)
+        ds = _RingDataset(root, n, self.ring) if self.ring is not None else DiskDataset(root, n)
+        self.loader = torch.utils.data.DataLoader(ds, batch_sampler=self.sampler, num_workers=workers, collate_fn=_collate, **kw)
 
     def epoch(self, lo, hi):
         self.sampler.lo, self.sampler.hi = int(lo), int(hi)
