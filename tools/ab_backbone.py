@@ -57,6 +57,48 @@ def main():
             print("%-34s %-5s %8.2f ms   (3 warm-up steps took %.1f s; cudnn.benchmark %s)" % (label, mode, (time.perf_counter() - t0) / reps * 1e3, tw,
                   torch.backends.cudnn.benchmark), flush=True)
 
+    if only == "miopen_fused":
+        # experiment: MIOpen's own conv + bias (+ residual) + ReLU fusion plans (aten::miopen_convolution_relu / _add_relu) for the
+        # no-grad forward, instead of convolution + our one-pass epilogue
+        import torch.nn.functional as F
+
+        def folded(c):
+            scale, shift = c.norm.folded()
+            return (c.weight * scale).detach(), shift
+
+        def conv_relu(c, x):
+            w, b = folded(c)
+            return torch.miopen_convolution_relu(x, w, b, c.stride, c.padding, (1, 1), 1)
+
+        def block(self, x):
+            y = conv_relu(self.conv1, x)
+            y = conv_relu(self.conv2, y)
+            w3, b3 = folded(self.conv3)
+            if self.shortcut is not None:
+                ws, bs = folded(self.shortcut)
+                z = F.conv2d(x, ws, bs, self.shortcut.stride, self.shortcut.padding)
+            else:
+                z = x
+            return torch.miopen_convolution_add_relu(y, w3, z, 1.0, b3, self.conv3.stride, self.conv3.padding, (1, 1), 1)
+
+        def stem(self, x):
+            return F.max_pool2d(conv_relu(self.conv1, x), kernel_size=3, stride=2, padding=1)
+        net.eval()
+        with torch.no_grad():
+            ref = {k: v.clone() for k, v in net(x).items()}
+        bb.Bottleneck.forward, bb.Stem.forward = block, stem
+        with torch.no_grad():
+            got = net(x)
+            print("max |fused - product| relative:", max(float((got[k] - ref[k]).abs().max() / ref[k].abs().max()) for k in ref))
+            for _ in range(3):
+                net(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                net(x)
+            torch.cuda.synchronize()
+        print("%-34s %-5s %8.2f ms" % ("MIOpen fusion plans (conv+bias+relu)", "eval", (time.perf_counter() - t0) / reps * 1e3), flush=True)
+        return
     if only in ("", "nchw"):
         run("NCHW + fused epilogues (product)", True, False)
         run("NCHW, plain torch epilogues", False, False)
