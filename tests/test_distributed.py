@@ -147,24 +147,25 @@ def _overlap_worker(rank, world, port, q, layout):
             net = torch.nn.Sequential(torch.nn.Linear(8, 64), torch.nn.Tanh(), torch.nn.Linear(64, 64), torch.nn.Tanh(), torch.nn.Linear(64, 256))
             unused = torch.nn.Parameter(torch.zeros(3))
             w = torch.nn.Parameter(torch.full((256,), 0.5))
-            return net, unused, w
+            sometimes = torch.nn.Parameter(torch.ones(256))        # data dependent: a gradient on steps 1 and 3 only (a late joiner,
+            return net, unused, w, sometimes                       # and a live parameter without gradient anywhere on step 2)
 
-        def step_loss(net, w, step):
+        def step_loss(net, w, sometimes, step):
             xs, labs = _graphs(100 + rank + 10 * step, layout[step % len(layout)][rank])
-            nodes = [net(x) for x in xs] if xs else None
+            nodes = [net(x) * (sometimes if step % 2 == 1 else 1.0) for x in xs] if xs else None
             all_nodes, _ = su.gather_graphs(nodes, labs if xs else None, torch.device("cpu"))
             return _toy_loss(all_nodes, w)
 
         out = {}
         for mode in ("posthoc", "overlap"):
-            net, unused, w = build()
-            summed, repl = list(net.parameters()) + [unused], [w]
+            net, unused, w, sometimes = build()
+            summed, repl = list(net.parameters()) + [unused, sometimes], [w]
             red = su.OverlappedGradReducer(summed, repl, bucket_bytes=4096) if mode == "overlap" else None     # several buckets
             grads = []
             for step in range(4):
                 for p in summed + repl:
                     p.grad = None
-                loss = step_loss(net, w, step)
+                loss = step_loss(net, w, sometimes, step)
                 if red is None:
                     loss.backward()
                     su.allreduce_grads(summed, repl, bucket_bytes=4096)
@@ -181,9 +182,12 @@ def _overlap_worker(rank, world, port, q, layout):
             if red is not None:
                 out["launched_in_backward"] = red.overlapped_launches
                 out["nbuckets"] = len(red.buckets)
+                out["late"] = red.late_joins
                 red.remove()
         same = all((a is None and b is None) or torch.equal(a, b) for ga, gb in zip(out["posthoc"], out["overlap"]) for a, b in zip(ga, gb))
-        q.put((rank, same, out["launched_in_backward"], out["nbuckets"], out["overlap"][-1][0].clone(), out["overlap"][-1][-2] is None))
+        none_pattern = [[g is None for g in step] for step in out["overlap"]]
+        q.put((rank, same, out["launched_in_backward"], out["nbuckets"], out["overlap"][-1][0].clone(), out["overlap"][-1][-3] is None, out["late"],
+               none_pattern == [[g is None for g in step] for step in out["posthoc"]], [step[-2] is None for step in out["overlap"]]))
     finally:
         dist.destroy_process_group()
 
@@ -192,7 +196,8 @@ def test_overlapped_gradient_allreduce_equals_posthoc_bit_for_bit():
     """Mode S, VERDICT r2 item 9: gradient buckets launched from autograd hooks in reverse layer order (the all-reduce
     overlaps the rest of the backward) give exactly the gradients of the post-hoc bucketed reduction, over several steps,
     including steps where one rank holds no graph at all (no hook fires there: everything is launched by finalize, in the
-    same order) and a parameter that never receives a gradient."""
+    same order), a parameter that never receives a gradient, and a parameter whose gradient is data dependent (it joins the live
+    set late, and returns to ``grad is None`` on a step in which no rank differentiates it - as the single-GPU step would)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 35500 + os.getpid() % 2000
@@ -204,9 +209,11 @@ def test_overlapped_gradient_allreduce_equals_posthoc_bit_for_bit():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, same, launched, nb, g_last, unused_none in res:
+    for rank, same, launched, nb, g_last, unused_none, late, same_none, sometimes_none in res:
         assert same, "overlapped reduction differs from the post-hoc one on rank %d" % rank
-        assert nb >= 3 and unused_none
+        assert nb >= 3 and unused_none and same_none
+        assert late == 1                                   # `sometimes` joined the live set on step 1 ...
+        assert sometimes_none == [True, False, True, False]    # ... and went back to grad None on step 2, where no rank had a gradient for it
     assert res[0][2] >= 3                        # rank 0 always has graphs: buckets did go out from inside backward
     assert torch.equal(res[0][4], res[1][4])     # replicas hold identical gradients
 

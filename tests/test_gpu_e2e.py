@@ -380,3 +380,36 @@ def test_train_net_eval_only_on_coco_json(tmp_path):
     assert set(res) == {"fundusA_val", "fundusB_val", "fundusA_mean", "fundusB_mean"}
     for v in res.values():
         assert set(v) == {"Dice Coefficient", "Enhanced Alignment Metric", "Structural Similarity Metric"}
+
+
+def test_streaming_disk_loader_on_the_device_matches_the_resident_loader(tmp_path):
+    """The loader path of bench.py's `ab.loader_inclusive`: a dataset pre-rendered to disk, read by worker
+    processes into the shared page-locked ring, DMA from the ring slot, resize on the device.  Every item equals the resident
+    loader's (host mapper) item: ids, teacher-forced boxes, images within 1 LSB, and the ground-truth masks that travelled to the
+    device with the batch; over two passes and more batches than ring slots."""
+    from ttdg_mgm_amd import data
+    from ttdg_mgm_amd.config import get_cfg
+    cfg = get_cfg()
+    cfg.TEST.BATCH = 2
+    cfg.INPUT.MIN_SIZE_TEST = 200
+    dev = torch.device("cuda:0")
+    data.register_synthetic("gstream_src", 31, size=128, id_offset=900)
+    data.register_disk("gstream", str(tmp_path / "s"), source="gstream_src", workers=2)
+    res = data.build_detection_test_loader(cfg, "gstream_src", 0, 1, None, resident=True)
+    stm = data.build_detection_test_loader(cfg, "gstream", 0, 1, dev, resident=False)
+    stm.start_workers()
+    assert stm._disk.ring is not None and stm._disk.ring.pinned and stm.device_resize
+    ref = [it for b in res for it in b]
+    for _ in range(2):
+        k = 0
+        for batch in stm:
+            for it in batch:
+                r = ref[k]
+                assert it["image_id"] == r["image_id"] and torch.equal(it["tf_boxes"], r["tf_boxes"])
+                assert it["image"].is_cuda and it["image"].shape == r["image"].shape
+                d = (it["image"].cpu().int() - r["image"].int()).abs()
+                assert int(d.max()) <= 1 and float((d > 0).float().mean()) <= 2e-3
+                dm = it["dataset_dict"]["device_masks"]
+                assert dm.is_cuda and torch.equal(dm.cpu(), torch.stack([a["mask"] for a in r["dataset_dict"]["annotations"]]))
+                k += 1
+        assert k == 31

@@ -81,6 +81,15 @@ class _Ring:
                 ok = ok and int(rt.cudaHostRegister(t.data_ptr(), t.numel() * t.element_size(), 0)) == 0
             self.pinned = ok
 
+    def __del__(self):
+        if getattr(self, "pinned", False):
+            try:
+                rt = torch.cuda.cudart()
+                for t in (self.images, self.masks):
+                    rt.cudaHostUnregister(t.data_ptr())
+            except Exception:          # interpreter shutdown: the driver releases the registration with the process
+                pass
+
     def wait(self, slot):
         if self.events[slot] is not None:
             self.events[slot].synchronize()

@@ -184,18 +184,23 @@ class OverlappedGradReducer:
     on a rank that held no graph no hook ever fires and everything is launched there, with zeros - waits, and installs the
     reduced gradients.
 
-    Which parameters are live (have a gradient on some rank) is learned from the first step, which runs post-hoc through
-    ``allreduce_grads``; it is a property of the architecture (res3-5, FPN, the affinity module).  A
-    gradient that shows up on a parameter outside that set raises.  Same buckets, same buffers, same collectives as the
-    post-hoc path: the results are bit-identical (tests/test_distributed.py)."""
+    Which parameters carry a gradient is DATA dependent (an FPN output convolution is only differentiated when some node of
+    the step was sampled from its level), so the live set cannot be fixed once: it is the union of what has been seen so far
+    (learned post-hoc in the first step), and every step ends with one small MAX all-reduce of "has a gradient on this rank"
+    that settles the two remaining cases exactly as the post-hoc path does - a live parameter that received no gradient on
+    ANY rank in this step goes back to ``grad is None`` (the optimizer skips it, as the single-GPU step does; its zeros were
+    reduced for nothing), and a parameter outside the live set that did receive one is reduced in an extra bucket at the end
+    and joins the live set.  Same values as the post-hoc path: bit-identical at world size 2 (tests/test_distributed.py); for
+    more ranks equal up to the ring's reduction order, since the flat buffers are composed differently."""
 
     def __init__(self, summed, replicated, bucket_bytes=BUCKET_BYTES):
         self.params = list(summed) + list(replicated)
         self.nsum = len(summed)
         self.bucket_bytes = bucket_bytes
         self.buckets = plan_buckets(self.params, bucket_bytes)
-        self.have = None                         # learned on the first step
+        self.have = None                         # the live set, learned on the first step and grown afterwards
         self.overlapped_launches = 0             # buckets launched from inside backward (diagnostics / tests)
+        self.late_joins = 0                      # parameters that joined the live set after the first step
         self._armed = False
         self._bucket_of = {}
         for b, idx in enumerate(self.buckets):
@@ -205,10 +210,8 @@ class OverlappedGradReducer:
 
     def _hook(self, i):
         def fn(_p):
-            if not self._armed:
-                return
-            if not self.have[i]:
-                raise RuntimeError("parameter %d received a gradient but had none on any rank in the first step" % i)
+            if not self._armed or not self.have[i]:
+                return                           # not armed, or a late joiner: settled in finalize()
             b = self._bucket_of[i]
             self._pending[b] -= 1
             self._advance(from_hook=True)
@@ -241,11 +244,29 @@ class OverlappedGradReducer:
             _finish(work)
             return
         self._armed = False
+        local = [p.grad is not None for p in self.params]    # before anything is installed
         for b in range(self._next, len(self.buckets)):       # not ready by hooks (this rank had no graph / no gradient)
             self._pending[b] = 0
         self._advance(from_hook=False)
+        # every rank has now issued the same sequence of bucket collectives (some from inside backward, the rest just now);
+        # only then the mask exchange - a rank without graphs would otherwise issue it BEFORE its buckets and the ranks' collective
+        # orders would differ
+        have = torch.tensor(local, dtype=torch.int32, device=self.params[0].device)
+        _all_reduce_async(have, dist.ReduceOp.MAX).wait()
+        anywhere = [bool(h) for h in have.tolist()]          # gradients that exist on SOME rank in this step
+        late = [i for i, (a, h) in enumerate(zip(anywhere, self.have)) if a and not h]
+        if late:                                 # outside the live set so far: one extra bucket, the same on every rank
+            w = _launch_bucket(self.params, late, anywhere, self.nsum, self._world)
+            if w is not None:
+                self._work.append(w)
+            self.late_joins += len(late)
         _finish(self._work)
         self._work = []
+        for i, (a, h) in enumerate(zip(anywhere, self.have)):
+            if h and not a:
+                self.params[i].grad = None       # no gradient anywhere in this step: skipped by the optimizer, as post-hoc
+            elif a and not h:
+                self.have[i] = True
 
     def remove(self):
         for h in self._handles:
