@@ -180,7 +180,7 @@ def build_model(cfg, args, device, weights, calib_batch, world):
 
 
 # ------------------------------------------------------------------------------------------- the timed pass
-def timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, world, device, teacher_forced, loader_factory=None, lazy_gt=False):
+def timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, world, device, teacher_forced, loader_factory=None):
     """W untimed warm-up batches, then EXACTLY K adapted batches (K TTA steps, then the Dice pass over the same K batches)
     between barrier + synchronize on both sides.  ``loader_factory`` (A/B): the K timed batches come from a streaming loader
     (decode / synthesise + resize + H2D inside the loop, 2-deep prefetch) instead of the resident list."""
@@ -618,9 +618,10 @@ def gpu_main(args, rank, world, local):
         def stream():
             return sloader
         ab["loader_inclusive"] = short(
-            timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, world, device, tf, loader_factory=stream, lazy_gt=True),
-            "timed batches stream from local storage through %d worker processes: read + unpack, pinned H2D of the raw %dx%d uint8 image, "
-            "resize to the test size ON THE DEVICE, 2-deep prefetch; ground truth travels with the items; in both passes"
+            timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, world, device, tf, loader_factory=stream),
+            "timed batches stream from local storage through %d worker processes that write each batch into a shared page-locked ring; DMA of the "
+            "raw %dx%d uint8 batch and its ground-truth masks from the ring slot, resize to the test size ON THE DEVICE, staged one batch ahead; "
+            "in both passes (rendering the stream to disk and starting the workers are outside the timed region)"
             % (cfg.DATALOADER.NUM_WORKERS, args.size, args.size))
         ab["loader_inclusive"]["fraction_of_resident"] = ab["loader_inclusive"]["value"] / (K * B / main["elapsed"])
     if args.workload != "cfg2":
