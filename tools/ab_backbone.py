@@ -99,6 +99,27 @@ def main():
             torch.cuda.synchronize()
         print("%-34s %-5s %8.2f ms" % ("MIOpen fusion plans (conv+bias+relu)", "eval", (time.perf_counter() - t0) / reps * 1e3), flush=True)
         return
+    if only == "fpn_cl":
+        # experiment: only the FPN 3x3 output convolutions (the igemm NHWC kernels + MIOpen's transposes around them) see
+        # channels_last tensors; the trunk stays NCHW
+        import torch.nn.functional as F
+        CL = torch.channels_last
+
+        def fpn_forward(self, x):
+            c2, c3, c4, c5 = self.bottom_up(x)
+            prev = self.fpn_lateral5(c5)
+            outs = [self.fpn_output5(prev.contiguous(memory_format=CL))]
+            for i, c in ((4, c4), (3, c3), (2, c2)):
+                prev = getattr(self, "fpn_lateral%d" % i)(c) + F.interpolate(prev, scale_factor=2.0, mode="nearest")
+                outs.insert(0, getattr(self, "fpn_output%d" % i)(prev.contiguous(memory_format=CL)))
+            outs.append(F.max_pool2d(outs[-1], kernel_size=1, stride=2, padding=0))
+            return dict(zip(("p2", "p3", "p4", "p5", "p6"), outs))
+        for i in (2, 3, 4, 5):
+            m = getattr(net, "fpn_output%d" % i)
+            m.weight.data = m.weight.data.contiguous(memory_format=CL)
+        type(net).forward = fpn_forward
+        run("FPN output convs channels_last", True, False)
+        return
     if only in ("", "nchw"):
         run("NCHW + fused epilogues (product)", True, False)
         run("NCHW, plain torch epilogues", False, False)
