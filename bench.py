@@ -79,6 +79,7 @@ def parse(argv=None):
     ap.add_argument("--roi-xcd-chunks", action="store_true", help="A/B: channels-last ROIPooler with one contiguous eighth of the ROI list per XCD instead of ROI r on workgroup r")
     ap.add_argument("--roi-chunk", type=int, default=0, help="A/B: bins the channels-last ROIPooler stages per output flush: 49 (round 2), 25 (default) or 13")
     ap.add_argument("--flat-bias-act", action="store_true", help="A/B: the round-2 flat bias_act kernel instead of the per-plane one")
+    ap.add_argument("--torch-profile", default="", help="debug: after the headline pass, repeat it under torch.profiler and write the per-operator table to this path")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch, rendezvous, sharding and the collectives of the bench without any GPU work (CPU test of --gpus N)")
     a = ap.parse_args(argv)
@@ -268,18 +269,18 @@ def kernel_rooflines(run):
             e["work"] += sum(4 * H * r * c for r, c in _pairs(meta))
         elif nm == "pair_stage_bwd":
             e["work"] += 2 * sum(8 * r * c for r, c in _pairs(meta))
-        elif nm in ("sgd", "bias_act", "relu_bwd", "roi_align_nhwc"):
+        elif nm in ("sgd", "bias_act", "relu_bwd", "roi_align_nhwc", "row_scale_multi"):
             e["work"] += meta
     out = []
     for nm, e in acc.items():
-        hbm = nm in ("sinkhorn_pairs_fwd", "sinkhorn_pairs_bwd", "sgd", "pair_stage_bwd", "bias_act", "relu_bwd", "roi_align_nhwc")
+        hbm = nm in ("sinkhorn_pairs_fwd", "sinkhorn_pairs_bwd", "sgd", "pair_stage_bwd", "bias_act", "relu_bwd", "roi_align_nhwc", "row_scale_multi")
         ach = e["work"] / e["t"] / (1e9 if hbm else 1e12)
         peak = HBM_PEAK_GBS if hbm else FP32_PEAK_TFLOPS
         r = {"kernel": {"gagm": "gagm_kernel", "sgd": "sgd_multi_tensor_kernel", "affinity_fwd": "affinity_fwd_kernel",
                         "affinity_bwd": "affinity_bwd_kernel(+finish)", "sinkhorn_pairs_fwd": "sinkhorn_pairs_fwd_kernel",
                         "sinkhorn_pairs_bwd": "sinkhorn_pairs_bwd_kernel", "pair_stage_fwd": "pair_stage_fwd_kernel",
                         "pair_stage_bwd": "pair_stage_bwd_kernel", "bias_act": "bias_act_plane_kernel", "relu_bwd": "relu_bwd_kernel",
-                        "roi_align_nhwc": "roi_align_nhwc_kernel"}[nm],
+                        "roi_align_nhwc": "roi_align_nhwc_kernel", "row_scale_multi": "row_scale_multi_kernel"}[nm],
              "bound": "hbm" if hbm else "mfma", "achieved": ach, "peak": peak, "unit": "GB/s" if hbm else "TFLOP/s", "frac": ach / peak,
              "traffic": pmc_traffic(nm), "launches": e["n"], "avg_launch_ms": e["t"] / e["n"] * 1e3, "total_ms": e["t"] * 1e3,
              "algorithmic_work_per_launch": e["work"] / e["n"]}
@@ -303,7 +304,7 @@ def pmc_traffic(stamp_name):
              "affinity_bwd": ("affinity_bwd_kernel", False), "sinkhorn_pairs_fwd": ("sinkhorn_pairs_fwd", False),
              "sinkhorn_pairs_bwd": ("sinkhorn_pairs_bwd", False), "pair_stage_fwd": ("pair_stage_fwd", False),
              "pair_stage_bwd": ("pair_stage_bwd", False), "bias_act": ("bias_act", True), "relu_bwd": ("relu_bwd", True),
-             "roi_align_nhwc": ("roi_align_nhwc", True)}
+             "roi_align_nhwc": ("roi_align_nhwc", True), "row_scale_multi": ("row_scale_multi", True)}
     kernel, streaming = names[stamp_name]
     for f in ("r03_bench_pmc.json", "r02_bench_pmc.json", "r01_bench_pmc.json"):
         try:
@@ -554,6 +555,17 @@ def gpu_main(args, rank, world, local):
     tf = bool(args.teacher_forced)
     main = timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, world, device, tf)
     note("headline pass done: %.1f images/s" % (world * K * B / main["elapsed"]))
+    if args.torch_profile and world == 1:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, world, device, tf)
+        with open(args.torch_profile, "w") as f:
+            f.write("# torch.profiler over W=%d warm-up + K=%d adapted batches (TTA steps + Dice pass), operators by device time\n" % (W, K))
+            f.write(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=70, max_name_column_width=70))
+            f.write("\n\n# by call count\n")
+            rows = sorted(prof.key_averages(), key=lambda e: -e.count)[:60]
+            for e in rows:
+                f.write("%-70s calls %6d  self device %9.1f us  self cpu %9.1f us\n" % (e.key[:70], e.count, e.self_device_time_total, e.self_cpu_time_total))
 
     strong = None
     if world > 1 and not args.images and args.strong_images and not args.sync_universe:

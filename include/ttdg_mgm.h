@@ -244,6 +244,18 @@ typedef struct {
 int ttdg_sgd_multi_tensor(const ttdg_sgd_tensor_t* table, const int32_t* chunk_tensor, const int64_t* chunk_off,
                           int nchunks, int chunk, float lr, float momentum, ttdg_stream_t stream);
 
+/* ---- FrozenBN scale folded into many convolution filters at once (detectron2 FrozenBatchNorm2d [3P] behind every ResNet
+ *      convolution of the backbone called at rcnn.py:219 / :181): out_t[r][j] = in_t[r][j] * scale_t[r], row = output channel;
+ *      also its backward (grad_w = grad_wf * scale).  Up to TTDG_ROW_SCALE_MAX tensors per launch, table passed by value. */
+#define TTDG_ROW_SCALE_MAX 64
+typedef struct {
+  const float* in;
+  const float* scale;
+  float* out;
+  int rows, rowlen;
+} ttdg_row_scale_t;
+int ttdg_row_scale_multi(const ttdg_row_scale_t* items, int n, ttdg_stream_t stream);
+
 /* ---- detection helpers of the torch-native Mask R-CNN stand-in (stands in for the
  *      un-vendored detectron2 ROIAlignV2 / torchvision nms [3P]); forward-only on the TTA path -------------
  * rois (R,5) = (batch idx, x1,y1,x2,y2) image coords; feat (B,C,H,W); out (R,C,P,P); aligned, adaptive sampling. */

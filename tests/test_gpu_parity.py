@@ -1181,6 +1181,80 @@ def test_fused_bias_residual_relu_epilogue(dev):
     assert maxerr(fused, plain) <= 1e-4 * max(1.0, float(plain.abs().max()))
 
 
+def test_multi_tensor_filter_fold_is_the_per_filter_multiply(dev):
+    """csrc/fold.hip: the FrozenBN scale folded into all filters of a stage in one launch.  The kernel against torch's
+    broadcast multiply (bit-exact: one fp32 product per value) on vector, scalar (row length % 4 != 0), unaligned and empty
+    tensors, more than 64 tensors per call, and through autograd; then the ResNet trunk with the switch on and off - outputs
+    bit-identical, every filter gradient equal to the vendor kernels' reproducibility in a TTA-style pass (gradients flow through res3 - res5) and in the
+    no-grad pass, including after the filters have moved in place."""
+    from ttdg_mgm_amd import ops
+    from ttdg_mgm_amd.modeling import backbone as bb
+    g = synth.gen(7420)
+    shapes = [(8, 4, 3, 3), (5, 3, 7, 7), (16, 64, 1, 1), (3, 5), (0, 4, 1, 1), (130, 64, 3, 3), (7, 1, 1, 1)] + [(4, 8, 1, 1)] * 70
+    ts = [synth.normal(g, sh, 1.0).to(dev) for sh in shapes]
+    ts[2] = torch.cat([torch.zeros(1, device=dev), ts[2].flatten()])[1:].view(shapes[2])        # 4-byte aligned only
+    sc = [synth.normal(g, (sh[0],), 1.0).to(dev) for sh in shapes]
+    outs = ops.row_scale_multi(ts, sc)
+    assert len(outs) == len(ts)
+    for t, s_, o in zip(ts, sc, outs):
+        assert o.shape == t.shape and torch.equal(o, t * s_.view([-1] + [1] * (t.dim() - 1)))
+    ws = [t.clone().requires_grad_() for t in ts[:6]]
+    got = ops.FoldFiltersFn.apply(tuple(sc[:6]), *ws)
+    up = [synth.normal(g, t.shape, 1.0).to(dev) for t in ws]
+    sum((o * u).sum() for o, u in zip(got[:5], up[:5])).backward()            # the sixth result is unused: its filter gets no gradient
+    for i, (w, s_, u) in enumerate(zip(ws, sc, up)):
+        if i == 5:
+            assert w.grad is None
+        else:
+            assert torch.equal(w.grad, u * s_.view([-1] + [1] * (w.dim() - 1)))
+    with pytest.raises(ValueError):
+        ops.row_scale_multi(ts[:2], sc[:1])
+    with pytest.raises(ValueError):
+        ops.row_scale_multi([ts[0]], [sc[1]])
+
+    torch.manual_seed(2)
+    net = bb.ResNet50(2).to(dev).train()
+    for m in net.modules():
+        if isinstance(m, bb.FrozenBatchNorm2d):
+            m.weight.copy_(synth.normal(g, m.weight.shape, 0.1).to(dev) + 1.0)
+            m.running_mean.copy_(synth.normal(g, m.bias.shape, 0.1).to(dev))
+    x0 = synth.normal(g, (1, 3, 64, 64), 1.0).to(dev)
+    res = {}
+    for multi in (True, False, None):                            # None: the per-filter path a second time
+        bb.MULTI_FOLD = bool(multi)
+        try:
+            net.zero_grad(set_to_none=True)
+            outs = net(x0)
+            sum(o.square().mean() for o in outs).backward()
+            grads = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+            with torch.no_grad():
+                quiet = [o.clone() for o in net(x0)]
+                keep = [p.clone() for p in net.res4.parameters()]
+                for p in net.res4.parameters():
+                    p.mul_(1.01)                                 # the filters move in place: the cached folds are stale
+                moved = [o.clone() for o in net(x0)]
+                for p, k in zip(net.res4.parameters(), keep):
+                    p.copy_(k)
+            res[multi] = ([o.detach().clone() for o in outs], grads, quiet, moved)
+        finally:
+            bb.MULTI_FOLD = True
+    assert all(c._staged_w is None for c in net.modules() if isinstance(c, bb.ConvNorm))
+    assert len(res[True][1]) == len(res[False][1]) > 40
+    flat = {m: r[0] + r[2] + r[3] for m, r in res.items()}
+    # are the vendor convolutions bit-reproducible on these shapes at all?  (small GEMM-shaped 1x1 convolutions may split K with atomics)
+    reproducible = all(torch.equal(a, b) for a, b in zip(flat[False], flat[None]))
+    print("trunk with per-filter folds, run twice: %s" % ("bit-identical" if reproducible else "NOT bit-identical (max %.2e)" % max(
+        maxerr(a, b) for a, b in zip(flat[False], flat[None]))))
+    for k, (a, b) in enumerate(zip(flat[True], flat[False])):
+        if reproducible:
+            assert torch.equal(a, b), "output %d differs by %.3e" % (k, maxerr(a, b))
+        else:
+            assert maxerr(a, b) <= 2e-5 * max(1.0, float(b.abs().max())), "output %d differs by %.3e" % (k, maxerr(a, b))
+    for n, gr in res[False][1].items():                          # (MIOpen's weight-gradient kernels may split K with atomics: not bit-reproducible)
+        assert maxerr(res[True][1][n], gr) <= 1e-5 * max(1e-30, float(gr.abs().max())), n
+    assert not torch.equal(res[True][3][2], res[True][2][2])
+
+
 def test_fused_epilogue_with_gradients_is_the_plain_torch_block(dev):
     """The adapted bottlenecks (gradients flow) take ops.BiasActFn - in-place shift / residual / ReLU with a one-pass backward.
     Same arithmetic in the same order as conv-with-bias, add, F.relu_: outputs, input gradient and every filter gradient must

@@ -51,7 +51,13 @@ class GemmDesc(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("K2", C.c_int32), ("alpha", C.c_float), ("beta", C.c_float)]
 
 
+class RowScale(C.Structure):
+    """ttdg_row_scale_t: one tensor of a multi-tensor row scaling."""
+    _fields_ = [("inp", C.c_void_p), ("scale", C.c_void_p), ("out", C.c_void_p), ("rows", C.c_int32), ("rowlen", C.c_int32)]
+
+
 GEMM_GROUP_MAX = 8
+ROW_SCALE_MAX = 64
 _P, _I, _L, _F, _S = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_void_p
 
 # name -> (restype, argtypes); one entry per symbol declared in include/ttdg_mgm.h
@@ -63,6 +69,7 @@ SIGNATURES = {
     "ttdg_gemm_f32_splitk": (C.c_int, [_P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _F, _F, _I, _P, _S]),
     "ttdg_gemm_f32_grouped": (C.c_int, [C.POINTER(GemmDesc), _I, _S]),
     "ttdg_colsum_f32": (C.c_int, [_P, _L, _P, _I, _I, _S]),
+    "ttdg_row_scale_multi": (C.c_int, [C.POINTER(RowScale), _I, _S]),
     "ttdg_affinity_pairwise_fwd": (C.c_int, [_P, _P, _P, _I, Graphs, _I, _P, _S]),
     "ttdg_affinity_bwd_workspace_bytes": (C.c_size_t, [_I, _I]),
     "ttdg_affinity_pairwise_bwd": (C.c_int, [_P, _P, _P, _P, _I, Graphs, _P, _P, _P, _P, _P, _S]),

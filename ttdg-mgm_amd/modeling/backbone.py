@@ -12,6 +12,9 @@ import os
 
 # module switch (calibrate_frozen_bn turns it off: its statistics hooks sit on ConvNorm.forward); TTDG_FUSED_EPILOGUE=0 for A/B runs
 FUSED_EPILOGUE = os.environ.get("TTDG_FUSED_EPILOGUE", "1") != "0"
+# the FrozenBN scale is folded into all filters of a ResNet stage by ONE launch (ops.row_scale_multi) instead of one elementwise
+# kernel per filter per pass; TTDG_MULTI_FOLD=0 for A/B runs
+MULTI_FOLD = os.environ.get("TTDG_MULTI_FOLD", "1") != "0"
 
 
 def _publish(t):
@@ -72,6 +75,7 @@ class ConvNorm(nn.Conv2d):
         super().__init__(cin, cout, k, stride=stride, padding=padding, bias=not norm)
         self.norm = FrozenBatchNorm2d(cout) if norm else None
         self._wfold = None
+        self._staged_w = None            # the folded filter of the current forward pass, when the stage folded all of its filters at once
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
 
     def raw(self, x):
@@ -86,7 +90,8 @@ class ConvNorm(nn.Conv2d):
     def raw_on_tape(self, x):
         """raw() for a filter that is being adapted: the folded filter stays on the autograd tape."""
         scale, shift = self.norm.folded()
-        return F.conv2d(x, self.weight * scale, None, self.stride, self.padding), shift
+        w = self._staged_w if self._staged_w is not None else self.weight * scale
+        return F.conv2d(x, w, None, self.stride, self.padding), shift
 
     def forward(self, x):
         if self.norm is None:
@@ -104,6 +109,38 @@ class ConvNorm(nn.Conv2d):
                     self._wfold = (key, _publish(self.weight * scale))
             w = self._wfold[1]
         return F.conv2d(x, w, shift.to(x.dtype), self.stride, self.padding)
+
+
+def _fold_stage(stage, x):
+    """Fold the FrozenBN scales into every filter of ``stage`` that needs it, in one launch, before its blocks run.
+    Gradients flow (the adapted stages of a TTA step): the folded filters come from ops.FoldFiltersFn and are handed to the
+    blocks through ``ConvNorm._staged_w``; returns the list to release after the stage.  No gradient (Dice pass, frozen stages):
+    refreshes the stale entries of the per-filter caches ``ConvNorm.raw`` reads.  Same products as the per-filter multiplies."""
+    if not (MULTI_FOLD and FUSED_EPILOGUE and x.is_cuda and x.dtype == torch.float32) or torch.is_autocast_enabled():
+        return None
+    convs = stage.__dict__.get("_convnorms")
+    if convs is None:
+        convs = stage.__dict__["_convnorms"] = [m for m in stage.modules() if isinstance(m, ConvNorm) and m.norm is not None]
+    if not convs:
+        return None
+    if torch.is_grad_enabled() and (x.requires_grad or any(c.weight.requires_grad for c in convs)):
+        scales = tuple(c.norm.folded()[0].view(-1) for c in convs)
+        for c, w in zip(convs, ops.FoldFiltersFn.apply(scales, *[c.weight for c in convs])):
+            c._staged_w = w
+        return convs
+    stale = []
+    for c in convs:
+        scale = c.norm.folded()[0]
+        key = (c.weight._version, c.weight.data_ptr(), c.norm._fold[0])
+        if c._wfold is None or c._wfold[0] != key:
+            stale.append((c, key, scale.view(-1)))
+    if len(stale) > 1:
+        with torch.no_grad():
+            outs = ops.row_scale_multi([c.weight for c, _, _ in stale], [sc for _, _, sc in stale])
+        _publish(outs[0])
+        for (c, key, _), w in zip(stale, outs):
+            c._wfold = (key, w)
+    return None
 
 
 class Stem(nn.Module):
@@ -167,11 +204,17 @@ class ResNet50(nn.Module):
 
     def forward(self, x):
         x = self.stem(x)
-        c2 = self.res2(x)
-        c3 = self.res3(c2)
-        c4 = self.res4(c3)
-        c5 = self.res5(c4)
-        return c2, c3, c4, c5
+        outs = []
+        for name in ("res2", "res3", "res4", "res5"):
+            stage = getattr(self, name)
+            staged = _fold_stage(stage, x)
+            try:
+                x = stage(x)
+            finally:
+                for c in staged or ():
+                    c._staged_w = None
+            outs.append(x)
+        return tuple(outs)
 
 
 class FPN(nn.Module):

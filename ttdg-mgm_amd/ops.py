@@ -98,6 +98,55 @@ def colsum(X):
     return out
 
 
+def row_scale_multi(tensors, scales):
+    """[t * s.view(-1, 1, ...) for t, s in zip(tensors, scales)] in ONE launch per 64 tensors (csrc/fold.hip): every tensor is
+    dense fp32 with its rows (dim 0) scaled by the matching entry of ``s``.  The results are views of one flat buffer."""
+    if len(tensors) != len(scales):
+        raise ValueError("row_scale_multi: %d tensors, %d scale vectors" % (len(tensors), len(scales)))
+    if not tensors:
+        return []
+    ins, offs, total = [], [], 0
+    for t, sc in zip(tensors, scales):
+        check_f32(t, sc)
+        if sc.numel() != t.shape[0] or sc.device != t.device:
+            raise ValueError("row_scale_multi: scale of %d entries for a tensor of %d rows" % (sc.numel(), t.shape[0]))
+        ins.append(t)
+        offs.append(total)
+        total += (t.numel() + 63) // 64 * 64               # every result starts on a 256-byte boundary, like an allocation of its own
+    flat = torch.empty(total, device=tensors[0].device, dtype=torch.float32)
+    outs = [flat[o:o + t.numel()].view(t.shape) for o, t in zip(offs, ins)]
+    items = []
+    for t, sc, o in zip(ins, scales, outs):
+        it = _lib.RowScale()
+        it.inp, it.scale, it.out = ptr(t), ptr(sc), ptr(o)
+        it.rows, it.rowlen = t.shape[0], t.numel() // max(1, t.shape[0])
+        items.append(it)
+    with _timed("row_scale_multi", 8 * sum(t.numel() for t in ins)):          # algorithmic bytes: read + write every value
+        for i in range(0, len(items), _lib.ROW_SCALE_MAX):
+            chunk = items[i:i + _lib.ROW_SCALE_MAX]
+            call("ttdg_row_scale_multi", (_lib.RowScale * len(chunk))(*chunk), len(chunk), stream())
+    return outs
+
+
+class FoldFiltersFn(torch.autograd.Function):
+    """wf_i = w_i * scale_i (per output channel) for a LIST of convolution filters: one launch forward, one backward
+    (grad_w_i = grad_wf_i * scale_i - the same multiplications autograd's MulBackward0 performs filter by filter)."""
+
+    @staticmethod
+    def forward(ctx, scales, *weights):
+        ctx.scales = scales
+        ctx.set_materialize_grads(False)          # an unused folded filter hands back None, not a tensor of zeros
+        return tuple(row_scale_multi(list(weights), scales))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        live = [i for i, g in enumerate(grads) if g is not None]
+        out = [None] * len(grads)
+        for i, r in zip(live, row_scale_multi([grads[i].contiguous() for i in live], [ctx.scales[i] for i in live])):
+            out[i] = r
+        return (None,) + tuple(out)
+
+
 class LinearFn(torch.autograd.Function):
     """nn.Linear on the MFMA GEMM (forward + both backward products)."""
 
