@@ -79,6 +79,8 @@ def parse(argv=None):
     ap.add_argument("--roi-xcd-chunks", action="store_true", help="A/B: channels-last ROIPooler with one contiguous eighth of the ROI list per XCD instead of ROI r on workgroup r")
     ap.add_argument("--roi-chunk", type=int, default=0, help="A/B: bins the channels-last ROIPooler stages per output flush: 49 (round 2), 25 (default) or 13")
     ap.add_argument("--flat-bias-act", action="store_true", help="A/B: the round-2 flat bias_act kernel instead of the per-plane one")
+    ap.add_argument("--miopen-search", action="store_true", help="tuning run: torch.backends.cudnn.benchmark = True, i.e. MIOpen times its solvers for every "
+                    "convolution shape it meets (minutes) and records the winners in its user find-db (MIOPEN_USER_DB_PATH)")
     ap.add_argument("--torch-profile", default="", help="debug: after the headline pass, repeat it under torch.profiler and write the per-operator table to this path")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch, rendezvous, sharding and the collectives of the bench without any GPU work (CPU test of --gpus N)")
@@ -337,6 +339,8 @@ def allcores_note():
     try:
         with open(os.path.join(ROOT, "profiles", "r03_bench_cpu_allcores.json")) as f:
             a = json.load(f)["cpu_baseline"]["all_cores"]
+        if a["value"] is None:
+            return "all %d host threads, tried once this round: %s (64 threads is the fastest setting found)" % (a["cores"], a["protocol"])
         return "all %d host threads, recorded once this round: %s images/s (%s)" % (a["cores"], a["value"], a["protocol"])
     except (OSError, ValueError, KeyError):
         return "torch's CPU kernels stop scaling beyond 64 intra-op threads on these tensor sizes; all-cores figure not recorded"
@@ -514,6 +518,8 @@ def run(args):
 def gpu_main(args, rank, world, local):
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    if args.miopen_search:
+        torch.backends.cudnn.benchmark = True
     import __graft_entry__
     if rank == 0:
         __graft_entry__.build()
