@@ -79,6 +79,7 @@ def parse(argv=None):
     ap.add_argument("--roi-xcd-chunks", action="store_true", help="A/B: channels-last ROIPooler with one contiguous eighth of the ROI list per XCD instead of ROI r on workgroup r")
     ap.add_argument("--roi-chunk", type=int, default=0, help="A/B: bins the channels-last ROIPooler stages per output flush: 49 (round 2), 25 (default) or 13")
     ap.add_argument("--flat-bias-act", action="store_true", help="A/B: the round-2 flat bias_act kernel instead of the per-plane one")
+    ap.add_argument("--no-miopen-db", action="store_true", help="A/B: ignore the tuned MIOpen find-db shipped in ttdg-mgm_amd/miopen_db (MIOpen's heuristic picks the solvers)")
     ap.add_argument("--miopen-search", action="store_true", help="tuning run: torch.backends.cudnn.benchmark = True, i.e. MIOpen times its solvers for every "
                     "convolution shape it meets (minutes) and records the winners in its user find-db (MIOPEN_USER_DB_PATH)")
     ap.add_argument("--torch-profile", default="", help="debug: after the headline pass, repeat it under torch.profiler and write the per-operator table to this path")
@@ -494,6 +495,8 @@ def steps_per_rank(args, world):
 
 
 def run(args):
+    if args.no_miopen_db:
+        os.environ["TTDG_MIOPEN_DB"] = "0"              # read when the package is first imported (below)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -671,6 +674,9 @@ def gpu_main(args, rank, world, local):
         "inputs": "pre-staged in HBM (uint8, already resized to 800x800 by the test mapper); loader-inclusive rate under ab.loader_inclusive",
         "tta_only_images_per_s": images / main["tta"], "dice": main["dice"], "kept_masks": main["kept_masks"],
         "tta_steps_taken": main["steps_taken"],
+        "vendor_convolutions": ("MIOpen immediate mode, solvers from the find-db shipped in ttdg-mgm_amd/miopen_db (tools/tune_miopen.sh; A/B: --no-miopen-db)"
+                                if os.environ.get("MIOPEN_USER_DB_PATH", "").rstrip("/").endswith("miopen_db") and not args.miopen_search else
+                                "MIOpen timing its solvers in this process (--miopen-search)" if args.miopen_search else "MIOpen immediate mode, heuristic solver choice"),
     }
     if roofs:
         out["roofline"] = roofs[0]          # the hand-written kernel with the largest total time in the timed region (live HIP events)

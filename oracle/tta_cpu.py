@@ -46,7 +46,7 @@ class _CpuBackend:
         scores[:, col0:col0 + k] = torch.where(ok, score, score.new_full((), float("-inf")))
 
     @staticmethod
-    def nms_batched(boxes, scores, lvl, nlvl, thr, max_group, topk, device_counts=False):
+    def nms_batched(boxes, scores, lvl, nlvl, thr, max_group, topk, device_counts=False, level_sizes=None):
         B, K = scores.shape
         idx = torch.zeros(B, min(int(topk), K), dtype=torch.int64)
         counts = []

@@ -1101,6 +1101,12 @@ def test_rpn_decode_and_batched_selection_match_host_formulation(dev):
             col += k
         keep, counts = be.nms_batched(boxes, scores, lvl.to(dv), len(shapes), 0.7, pre, post)
         res[name] = (boxes.cpu(), scores.cpu(), keep.cpu(), counts)
+        if name == "gpu":
+            # the RPN's own call: per-level blocks already in descending score order -> the sort-free sweep, same selection
+            keep2, counts2 = be.nms_batched(boxes, scores, lvl.to(dv), len(shapes), 0.7, pre, post, level_sizes=ks)
+            assert counts2 == counts
+            for b in range(B):
+                assert torch.equal(keep2[b, :counts2[b]], keep[b, :counts[b]]), b
     (bc, sc_, kc, cc), (bg, sg, kg, cg) = res["cpu"], res["gpu"]
     live = sc_ > float("-inf")
     assert torch.equal(live, sg > float("-inf")) and int((~live).sum()) >= 1

@@ -309,7 +309,8 @@ def test_continual_tta_trajectory_matches_cpu_port(trained):
         for g, ns in names.items():
             move = max(float((th_h[n].detach() - theta0[n]).abs().max()) for n in ns)
             diff = max(float((th_d[n] - th_h[n].detach()).abs().max()) for n in ns)
-            row["groups"][g] = dict(moved=move, device_minus_host=diff, rel=diff / max(move, 1e-30))
+            ulp = 2.0 ** -23 * max(float(th_h[n].detach().abs().max()) for n in ns)          # rounding unit of the group's largest parameter
+            row["groups"][g] = dict(moved=move, device_minus_host=diff, rel=diff / max(move, 1e-30), param_ulp=ulp)
         if k == 0:
             e_ref = {}
             for g, ns in names.items():
@@ -347,7 +348,10 @@ def test_continual_tta_trajectory_matches_cpu_port(trained):
         assert e_ref[g]["device"] <= bound0, ("step 0 vs float64", g, e_ref[g], bound0)
         for row in rec:
             bound = max(1e-4, TRAJ_FACTOR * e_ref[g]["host32"]) * (row["step"] + 1)
-            assert row["groups"][g]["rel"] <= bound, (row["step"], g, row["groups"][g], bound)
+            # (a group that has barely moved - the affinity layers: 2e-4 after three steps on parameters of size 2 - is compared in
+            #  units of the parameters' own rounding: the fused SGD kernel's fma and torch's mul + add may differ by one ulp per step)
+            v = row["groups"][g]
+            assert v["rel"] <= bound or v["device_minus_host"] <= 2 * (row["step"] + 1) * v["param_ulp"], (row["step"], g, v, bound)
     lb = max(1e-4, TRAJ_FACTOR * e_ref["loss"]["host32"])
     assert e_ref["loss"]["device"] <= lb, e_ref["loss"]
     for row in rec:

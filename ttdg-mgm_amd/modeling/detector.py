@@ -125,7 +125,7 @@ class PseudoLabRPN(nn.Module):
             sc, idx = lg.permute(0, 2, 3, 1).reshape(N, -1).topk(k, dim=1)
             _backend.rpn_decode(dl, an, idx, sc.float(), sizes_t, boxes, scores, col)      # decode + clip + validity, fused
             col += k
-        keep, counts = _backend.nms_batched(boxes, scores, lvl, L, self.nms_thresh, pre, post, device_counts=True)
+        keep, counts = _backend.nms_batched(boxes, scores, lvl, L, self.nms_thresh, pre, post, device_counts=True, level_sizes=ks)
         return boxes, scores, keep, counts
 
     @staticmethod
