@@ -282,6 +282,19 @@ int ttdg_nms_grouped(const float* boxes, const int32_t* seg, int ngroups, int N,
  * paste_masks: soft masks (R, S, S) -> (R, H, W) bytes (0/1): bilinear resampling inside boxes (R, 4), >= threshold. */
 int ttdg_rpn_decode(const float* deltas, const float* anchors, const int64_t* idx, const float* score, const float* sizes,
                     int B, int k, int A, int H, int W, int K, int col0, float* boxes, float* scores, ttdg_stream_t stream);
+/* rpn_select: find_top_rpn_proposals [3P] up to the NMS for ALL levels and images in one launch - per (image, level) the k best
+ *   logits (B, A, H, W as produced by the head) in descending order (ties: ascending (h, w, a) raster index), decoded as rpn_decode
+ *   does, into columns [col0, col0 + k) of boxes (B, K, 4) / scores (B, K).  k <= min(2048, A*H*W).  Replaces per level a
+ *   permute + torch.topk + rpn_decode. */
+#define TTDG_RPN_LEVELS_MAX 8
+typedef struct {
+  const float* logits;
+  const float* deltas;
+  const float* anchors;
+  int H, W, k, col0;
+} ttdg_rpn_level_t;
+int ttdg_rpn_select(const ttdg_rpn_level_t* levels, int nlevels, int B, int A, const float* sizes, int K, float* boxes,
+                    float* scores, ttdg_stream_t stream);
 int ttdg_box_inference(const float* logits, const float* deltas, const float* rois, const float* sizes, int N, int C,
                        float wx, float wy, float ww, float wh, float score_thresh, float* boxes, float* scores,
                        ttdg_stream_t stream);

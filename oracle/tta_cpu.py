@@ -45,6 +45,14 @@ class _CpuBackend:
         boxes[:, col0:col0 + k] = torch.nan_to_num(bx, nan=0.0)
         scores[:, col0:col0 + k] = torch.where(ok, score, score.new_full((), float("-inf")))
 
+    @classmethod
+    def rpn_select(cls, logits, deltas, anchors, ks, sizes_t, boxes, scores):
+        col = 0
+        for lg, dl, an, k in zip(logits, deltas, anchors, ks):
+            sc, idx = lg.permute(0, 2, 3, 1).reshape(lg.shape[0], -1).topk(k, dim=1)
+            cls.rpn_decode(dl, an, idx, sc.float(), sizes_t, boxes, scores, col)
+            col += k
+
     @staticmethod
     def nms_batched(boxes, scores, lvl, nlvl, thr, max_group, topk, device_counts=False, level_sizes=None):
         B, K = scores.shape

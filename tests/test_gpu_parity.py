@@ -1116,6 +1116,82 @@ def test_rpn_decode_and_batched_selection_match_host_formulation(dev):
         assert torch.equal(kc[b, :cc[b]], kg[b, :cg[b]]), b
 
 
+def test_fused_rpn_selection_equals_per_level_topk_and_decode(dev):
+    """ttdg_rpn_select (one launch: exact radix select + LDS sort + decode for every (image, level)) against the path it
+    replaces - per level permute + torch.topk + ttdg_rpn_decode: scores bit-identical in every slot, boxes bit-identical, the
+    selected SET identical; and on the CPU host backend's formulation.  Cases: the bench's level shapes scaled down and one
+    level larger than a workgroup's pass (3 x 120 x 100 = 36000 logits, k = 2000), k == n (tiny level), k == 1, exact ties
+    across the k-th rank (quantised logits: more ties than slots -> the deterministic lowest-index rule), constant logits,
+    +-inf and NaN logits, NaN deltas."""
+    from ttdg_mgm_amd import ops
+    cb = _cpu_backend()
+    g = synth.gen(7150)
+    A = 3
+
+    def run(shapes, pre, B, quant=None, special=False, sizes=None):
+        anchors, logits, deltas = [], [], []
+        for li, (h, w) in enumerate(shapes):
+            s_ = 4 * 2 ** li
+            ys, xs = np.meshgrid(np.arange(h) * s_, np.arange(w) * s_, indexing="ij")
+            base = np.array([[-8, -4, 8, 4], [-6, -6, 6, 6], [-4, -8, 4, 8]], np.float32) * (s_ / 4)
+            anchors.append(torch.from_numpy((np.stack((xs, ys, xs, ys), -1).reshape(-1, 1, 4) + base[None]).reshape(-1, 4).astype(np.float32)).to(dev))
+            lg = synth.normal(g, (B, A, h, w), 1.0)
+            if quant is not None:
+                lg = (lg / quant).round() * quant if quant > 0 else torch.zeros_like(lg)
+            d = synth.normal(g, (B, A * 4, h, w), 0.5)
+            if special and h * w > 8:
+                lg[0, 0, 0, 0], lg[0, 1, 0, 1], lg[0, 2, 1, 0] = float("inf"), float("-inf"), float("nan")
+                d[0, 0, 0, 2] = float("nan")
+                lg[0, 0, 0, 2] = 50.0                                    # (so the NaN-delta candidate is certainly selected)
+            logits.append(lg.to(dev)); deltas.append(d.to(dev))
+        ks = [min(pre, A * h * w) for h, w in shapes]
+        K = sum(ks)
+        sizes = sizes or [(shapes[0][0] * 4, shapes[0][1] * 4)] * B
+        st = ops.image_sizes_tensor(sizes, dev)
+        out = {}
+        for fused in (True, False):
+            ops.RPN_SELECT = fused
+            try:
+                boxes, scores = torch.full((B, K, 4), -7.0, device=dev), torch.full((B, K), -7.0, device=dev)
+                ops.rpn_select(logits, deltas, anchors, ks, st, boxes, scores)
+                out[fused] = (boxes.cpu(), scores.cpu())
+            finally:
+                ops.RPN_SELECT = True
+        (bf, sf), (bp, sp) = out[True], out[False]
+        # (a) the kernel's own rule - descending score, ascending (h, w, a) index on ties, -0.0 == +0.0, NaN first - restated on
+        #     the CPU: a stable descending sort of the raster, then the host backend's decode.  Every slot must coincide.
+        bc, sc_ = torch.empty(B, K, 4), torch.empty(B, K)
+        stc = cb.image_sizes_tensor(sizes, torch.device("cpu"))
+        col = 0
+        for lg, dl, an, k in zip(logits, deltas, anchors, ks):
+            v, order = torch.sort(lg.cpu().permute(0, 2, 3, 1).reshape(B, -1), dim=1, descending=True, stable=True)
+            cb.rpn_decode(dl.cpu(), an.cpu(), order[:, :k].contiguous(), v[:, :k].contiguous(), stc, bc, sc_, col)
+            col += k
+        live = sc_ > float("-inf")
+        assert torch.equal(live, sf > float("-inf")), "live slots differ: %s" % (shapes,)
+        assert torch.equal(sf[live], sc_[live]) and maxerr(bf[live], bc[live]) <= 1e-3 and bool((bf[~live] == 0).all())
+        # (b) the path it replaces (per level permute + torch.topk + ttdg_rpn_decode), where that path is determined: no designed
+        #     ties, and not in the slots where random fp32 logits happen to collide (7500 per row: now and then)
+        if quant is None:
+            assert torch.equal(torch.isnan(sf), torch.isnan(sp)) and torch.equal(sf.nan_to_num(nan=7.0), sp.nan_to_num(nan=7.0)), "scores differ: %s" % (shapes,)
+            uq = torch.ones_like(live)
+            uq[:, 1:] &= sf[:, 1:] != sf[:, :-1]
+            uq[:, :-1] &= sf[:, :-1] != sf[:, 1:]
+            assert torch.equal(bf[uq], bp[uq])
+        return sf
+
+    run([(50, 50), (25, 25), (13, 13), (7, 7), (4, 4)], 1000, 4)                 # the bench's pyramid at a quarter of the size (k = 1000; 48 = k == n on top)
+    run([(120, 100), (2, 2)], 2000, 2)                                            # 36000 logits per row, k = 2000; a level with k == n == 12
+    run([(24, 24), (12, 12)], 1, 3)                                               # k == 1
+    run([(40, 40), (20, 20)], 700, 2, quant=0.25)                                 # ties across the k-th rank
+    s0 = run([(16, 16)], 100, 2, quant=0)                                         # constant logits: 100 of 768 equal keys
+    assert bool((s0[s0 > float("-inf")] == 0).all())
+    run([(30, 30), (15, 15)], 500, 2, special=True)                               # +-inf / NaN logits, NaN deltas
+    with pytest.raises(RuntimeError):
+        lv = ops._lib.RpnLevel()
+        ops.call("ttdg_rpn_select", (ops._lib.RpnLevel * 1)(lv), 1, 1, 3, 0, 0, 0, 0, ops.stream())
+
+
 def test_box_inference_and_ragged_nms_match_host_formulation(dev):
     from ttdg_mgm_amd import ops
     cb = _cpu_backend()

@@ -56,8 +56,16 @@ class RowScale(C.Structure):
     _fields_ = [("inp", C.c_void_p), ("scale", C.c_void_p), ("out", C.c_void_p), ("rows", C.c_int32), ("rowlen", C.c_int32)]
 
 
+class RpnLevel(C.Structure):
+    """ttdg_rpn_level_t: one FPN level of the fused RPN selection."""
+    _fields_ = [("logits", C.c_void_p), ("deltas", C.c_void_p), ("anchors", C.c_void_p), ("H", C.c_int32), ("W", C.c_int32),
+                ("k", C.c_int32), ("col0", C.c_int32)]
+
+
 GEMM_GROUP_MAX = 8
 ROW_SCALE_MAX = 64
+RPN_LEVELS_MAX = 8
+RPN_SELECT_MAX_K = 2048
 _P, _I, _L, _F, _S = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_void_p
 
 # name -> (restype, argtypes); one entry per symbol declared in include/ttdg_mgm.h
@@ -99,6 +107,7 @@ SIGNATURES = {
     "ttdg_nms": (C.c_int, [_P, _P, _I, _F, _P, _P, _P, _S]),
     "ttdg_nms_grouped": (C.c_int, [_P, _P, _I, _I, _I, _F, _P, _P, _S]),
     "ttdg_rpn_decode": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _S]),
+    "ttdg_rpn_select": (C.c_int, [C.POINTER(RpnLevel), _I, _I, _I, _P, _I, _P, _P, _S]),
     "ttdg_box_inference": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _P, _P, _S]),
     "ttdg_roi_align_multilevel": (C.c_int, [Fpn, Levels, _P, _I, _I, _F, _I, _I, _P, _S]),
     "ttdg_debug_set_roi_align_sliced": (C.c_int, [_I]),

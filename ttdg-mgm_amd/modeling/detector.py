@@ -120,11 +120,7 @@ class PseudoLabRPN(nn.Module):
         # every candidate of the batch in two dense tensors; rejected ones carry score -inf (no compaction, no per-image loop)
         boxes = torch.empty(N, K, 4, device=dev, dtype=torch.float32)
         scores = torch.empty(N, K, device=dev, dtype=torch.float32)
-        col = 0
-        for lg, dl, an, k in zip(logits, deltas, anchors, ks):
-            sc, idx = lg.permute(0, 2, 3, 1).reshape(N, -1).topk(k, dim=1)
-            _backend.rpn_decode(dl, an, idx, sc.float(), sizes_t, boxes, scores, col)      # decode + clip + validity, fused
-            col += k
+        _backend.rpn_select(logits, deltas, anchors, ks, sizes_t, boxes, scores)      # per-level top-k + decode + clip + validity: one launch
         keep, counts = _backend.nms_batched(boxes, scores, lvl, L, self.nms_thresh, pre, post, device_counts=True, level_sizes=ks)
         return boxes, scores, keep, counts
 

@@ -783,6 +783,34 @@ def rpn_decode(deltas, anchors, idx, score, sizes_t, boxes, scores, col0):
          B, k, A4 // 4, H, W, boxes.shape[1], int(col0), ptr(boxes), ptr(scores), stream())
 
 
+RPN_SELECT = os.environ.get("TTDG_RPN_SELECT", "1") != "0"      # False = per level permute + torch.topk + rpn_decode (A/B)
+
+
+def rpn_select(logits, deltas, anchors, ks, sizes_t, boxes, scores):
+    """find_top_rpn_proposals [3P] up to the NMS for every level and image in ONE launch (csrc/detection.hip rpn_select_kernel):
+    logits[l] (B, A, H, W) / deltas[l] (B, 4A, H, W) as the head produces them, anchors[l] (H*W*A, 4); the ks[l] best logits of
+    every (image, level) in descending order, decoded + clipped + tested into their column block of boxes (B, K, 4) / scores
+    (B, K) (-inf = rejected, box zeroed).  Falls back to the per-level path for inputs the kernel does not take."""
+    B, A = logits[0].shape[0], logits[0].shape[1]
+    fused = RPN_SELECT and len(logits) <= _lib.RPN_LEVELS_MAX and max(ks) <= _lib.RPN_SELECT_MAX_K and \
+        all(t.dtype == torch.float32 and t.is_contiguous() for ts in (logits, deltas, anchors) for t in ts) and all(lg.shape[1] == A for lg in logits)
+    col = 0
+    if not fused:
+        for lg, dl, an, k in zip(logits, deltas, anchors, ks):
+            sc, idx = lg.permute(0, 2, 3, 1).reshape(B, -1).topk(k, dim=1)
+            rpn_decode(dl, an, idx, sc.float(), sizes_t, boxes, scores, col)
+            col += k
+        return
+    items = []
+    for lg, dl, an, k in zip(logits, deltas, anchors, ks):
+        it = _lib.RpnLevel()
+        it.logits, it.deltas, it.anchors = ptr(lg), ptr(dl), ptr(an)
+        it.H, it.W, it.k, it.col0 = lg.shape[2], lg.shape[3], int(k), col
+        items.append(it)
+        col += k
+    call("ttdg_rpn_select", (_lib.RpnLevel * len(items))(*items), len(items), B, A, ptr(sizes_t), boxes.shape[1], ptr(boxes), ptr(scores), stream())
+
+
 def _grouped_flags(bx, sc, gf, ngroups, max_group, thr):
     """keep mask (N,) of greedy NMS inside each group; group id == ngroups marks candidates that take no part."""
     N = sc.numel()
