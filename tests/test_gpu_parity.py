@@ -1337,6 +1337,75 @@ def test_multi_tensor_filter_fold_is_the_per_filter_multiply(dev):
     assert not torch.equal(res[True][3][2], res[True][2][2])
 
 
+def test_fused_bias_epilogues_of_fpn_rpn_head_and_mask_head(dev):
+    """modeling.backbone.FUSED_HEADS: the FPN's lateral / output convolutions apply bias (+ the top-down sum) through the
+    in-place epilogue kernel (ops.BiasAddFn when gradients flow), the RPN head runs without a tape inside the TTA step and the
+    mask head fuses bias + ReLU.  Same sums in the same order as conv-with-bias, add, relu: outputs and every gradient against
+    the plain torch formulation (vendor convolutions see identical operands; their own run-to-run rounding is the tolerance)."""
+    from ttdg_mgm_amd import ops
+    from ttdg_mgm_amd.modeling import backbone as bb
+    from ttdg_mgm_amd.modeling import detector as det
+    g = synth.gen(7430)
+    # BiasAddFn against torch, exactly
+    y0, r0, b0 = synth.normal(g, (2, 6, 8, 8), 1.0).to(dev), synth.normal(g, (2, 6, 8, 8), 1.0).to(dev), synth.normal(g, (6,), 1.0).to(dev)
+    up = synth.normal(g, (2, 6, 8, 8), 1.0).to(dev)
+    for with_res in (True, False):
+        y, r, b = y0.clone().requires_grad_(), r0.clone().requires_grad_(), b0.clone().requires_grad_()
+        out = ops.BiasAddFn.apply(y * 1.0, b, r * 1.0 if with_res else None)
+        (out * up).sum().backward()
+        y2, r2, b2 = y0.clone().requires_grad_(), r0.clone().requires_grad_(), b0.clone().requires_grad_()
+        ref = (y2 + b2.view(1, -1, 1, 1)) + r2 if with_res else y2 + b2.view(1, -1, 1, 1)
+        (ref * up).sum().backward()
+        assert torch.equal(out, ref) and torch.equal(y.grad, y2.grad) and maxerr(b.grad, b2.grad) <= 1e-5
+        assert (torch.equal(r.grad, r2.grad) if with_res else r.grad is None)
+    # the FPN on top of a fixed pyramid (the trunk is covered elsewhere): train-style pass and no-grad pass
+    torch.manual_seed(3)
+    fpn = bb.FPN(2).to(dev).train()
+    for m in fpn.modules():
+        if isinstance(m, torch.nn.Conv2d) and m.bias is not None:
+            m.bias.data.copy_(synth.normal(g, m.bias.shape, 0.5).to(dev))
+    x0 = synth.normal(g, (1, 3, 64, 64), 1.0).to(dev)
+    res = {}
+    for fused in (True, False):
+        bb.FUSED_HEADS = fused
+        try:
+            fpn.zero_grad(set_to_none=True)
+            outs = fpn(x0)
+            sum(v.square().mean() for v in outs.values()).backward()
+            grads = {n: p.grad.clone() for n, p in fpn.named_parameters() if p.grad is not None and n.startswith("fpn_")}
+            with torch.no_grad():
+                quiet = fpn(x0)
+            res[fused] = ({k: v.detach().clone() for k, v in outs.items()}, grads, {k: v.clone() for k, v in quiet.items()})
+        finally:
+            bb.FUSED_HEADS = True
+    assert len(res[True][1]) == len(res[False][1]) == 16
+    for k in res[False][0]:
+        sc_ = max(1.0, float(res[False][0][k].abs().max()))
+        assert maxerr(res[True][0][k], res[False][0][k]) <= 2e-5 * sc_ and maxerr(res[True][2][k], res[False][2][k]) <= 2e-5 * sc_, k
+    for n, gr in res[False][1].items():
+        assert maxerr(res[True][1][n], gr) <= 1e-4 * max(1e-30, float(gr.abs().max())), n
+    # mask head (inference only) and RPN head without a tape
+    torch.manual_seed(4)
+    mh, rh = det.MaskRCNNConvUpsampleHead(3).to(dev).eval(), det.RPNHead().to(dev)
+    for m in list(mh.modules()) + list(rh.modules()):
+        if getattr(m, "bias", None) is not None and isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+            m.bias.data.copy_(synth.normal(g, m.bias.shape, 0.5).to(dev))
+            m.weight.data.mul_(20.0 if m.weight.std() < 0.02 else 1.0)
+    xm = synth.normal(g, (5, 256, 14, 14), 1.0).to(dev)
+    feats = [synth.normal(g, (2, 256, s_, s_), 1.0).to(dev) for s_ in (16, 8)]
+    out = {}
+    for fused in (True, False):
+        bb.FUSED_HEADS = fused
+        try:
+            with torch.no_grad():
+                out[fused] = (mh(xm).clone(), [t.clone() for ts in rh(feats) for t in ts])
+        finally:
+            bb.FUSED_HEADS = True
+    assert out[True][0].shape == (5, 3, 28, 28) and maxerr(out[True][0], out[False][0]) <= 2e-5 * max(1.0, float(out[False][0].abs().max()))
+    for a, b in zip(out[True][1], out[False][1]):
+        assert maxerr(a, b) <= 2e-5 * max(1.0, float(b.abs().max()))
+
+
 def test_fused_epilogue_with_gradients_is_the_plain_torch_block(dev):
     """The adapted bottlenecks (gradients flow) take ops.BiasActFn - in-place shift / residual / ReLU with a one-pass backward.
     Same arithmetic in the same order as conv-with-bias, add, F.relu_: outputs, input gradient and every filter gradient must

@@ -102,7 +102,10 @@ class PseudoLabRPN(nn.Module):
         graph): candidates of the batch in dense tensors boxes (B, K, 4) / scores (B, K) (-inf = rejected), the kept
         indices (B, post) by descending score and their counts (B,) as a device tensor."""
         feats = [features[f].detach() for f in self.in_features]
-        logits, deltas = self.rpn_head(feats)
+        from . import backbone as _bb
+        # proposals carry no gradient (compute_loss=False, rpn.py:16-56): no tape, and the fused epilogues in the TTA step too
+        with torch.set_grad_enabled(torch.is_grad_enabled() and not _bb.FUSED_HEADS):
+            logits, deltas = self.rpn_head(feats)
         dev = feats[0].device
         anchors = self._anchors([f.shape[-2:] for f in feats], dev)
         N, L = feats[0].shape[0], len(feats)
@@ -198,6 +201,14 @@ class MaskRCNNConvUpsampleHead(nn.Module):
         nn.init.constant_(self.predictor.bias, 0)
 
     def forward(self, x):
+        from . import backbone as _bb
+        if _bb.FUSED_HEADS and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled():
+            # inference: every convolution's bias + ReLU in one in-place pass
+            for i in range(1, 5):
+                m = getattr(self, "mask_fcn%d" % i)
+                x = ops.bias_act_(F.conv2d(x, m.weight, None, 1, 1), m.bias)
+            x = ops.bias_act_(F.conv_transpose2d(x, self.deconv.weight, None, 2), self.deconv.bias)
+            return self.predictor(x)
         for i in range(1, 5):
             x = F.relu(getattr(self, "mask_fcn%d" % i)(x))
         return self.predictor(F.relu(self.deconv(x)))

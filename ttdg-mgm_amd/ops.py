@@ -743,6 +743,24 @@ class BiasActFn(torch.autograd.Function):
         return gin, None, (gin if ctx.has_res else None), None
 
 
+class BiasAddFn(torch.autograd.Function):
+    """(y + bias[c]) + residual IN PLACE on a convolution output, with gradients: the bias of the FPN's lateral / output
+    convolutions (and the top-down sum) in one vectorised pass instead of torch's broadcast add_ (+ add).  Backward: the
+    gradient passes through to y and the residual unchanged, the bias gets its sum over (N, H, W)."""
+
+    @staticmethod
+    def forward(ctx, y, bias, residual):
+        bias_act_(y, bias, residual, None, relu=False)
+        ctx.mark_dirty(y)
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gout):
+        gb = gout.sum((0, 2, 3)) if ctx.needs_input_grad[1] else None
+        return gout, gb, (gout if ctx.has_res else None)
+
+
 def resize_u8(img, oh, ow):
     """(..., H, W) uint8 on the device -> (..., oh, ow) uint8: the test mapper's bilinear resize (antialiased when shrinking),
     bit-compatible with data.map_for_test to <= 1 LSB (csrc/resize.hip)."""
