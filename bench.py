@@ -82,6 +82,8 @@ def parse(argv=None):
     ap.add_argument("--no-miopen-db", action="store_true", help="A/B: ignore the tuned MIOpen find-db shipped in ttdg-mgm_amd/miopen_db (MIOpen's heuristic picks the solvers)")
     ap.add_argument("--miopen-search", action="store_true", help="tuning run: torch.backends.cudnn.benchmark = True, i.e. MIOpen times its solvers for every "
                     "convolution shape it meets (minutes) and records the winners in its user find-db (MIOPEN_USER_DB_PATH)")
+    ap.add_argument("--sync-debug", default="", help="debug: after the headline pass, repeat it with torch.cuda.set_sync_debug_mode('warn') and write the "
+                    "host-synchronising call sites (file:line inside the package, counts per adapted batch) to this path")
     ap.add_argument("--torch-profile", default="", help="debug: after the headline pass, repeat it under torch.profiler and write the per-operator table to this path")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch, rendezvous, sharding and the collectives of the bench without any GPU work (CPU test of --gpus N)")
@@ -564,6 +566,31 @@ def gpu_main(args, rank, world, local):
     tf = bool(args.teacher_forced)
     main = timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, world, device, tf)
     note("headline pass done: %.1f images/s" % (world * K * B / main["elapsed"]))
+    if args.sync_debug and world == 1:
+        import collections
+        import traceback
+        import warnings
+        sites = collections.Counter()
+
+        def record(message, category, filename, lineno, file=None, line=None):
+            if "synchron" not in str(message):
+                return
+            frames = [f for f in traceback.extract_stack() if (os.sep + "ttdg-mgm_amd" + os.sep in f.filename or f.filename.endswith("bench.py")) and f.name != "record"]
+            where = " <- ".join("%s:%d %s" % (os.path.relpath(f.filename, ROOT), f.lineno, f.name) for f in reversed(frames[-3:]))
+            sites[(where, str(message).split("\n")[0][:80])] += 1
+        old_show = warnings.showwarning
+        warnings.showwarning = record
+        warnings.simplefilter("always")
+        torch.cuda.set_sync_debug_mode("warn")
+        try:
+            timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, world, device, tf)
+        finally:
+            torch.cuda.set_sync_debug_mode("default")
+            warnings.showwarning = old_show
+        with open(args.sync_debug, "w") as f:
+            f.write("# host-synchronising calls over W=%d warm-up + K=%d adapted batches (TTA steps, then the Dice pass), torch.cuda.set_sync_debug_mode('warn')\n" % (W, K))
+            for (where, msg), n in sites.most_common():
+                f.write("%6d  (%.1f / batch)  %s   [%s]\n" % (n, n / (W + K), where, msg))
     if args.torch_profile and world == 1:
         from torch.profiler import ProfilerActivity, profile
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:

@@ -349,6 +349,11 @@ int ttdg_debug_set_pair_stage_profile(void* device_buffer);
  * in float64); one launch covers every kept prediction of an eval batch.  Zeroes `counts` itself. */
 int ttdg_mask_pair_counts(const unsigned long long* pred, const unsigned long long* gt, const int32_t* cy, const int32_t* cx,
                           int npairs, int H, int W, int32_t* counts, ttdg_stream_t stream);
+/* The closed forms themselves (dice_metric.py:54-66, :110-143, :147-240 for boolean maps), float64, one thread per pair, and the
+ * maximum over the same-class ground truths of a prediction (:76-92): best[owner[i]][{0,1,2}] = max(best, 100 * {Dice, E, S}_i).
+ * best (npred, 3) doubles must be zero-initialised (a prediction without a same-class ground truth scores 0). */
+int ttdg_mask_measures(const int32_t* counts, const int32_t* cy, const int32_t* cx, const int32_t* owner, int npairs, int H, int W,
+                       double alpha, double* best, ttdg_stream_t stream);
 
 #ifdef __cplusplus
 }

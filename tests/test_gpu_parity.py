@@ -1624,6 +1624,48 @@ def test_mask_pair_counts_kernel_exact(dev, H, W):
         assert row == quadrant_counts(P[a], G[b], cy, cx), (a, b, cy, cx)
 
 
+@pytest.mark.parametrize("H,W", [(96, 80), (33, 17), (512, 512)])
+def test_mask_measures_kernel_equals_the_float64_closed_forms(dev, H, W):
+    """ttdg_mask_measures (float64 closed forms of Dice / E-measure / S-measure from the twelve counts + the maximum over a
+    prediction's same-class ground truths, one thread per pair) against evaluation.measures_from_counts on the SAME counts
+    (torch float64 on the CPU - itself held to dice_metric.py's numpy functions by tests/test_host.py): to 1e-12 relative.
+    Edge cases: empty prediction, empty / full ground truth, cuts at 0, at the border and beyond it, one-pixel quadrants,
+    a prediction with three ground truths (maximum), a prediction with none (stays 0)."""
+    from ttdg_mgm_amd import ops
+    from ttdg_mgm_amd.evaluation import measures_from_counts
+    g = synth.gen(H * 77 + W)
+    P = torch.from_numpy(g.uniform(size=(6, H, W)) < 0.4)
+    G = torch.from_numpy(g.uniform(size=(5, H, W)) < 0.6)
+    P[4] = False                                   # empty prediction
+    G[3], G[4] = False, True                       # empty and full ground truth
+    yy, xx = np.mgrid[0:H, 0:W]
+    P[5] = torch.from_numpy((yy - H / 2) ** 2 + (xx - W / 2) ** 2 < (min(H, W) / 3) ** 2)      # a disc against ...
+    G[2] = torch.from_numpy((yy - H / 2 - 2) ** 2 + (xx - W / 2 + 1) ** 2 < (min(H, W) / 3) ** 2)      # ... a shifted disc (high scores)
+    Pd, Gd = P.to(dev).contiguous(), G.to(dev).contiguous()
+    # (prediction, ground truth, cy, cx, owner)
+    pairs = [(0, 0, 0, 0, 0), (1, 1, H, W, 1), (2, 2, H // 2, W // 2, 2), (3, 0, min(H, 5), min(W, 3), 3), (4, 1, 1, 1, 4), (0, 3, H - 1, W - 1, 5),
+             (1, 4, H // 3, W // 3, 6), (5, 2, H // 2, W // 2, 7), (5, 0, H // 2 + 1, W // 2, 7), (5, 1, 1, W, 7), (4, 3, H + 3, W + 9, 8), (2, 4, H, 0, 9)]
+    npred = 11                                     # owner 10 has no pair
+    best = torch.zeros(npred, 3, dtype=torch.float64, device=dev)
+    counts = ops.mask_pair_measures([Pd[a].data_ptr() for a, *_ in pairs], [Gd[b].data_ptr() for _, b, *_ in pairs], [p[2] for p in pairs],
+                                    [p[3] for p in pairs], [p[4] for p in pairs], H, W, best)
+    want = measures_from_counts(counts.cpu(), H, W, [p[2] for p in pairs], [p[3] for p in pairs]) * 100
+    ref = torch.zeros(npred, 3, dtype=torch.float64)
+    for row, p in zip(want, pairs):
+        ref[p[4]] = torch.maximum(ref[p[4]], row)
+    got = best.cpu()
+    assert float(got[10].abs().max()) == 0.0
+    assert float(got[7, 0]) > 60.0                                                             # the two discs
+    # a one-pixel quadrant (cut at row 1 / column 1) has no sample covariance: NaN in the reference's S-measure, in the host
+    # statement and - propagated through the maximum, as torch.maximum does - on the device
+    assert torch.equal(torch.isnan(got), torch.isnan(ref)) and bool(torch.isnan(ref[4, 2])) and int(torch.isnan(ref).sum()) <= 2
+    ok = ~torch.isnan(ref)
+    err = (got[ok] - ref[ok]).abs() / ref[ok].abs().clamp(min=1.0)
+    assert float(err.max()) <= 1e-12, (err.max(), got, ref)
+    with pytest.raises(TypeError):
+        ops.mask_pair_measures([Pd[0].data_ptr()], [Gd[0].data_ptr()], [1], [1], [0], H, W, torch.zeros(1, 3, device=dev))
+
+
 # ------------------------------------------------------------------------------------------- N4: loader on the device
 @pytest.mark.parametrize("shape,min_size,max_size", [((3, 512, 512), 800, 1333), ((3, 384, 384), 384, 1333), ((3, 640, 480), 320, 1333),
                                                      ((3, 300, 500), 800, 1333), ((1, 97, 131), 211, 260), ((3, 800, 800), 511, 1333)])

@@ -121,6 +121,7 @@ SIGNATURES = {
     "ttdg_relu_bwd": (C.c_int, [_P, _P, _P, C.c_size_t, _S]),
     "ttdg_paste_masks": (C.c_int, [_P, _P, _I, _I, _I, _I, _F, _P, _S]),
     "ttdg_mask_pair_counts": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _S]),
+    "ttdg_mask_measures": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, C.c_double, _P, _S]),
 }
 
 _lib = None

@@ -80,3 +80,80 @@ extern "C" int ttdg_mask_pair_counts(const unsigned long long* pred, const unsig
   hipLaunchKernelGGL(mask_pair_counts_kernel, grid, dim3(EV_THREADS), 0, st, pred, gt, cy, cx, H, W, counts);
   return ttdg_launch_status("mask_pair_counts");
 }
+
+// ---- the closed forms, on the device too ------------------------------------------------------------------------------------
+// Dice (dice_metric.py:54-66), E-measure (:110-143) and S-measure (:147-240) of one BOOLEAN pair from its twelve counts, in
+// float64, one thread per pair - the arithmetic of evaluation/__init__.py:measures_from_counts term by term (which stays as the
+// host-side statement the tests compare against).  As ~150 tiny float64 torch launches per batch this was 2 % of an adapted
+// batch's launches for a few hundred flops.  best[owner[pair]][0..2] <- max(best, 100 x measure): the maximum over the same-class
+// ground truths of a prediction (dice_metric.py:76-92); the measures are >= 0, so the maximum of doubles is the maximum of their
+// bit patterns (one 64-bit integer atomic; order independent, hence deterministic).
+__device__ __forceinline__ double ev_val(double f, double g, double mf, double mg) {
+  const double af = f - mf, ag = g - mg;
+  const double t = (2.0 * (ag * af) / (ag * ag + af * af + 1e-8)) + 1.0;
+  return t * t / 4.0;
+}
+__device__ __forceinline__ double ev_s_object(double hit, double cnt) {
+  const double x = hit / cnt;
+  const double sig = sqrt((hit * ((1.0 - x) * (1.0 - x)) + (cnt - hit) * x * x) / cnt);
+  return 2.0 * x / (x * x + 1.0 + sig + 1e-8);
+}
+
+__global__ __launch_bounds__(64) void mask_measures_kernel(const int* __restrict__ counts, const int* __restrict__ cy_,
+                                                           const int* __restrict__ cx_, const int* __restrict__ owner, int n, int H,
+                                                           int W, double alpha, double* __restrict__ best) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  double c[4][3];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) c[q][k] = (double)counts[(size_t)i * 12 + q * 3 + k];
+  const double N = (double)H * (double)W;
+  const double n11 = ((c[0][0] + c[1][0]) + c[2][0]) + c[3][0];
+  const double npd = ((c[0][1] + c[1][1]) + c[2][1]) + c[3][1];
+  const double ng = ((c[0][2] + c[1][2]) + c[2][2]) + c[3][2];
+  const double dice = 2.0 * n11 / (npd + ng + 1e-6);
+  // E-measure: fm = p, or all ones when the prediction is empty
+  const double nf = npd == 0.0 ? N : npd, n11f = npd == 0.0 ? ng : n11;
+  const double mf = nf / N, mg = ng / N;
+  const double general = n11f * ev_val(1.0, 1.0, mf, mg) + (nf - n11f) * ev_val(1.0, 0.0, mf, mg) + (ng - n11f) * ev_val(0.0, 1.0, mf, mg) +
+                         (N - nf - ng + n11f) * ev_val(0.0, 0.0, mf, mg);
+  const double em = (ng == 0.0 ? N - nf : (ng == N ? nf : general)) / (N - 1.0 + 1e-8);
+  // S-measure: object term from the totals, region term from the quadrants
+  const double y = ng / N;
+  const double obj = y * ev_s_object(n11, ng) + (1.0 - y) * ev_s_object(N - npd - ng + n11, N - ng);
+  const double cy = fmin(fmax((double)cy_[i], 0.0), (double)H), cx = fmin(fmax((double)cx_[i], 0.0), (double)W);
+  const double areas[4] = {cy * cx, cy * (W - cx), (H - cy) * cx, (H - cy) * (W - cx)};
+  double reg = 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const double a = fmax(areas[q], 1.0);
+    const double x = c[q][1] / a, yq = c[q][2] / a;
+    const double sx = x * (1.0 - x), sy = yq * (1.0 - yq);
+    const double sxy = areas[q] > 1.0 ? (c[q][0] - a * x * yq) / fmax(a - 1.0, 1.0) : nan("");
+    const double al = 4.0 * x * yq * sxy, be = (x * x + yq * yq) * (sx + sy);
+    const double ssim = al != 0.0 ? al / (be + 1e-8) : (be == 0.0 ? 1.0 : 0.0);
+    reg += areas[q] > 0.0 ? areas[q] / N * ssim : 0.0;
+  }
+  const double sm = y == 0.0 ? 1.0 - npd / N : (y == 1.0 ? npd / N : alpha * obj + (1.0 - alpha) * reg);
+  const double v[3] = {dice * 100.0, em * 100.0, sm * 100.0};
+  unsigned long long* row = reinterpret_cast<unsigned long long*>(best + (size_t)owner[i] * 3);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    // a one-pixel quadrant has no sample covariance: the reference's S-measure is NaN there, and torch.maximum propagates it - so
+    // does this: the pattern of a positive quiet NaN is above every finite double's
+    if (isnan(v[k])) atomicMax(row + k, 0x7FF8000000000000ull);
+    else if (v[k] > 0.0) atomicMax(row + k, (unsigned long long)__double_as_longlong(v[k]));
+  }
+}
+
+extern "C" int ttdg_mask_measures(const int32_t* counts, const int32_t* cy, const int32_t* cx, const int32_t* owner, int npairs,
+                                  int H, int W, double alpha, double* best, ttdg_stream_t stream) {
+  TTDG_REQUIRE(npairs >= 0 && H > 0 && W > 0, "mask_measures: bad sizes");
+  if (npairs == 0) return 0;
+  TTDG_REQUIRE(counts && cy && cx && owner && best, "mask_measures: null pointer");
+  hipLaunchKernelGGL(mask_measures_kernel, dim3((npairs + 63) / 64), dim3(64), 0, (hipStream_t)stream, counts, cy, cx, owner, npairs, H, W,
+                     alpha, best);
+  return ttdg_launch_status("mask_measures");
+}

@@ -110,7 +110,9 @@ class TestLoader:
         # streaming to a GPU: upload the RAW uint8 image and resize there (csrc/resize.hip) unless told otherwise
         self.device_resize = (cuda and not resident) if device_resize is None else bool(device_resize and cuda)
         self._disk = None
-        self.stage_in_thread = os.environ.get("TTDG_STAGE_THREAD", "1") != "0"      # disk streams: stage (pin + H2D + resize) on a helper thread
+        # disk streams: stage (DMA from the ring + resize launch) from the consumer's own thread one batch ahead (default), or on a helper
+        # thread (TTDG_STAGE_THREAD=1).  Measured back to back on the final build: 0.932 / 0.950 x the resident rate against 0.902 / 0.940
+        self.stage_in_thread = os.environ.get("TTDG_STAGE_THREAD", "0") != "0"
         if not resident and _REGISTRY[name]["kind"] == "disk":
             from . import disk
             spec = _REGISTRY[name]

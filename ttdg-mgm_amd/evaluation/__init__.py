@@ -2,8 +2,15 @@
 absent), reductions on the device: per predicted mask with score >= thres, best Dice / E-measure / S-measure over
 the same-class GT masks, x100, mean over all kept masks.  Like the reference it is rank-local; ``gather_scores``
 adds the all-gather the reference omits (SURVEY.md §8e Mode R)."""
+import os
+
 import numpy as np
 import torch
+
+# the float64 closed forms of Dice / E / S run in ONE small HIP kernel after the count kernel (ops.mask_pair_measures);
+# TTDG_DEVICE_MEASURES=0 evaluates them with torch tensor operations instead (measures_from_counts: ~150 tiny launches per batch;
+# the statement the kernel is tested against)
+DEVICE_MEASURES = os.environ.get("TTDG_DEVICE_MEASURES", "1") != "0"
 
 
 # All three measures are written without host synchronisation (no .item(), no Python branch on a device value):
@@ -282,15 +289,18 @@ class DiceEvaluator:
         for (H, W), grp in groups.items():
             if not grp["pp"]:
                 continue
+            if DEVICE_MEASURES:      # counts, closed forms (x 100) and the maximum over the same-class GTs: two launches
+                ops.mask_pair_measures(grp["pp"], grp["gp"], grp["cy"], grp["cx"], grp["owner"], H, W, best)
+                continue
             counts = ops.mask_pair_counts(grp["pp"], grp["gp"], grp["cy"], grp["cx"], H, W, dev)
-            vals = measures_from_counts(counts, H, W, grp["cy"], grp["cx"])
+            vals = measures_from_counts(counts, H, W, grp["cy"], grp["cx"]) * 100
             owner = torch.tensor(grp["owner"], dtype=torch.int64).to(dev, non_blocking=True)
             for r in range(max(grp["rank"]) + 1):                              # usually one GT per class: a single pass
                 idx = [i for i, x in enumerate(grp["rank"]) if x == r]
                 it = owner if len(idx) == len(grp["rank"]) else owner[torch.tensor(idx, dtype=torch.int64).to(dev, non_blocking=True)]
                 vr = vals if len(idx) == len(grp["rank"]) else vals[torch.tensor(idx, dtype=torch.int64).to(dev, non_blocking=True)]
                 best[it] = torch.maximum(best[it], vr)
-        self._pending.append(best * 100)
+        self._pending.append(best)
 
     def _flush(self):
         if self._pending:

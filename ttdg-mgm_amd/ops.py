@@ -970,6 +970,23 @@ def mask_pair_counts(pred_ptrs, gt_ptrs, cy, cx, H, W, device):
     return counts
 
 
+def mask_pair_measures(pred_ptrs, gt_ptrs, cy, cx, owner, H, W, best, alpha=0.5):
+    """mask_pair_counts + the float64 closed forms + the maximum over a prediction's same-class ground truths, on the device:
+    best[owner[i]] = max(best[owner[i]], 100 * (Dice, E-measure, S-measure) of pair i); ``best`` (npred, 3) float64, zero-initialised
+    by the caller.  Two launches and two small table uploads for all pairs of one mask size.  Returns the (npairs, 12) counts."""
+    n = len(pred_ptrs)
+    counts = torch.empty(n, 12, device=best.device, dtype=torch.int32)
+    if n == 0:
+        return counts
+    if best.dtype != torch.float64 or not best.is_contiguous() or best.shape[1] != 3:
+        raise TypeError("mask_pair_measures: best must be a contiguous (npred, 3) float64 tensor")
+    table = torch.tensor([pred_ptrs, gt_ptrs], dtype=torch.int64).to(best.device, non_blocking=True)
+    cuts = torch.tensor([cy, cx, owner], dtype=torch.int32).to(best.device, non_blocking=True)
+    call("ttdg_mask_pair_counts", ptr(table), ptr(table) + 8 * n, ptr(cuts), ptr(cuts) + 4 * n, n, int(H), int(W), ptr(counts), stream())
+    call("ttdg_mask_measures", ptr(counts), ptr(cuts), ptr(cuts) + 4 * n, ptr(cuts) + 8 * n, n, int(H), int(W), float(alpha), ptr(best), stream())
+    return counts
+
+
 def nms(boxes, scores, thr, group=None):
     """Greedy NMS; returns kept indices (into the input order) sorted by descending score."""
     ng = None if group is None else int(group.max().item()) + 1 if group.numel() else 1
