@@ -18,5 +18,35 @@ __version__ = "0.1.0"
 # Text files keyed by device (gfx950, 256 CUs) and MIOpen version: ignored on anything else.  TTDG_MIOPEN_DB=0 (or a
 # MIOPEN_USER_DB_PATH of your own) turns it off.  Must be set before the first convolution.
 MIOPEN_DB = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "miopen_db")
+
+
+def _stage_miopen_db():
+    """MIOpen also WRITES to its user db directory (records for shapes it meets, lock and time-stamp files): give it a private
+    copy under the temp directory - named after the content, so a new db in the tree is picked up - and keep the tree clean
+    (and usable from a read-only checkout).  Several ranks may race here: every file appears by an atomic rename."""
+    import hashlib
+    import shutil
+    import tempfile
+    files = sorted(f for f in _os.listdir(MIOPEN_DB) if f.endswith(".txt"))
+    if not files:
+        return None
+    h = hashlib.sha1()
+    for f in files:
+        with open(_os.path.join(MIOPEN_DB, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    dst = _os.path.join(tempfile.gettempdir(), "ttdg_miopen_db_%d_%s_miopen_db" % (_os.getuid(), h.hexdigest()[:12]))
+    _os.makedirs(dst, exist_ok=True)
+    for f in files:
+        d = _os.path.join(dst, f)
+        if not _os.path.exists(d):
+            tmp = "%s.%d.tmp" % (d, _os.getpid())
+            shutil.copyfile(_os.path.join(MIOPEN_DB, f), tmp)
+            _os.replace(tmp, d)
+    return dst
+
+
 if _os.environ.get("TTDG_MIOPEN_DB", "1") != "0" and "MIOPEN_USER_DB_PATH" not in _os.environ and _os.path.isdir(MIOPEN_DB):
-    _os.environ["MIOPEN_USER_DB_PATH"] = MIOPEN_DB
+    try:
+        _os.environ["MIOPEN_USER_DB_PATH"] = _stage_miopen_db() or MIOPEN_DB
+    except OSError:
+        _os.environ["MIOPEN_USER_DB_PATH"] = MIOPEN_DB
