@@ -228,6 +228,10 @@ int ttdg_node_gather_fwd(ttdg_fpn_t fp, const int32_t* img, const int32_t* pid, 
                          ttdg_stream_t stream);
 int ttdg_node_gather_bwd(ttdg_fpn_t dfp, const int32_t* img, const int32_t* pid, int n, const float* dout,
                          ttdg_stream_t stream);
+/* the same on channels-last maps: fp.feat[l] is (B, H_l, W_l, C) contiguous (the layout the backbone runs in) */
+int ttdg_node_gather_fwd_nhwc(ttdg_fpn_t fp, const int32_t* img, const int32_t* pid, int n, float* out, ttdg_stream_t stream);
+int ttdg_node_gather_bwd_nhwc(ttdg_fpn_t dfp, const int32_t* img, const int32_t* pid, int n, const float* dout,
+                              ttdg_stream_t stream);
 
 /* ---- A11 fused multi-tensor SGD (torch.optim.SGD as built by detectron2 [3P];
  *      engine/trainer.py:480-482) ---------------------------------------------------
@@ -306,6 +310,9 @@ int ttdg_paste_masks(const float* masks, const float* boxes, int R, int S, int H
  * ReLU of a bottleneck in one pass. */
 int ttdg_bias_act(float* y, const float* bias, const float* residual, const float* bias2, int N, int C, int HW,
                   int relu, ttdg_stream_t stream);
+/* the same epilogue on a channels-last activation: y (rows, C) with rows = N*H*W, C % 4 == 0, 16-byte aligned pointers */
+int ttdg_bias_act_nhwc(float* y, const float* bias, const float* residual, const float* bias2, int64_t rows, int C, int relu,
+                       ttdg_stream_t stream);
 /* backward of that epilogue with relu != 0: gin[e] = out[e] > 0 ? gout[e] : 0 over `total` floats (torch threshold_backward
  * behind F.relu_, one pass; the result is the gradient of both the convolution output and the residual branch). */
 int ttdg_relu_bwd(const float* gout, const float* out, float* gin, size_t total, ttdg_stream_t stream);

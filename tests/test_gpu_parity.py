@@ -1337,6 +1337,113 @@ def test_multi_tensor_filter_fold_is_the_per_filter_multiply(dev):
     assert not torch.equal(res[True][3][2], res[True][2][2])
 
 
+def test_channels_last_layout_is_the_same_arithmetic(dev):
+    """The backbone runs in channels-last memory (modeling.backbone.CHANNELS_LAST).  Every kernel behind it on an (N, H, W, C)
+    activation against the NCHW form of the same operator, exactly (layout changes addresses, not sums): bias_act_ with bias /
+    residual / second bias / ReLU (vector body and tail sizes), BiasActFn + relu_bwd, the multi-tensor filter fold on
+    (O, kh, kw, I) filters, the node gather / scatter, the pooler fed channels-last maps.  Then ResNet-50 + FPN as a whole in both
+    layouts: outputs and filter gradients to the vendor convolutions' accuracy (the two layouts run different MIOpen solvers),
+    gradient strides matching the filters', and the fused SGD step applied to channels-last parameters."""
+    from ttdg_mgm_amd import ops
+    from ttdg_mgm_amd.modeling import backbone as bb
+    from ttdg_mgm_amd.optim import FusedSGD
+    g = synth.gen(7440)
+    CL = torch.channels_last
+    for shape in ((2, 8, 12, 12), (3, 64, 5, 7), (1, 256, 50, 50), (5, 4, 1, 3)):
+        y, r = synth.normal(g, shape, 1.0).to(dev), synth.normal(g, shape, 1.0).to(dev)
+        b, b2 = synth.normal(g, (shape[1],), 1.0).to(dev), synth.normal(g, (shape[1],), 1.0).to(dev)
+        for args in ((b, r, b2, True), (b, None, None, True), (b, r, None, False), (None, r, b2, True), (b, None, None, False)):
+            bb_, rr, b2_, relu = args
+            want = ops.bias_act_(y.clone(), bb_, rr, b2_, relu=relu)
+            ycl = y.clone().contiguous(memory_format=CL)
+            got = ops.bias_act_(ycl, bb_, None if rr is None else rr.contiguous(memory_format=CL), b2_, relu=relu)
+            assert got.data_ptr() == ycl.data_ptr() and (ops.is_channels_last(got) or min(shape[1], shape[2] * shape[3]) == 1)
+            assert torch.equal(got, want), (shape, relu)
+        # with gradients
+        res = {}
+        for cl in (False, True):
+            fmt = CL if cl else torch.contiguous_format
+            y0, r0 = y.clone().contiguous(memory_format=fmt).requires_grad_(), r.clone().contiguous(memory_format=fmt).requires_grad_()
+            out = ops.BiasActFn.apply((y0 * 1.0).contiguous(memory_format=fmt), b, (r0 * 1.0).contiguous(memory_format=fmt), b2)
+            (out * r).sum().backward()
+            res[cl] = (out.detach().clone(), y0.grad.clone(), r0.grad.clone())
+        for a, c in zip(res[True], res[False]):
+            assert torch.equal(a, c)
+    with pytest.raises(ValueError):
+        ops.bias_act_(y.clone().contiguous(memory_format=CL), b, r)                # residual in the other layout
+    # filter fold on channels-last filters
+    ws = [synth.normal(g, sh, 1.0).to(dev) for sh in ((8, 4, 3, 3), (16, 64, 1, 1), (12, 8, 7, 7))]
+    sc = [synth.normal(g, (w.shape[0],), 1.0).to(dev) for w in ws]
+    outs = ops.row_scale_multi([w.contiguous(memory_format=CL) for w in ws], sc)
+    for w, s_, o in zip(ws, sc, outs):
+        assert torch.equal(o, w * s_.view(-1, 1, 1, 1)) and o.is_contiguous(memory_format=CL)
+    # node gather / scatter
+    feats = [synth.normal(g, (2, 16, s_, s_ + 1), 1.0).to(dev) for s_ in (8, 4)]
+    img = torch.tensor([0, 1, 1, 0, 1], dtype=torch.int32, device=dev)
+    pid = torch.tensor([5, 70, (1 << 28) | 3, (1 << 28) | 19, 0], dtype=torch.int32, device=dev)
+    up = synth.normal(g, (5, 16), 1.0).to(dev)
+    res = {}
+    for cl in (False, True):
+        fs = [f.clone().contiguous(memory_format=CL if cl else torch.contiguous_format).requires_grad_() for f in feats]
+        rows = ops.NodeGatherFn.apply(img, pid, *fs)
+        (rows * up).sum().backward()
+        res[cl] = (rows.detach().clone(), [f.grad.clone() for f in fs], [f.grad.is_contiguous(memory_format=CL) for f in fs])
+    assert torch.equal(res[True][0], res[False][0]) and all(torch.equal(a, c) for a, c in zip(res[True][1], res[False][1])) and all(res[True][2])
+    # pooler: channels-last maps are used as they are
+    maps = [synth.normal(g, (2, 32, 16 // k, 16 // k), 1.0).to(dev) for k in (1, 2)]
+    rois = torch.tensor([[0, 1.0, 2.0, 30.0, 40.0], [1, 5.0, 5.0, 20.0, 12.0], [1, 0.0, 0.0, 63.0, 63.0]], device=dev)
+    a = ops.roi_align_multilevel(maps, rois, [4, 8], 7, nhwc=ops.to_nhwc(maps))
+    mcl = [m.contiguous(memory_format=CL) for m in maps]
+    views = ops.to_nhwc(mcl)
+    assert all(v.data_ptr() == m.data_ptr() for v, m in zip(views, mcl))
+    assert torch.equal(ops.roi_align_multilevel(mcl, rois, [4, 8], 7, nhwc=views), a)
+
+    # the whole trunk + FPN in both layouts
+    torch.manual_seed(5)
+    x0 = synth.normal(g, (2, 3, 64, 96), 1.0).to(dev)
+    res = {}
+    keep = bb.CHANNELS_LAST
+    for cl in (False, True):
+        bb.CHANNELS_LAST = cl
+        try:
+            torch.manual_seed(6)
+            net = bb.FPN(2).to(dev).train()
+            for m in net.modules():
+                if isinstance(m, bb.FrozenBatchNorm2d):
+                    m.weight.copy_(1.0 + 0.1 * torch.sin(torch.arange(m.weight.numel(), device=dev).float()))
+                    m.running_mean.copy_(0.1 * torch.cos(torch.arange(m.weight.numel(), device=dev).float()))
+            outs = net(x0)
+            sum(v.square().mean() for v in outs.values()).backward()
+            w = net.bottom_up.res4[0].conv2.weight
+            assert w.is_contiguous(memory_format=CL) == cl or not cl
+            if cl:
+                assert ops.is_channels_last(outs["p3"]) and ops.is_channels_last(w) and w.grad.stride() == w.stride()
+            grads = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+            with torch.no_grad():
+                quiet = net(x0)
+            opt = FusedSGD([p for p in net.parameters() if p.requires_grad], lr=0.01, momentum=0.9, weight_decay=1e-4)
+            before = {n: p.detach().clone() for n, p in net.named_parameters()}
+            opt.step()
+            moved = {n: (p.detach() - before[n]) for n, p in net.named_parameters() if p.grad is not None}
+            res[cl] = ({k: v.detach().clone() for k, v in outs.items()}, grads, moved, {k: v.clone() for k, v in quiet.items()})
+        finally:
+            bb.CHANNELS_LAST = keep
+    for k in res[False][0]:
+        sc_ = max(1.0, float(res[False][0][k].abs().max()))
+        assert maxerr(res[True][0][k], res[False][0][k]) <= 2e-4 * sc_ and maxerr(res[True][3][k], res[False][3][k]) <= 2e-4 * sc_, k
+    assert len(res[True][1]) == len(res[False][1]) > 50
+    # gradients of a randomly initialised 50-layer trunk amplify the rounding of the first layers: the two layouts (different
+    # MIOpen solvers in every convolution) are compared in the Frobenius norm, and entry-wise against the largest entry
+    worst = (0.0, None)
+    for n, gr in res[False][1].items():
+        rel = float((res[True][1][n] - gr).norm()) / max(1e-30, float(gr.norm()))
+        worst = max(worst, (rel, n))
+        assert rel <= 2e-2 and maxerr(res[True][1][n], gr) <= 5e-2 * max(1e-30, float(gr.abs().max())), (n, rel)
+        mv = res[False][2][n]                                                                   # first SGD step: -lr * (g + wd p)
+        assert float((res[True][2][n] - mv).norm()) <= 2e-2 * max(1e-30, float(mv.norm())), n
+    print("channels-last vs NCHW trunk: worst relative gradient difference %.2e (%s)" % worst)
+
+
 def test_fused_bias_epilogues_of_fpn_rpn_head_and_mask_head(dev):
     """modeling.backbone.FUSED_HEADS: the FPN's lateral / output convolutions apply bias (+ the top-down sum) through the
     in-place epilogue kernel (ops.BiasAddFn when gradients flow), the RPN head runs without a tape inside the TTA step and the

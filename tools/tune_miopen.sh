@@ -12,7 +12,8 @@ set -u
 export TMPDIR=/tmp
 OUT=${1:-gpurun_out/miopen_db}
 mkdir -p "$OUT"
-python bench.py --steps 2 --warmup 1 --no-ab --no-cpu-baseline --no-miopen-db > /dev/null 2>&1      # fits / caches the checkpoint outside the search
+cp -n ttdg-mgm_amd/miopen_db/*.txt "$OUT"/ 2>/dev/null      # keep the records already shipped (MIOpen appends: both memory layouts stay covered)
+python bench.py --steps 2 --warmup 1 --no-ab --no-cpu-baseline > /dev/null 2>&1      # fits / caches the checkpoint outside the search
 S=$(date +%s)
 MIOPEN_USER_DB_PATH=$PWD/$OUT timeout 1800 python bench.py --miopen-search --steps 4 --warmup 2 --no-ab --no-cpu-baseline > "$OUT/search_bench.json" 2> "$OUT/search.err"
 echo "search rc=$? took $(( $(date +%s) - S )) s"

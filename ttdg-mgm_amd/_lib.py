@@ -102,6 +102,8 @@ SIGNATURES = {
     "ttdg_node_select": (C.c_int, [_P, _I, Levels, _I, _I, _P, _P, _P, _S]),
     "ttdg_node_gather_fwd": (C.c_int, [Fpn, _P, _P, _I, _P, _S]),
     "ttdg_node_gather_bwd": (C.c_int, [Fpn, _P, _P, _I, _P, _S]),
+    "ttdg_node_gather_fwd_nhwc": (C.c_int, [Fpn, _P, _P, _I, _P, _S]),
+    "ttdg_node_gather_bwd_nhwc": (C.c_int, [Fpn, _P, _P, _I, _P, _S]),
     "ttdg_sgd_multi_tensor": (C.c_int, [_P, _P, _P, _I, _I, _F, _F, _S]),
     "ttdg_roi_align_fwd": (C.c_int, [_P, _I, _I, _I, _I, _P, _I, _F, _I, _P, _S]),
     "ttdg_nms": (C.c_int, [_P, _P, _I, _F, _P, _P, _P, _S]),
@@ -118,6 +120,7 @@ SIGNATURES = {
     "ttdg_nchw_to_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _S]),
     "ttdg_roi_align_multilevel_nhwc": (C.c_int, [Fpn, Levels, _P, _I, _I, _F, _I, _I, _P, _S]),
     "ttdg_bias_act": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _S]),
+    "ttdg_bias_act_nhwc": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _S]),
     "ttdg_relu_bwd": (C.c_int, [_P, _P, _P, C.c_size_t, _S]),
     "ttdg_paste_masks": (C.c_int, [_P, _P, _I, _I, _I, _I, _F, _P, _S]),
     "ttdg_mask_pair_counts": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _S]),

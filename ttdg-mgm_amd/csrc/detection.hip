@@ -682,6 +682,66 @@ __global__ __launch_bounds__(256) void bias_act_plane_kernel(float* __restrict__
   }
 }
 
+// The same epilogue on a CHANNELS-LAST activation (N, H, W, C contiguous: what the backbone runs in since MIOpen's fastest fp32
+// kernels on gfx950 are its NHWC implicit GEMMs - in NCHW it wraps them in transposes, 6 % of an adapted batch).  The channel is
+// the fastest index: a float4 covers four consecutive channels, so bias / bias2 are float4 loads from a C-float table that stays in
+// L1, no division (the lane's channel group advances by a constant), four vectors in flight per lane.  C % 4 == 0.
+__global__ __launch_bounds__(256) void bias_act_nhwc_kernel(float* __restrict__ y, const float* __restrict__ bias,
+                                                            const float* __restrict__ res, const float* __restrict__ bias2, int C4,
+                                                            size_t nvec, int relu) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  const int cstep = (int)(stride % (size_t)C4);
+  size_t v = (size_t)blockIdx.x * 256 + threadIdx.x;
+  int c4 = (int)(v % (size_t)C4);
+  const float4* b4 = reinterpret_cast<const float4*>(bias);
+  const float4* b24 = reinterpret_cast<const float4*>(bias2);
+  for (; v + 3 * stride < nvec; v += 4 * stride) {
+    float4 t[4], r[4];
+    int cc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      t[u] = reinterpret_cast<float4*>(y)[v + u * stride];
+      if (res) r[u] = reinterpret_cast<const float4*>(res)[v + u * stride];
+      cc[u] = c4;
+      c4 += cstep; c4 -= c4 >= C4 ? C4 : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (bias) { const float4 b = b4[cc[u]]; t[u].x += b.x; t[u].y += b.y; t[u].z += b.z; t[u].w += b.w; }
+      if (res) {
+        if (bias2) { const float4 b = b24[cc[u]]; r[u].x += b.x; r[u].y += b.y; r[u].z += b.z; r[u].w += b.w; }
+        t[u].x += r[u].x; t[u].y += r[u].y; t[u].z += r[u].z; t[u].w += r[u].w;
+      } else if (bias2) { const float4 b = b24[cc[u]]; t[u].x += b.x; t[u].y += b.y; t[u].z += b.z; t[u].w += b.w; }
+      if (relu) { t[u].x = fmaxf(t[u].x, 0.f); t[u].y = fmaxf(t[u].y, 0.f); t[u].z = fmaxf(t[u].z, 0.f); t[u].w = fmaxf(t[u].w, 0.f); }
+      reinterpret_cast<float4*>(y)[v + u * stride] = t[u];
+    }
+  }
+  for (; v < nvec; v += stride) {
+    float4 t = reinterpret_cast<float4*>(y)[v];
+    if (bias) { const float4 b = b4[c4]; t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w; }
+    if (res) {
+      float4 r = reinterpret_cast<const float4*>(res)[v];
+      if (bias2) { const float4 b = b24[c4]; r.x += b.x; r.y += b.y; r.z += b.z; r.w += b.w; }
+      t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
+    } else if (bias2) { const float4 b = b24[c4]; t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w; }
+    if (relu) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+    reinterpret_cast<float4*>(y)[v] = t;
+    c4 += cstep; c4 -= c4 >= C4 ? C4 : 0;
+  }
+}
+
+extern "C" int ttdg_bias_act_nhwc(float* y, const float* bias, const float* residual, const float* bias2, int64_t rows, int C,
+                                  int relu, ttdg_stream_t stream) {
+  TTDG_REQUIRE(y && rows >= 0 && C > 0 && (C & 3) == 0, "bias_act_nhwc: C must be a positive multiple of 4");
+  TTDG_REQUIRE((((uintptr_t)y | (uintptr_t)bias | (uintptr_t)residual | (uintptr_t)bias2) & 15) == 0, "bias_act_nhwc: 16-byte alignment");
+  const size_t nvec = (size_t)rows * (size_t)(C >> 2);
+  if (nvec == 0) return 0;
+  const size_t want = (nvec + 1023) / 1024;                  // ~4 vectors per lane
+  const int blocks = (int)(want < 1 ? 1 : (want > 16384 ? 16384 : want));
+  hipLaunchKernelGGL(bias_act_nhwc_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, bias, residual, bias2, C >> 2, nvec, relu);
+  return ttdg_launch_status("bias_act_nhwc");
+}
+
 static int g_bias_act_mode = 1;     // 1 = plane kernel where it applies (default), 0 = the flat round-2 kernel (A/B)
 extern "C" void ttdg_debug_set_bias_act_mode(int mode) { g_bias_act_mode = mode; }
 

@@ -142,6 +142,22 @@ __global__ __launch_bounds__(256) void node_gather_kernel(ttdg_fpn_t fp, const i
   }
 }
 
+// the same on channels-last maps (N, H, W, C): a node's C values are ONE contiguous row - a coalesced read / atomic row
+template <bool kBackward>
+__global__ __launch_bounds__(256) void node_gather_nhwc_kernel(ttdg_fpn_t fp, const int32_t* __restrict__ img,
+                                                               const int32_t* __restrict__ pid, int n, float* __restrict__ rows) {
+  const int node = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (node >= n) return;
+  const int id = pid[node], l = id >> 28, p = id & ((1 << 28) - 1);
+  const size_t hw = (size_t)fp.h[l] * fp.w[l];
+  float* f = fp.feat[l] + ((size_t)img[node] * hw + p) * fp.C;
+  float* r = rows + (size_t)node * fp.C;
+  for (int c = lane; c < fp.C; c += 64) {
+    if (kBackward) atomicAdd(f + c, r[c]);
+    else r[c] = f[c];
+  }
+}
+
 static int check_fpn(const ttdg_fpn_t& fp) {
   if (fp.n < 1 || fp.n > TTDG_MAX_LEVELS || fp.C <= 0) return ttdg_fail(TTDG_EINVAL, "node_gather: bad pyramid descriptor");
   for (int l = 0; l < fp.n; ++l)
@@ -166,4 +182,23 @@ extern "C" int ttdg_node_gather_bwd(ttdg_fpn_t dfp, const int32_t* img, const in
   hipLaunchKernelGGL((node_gather_kernel<true>), dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, dfp, img, pid, n,
                      const_cast<float*>(dout));
   return ttdg_launch_status("node_gather_bwd");
+}
+
+extern "C" int ttdg_node_gather_fwd_nhwc(ttdg_fpn_t fp, const int32_t* img, const int32_t* pid, int n, float* out,
+                                         ttdg_stream_t stream) {
+  TTDG_REQUIRE(img && pid && out && n >= 0, "node_gather_fwd_nhwc: bad arguments");
+  if (int e = check_fpn(fp)) return e;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL((node_gather_nhwc_kernel<false>), dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, fp, img, pid, n, out);
+  return ttdg_launch_status("node_gather_fwd_nhwc");
+}
+
+extern "C" int ttdg_node_gather_bwd_nhwc(ttdg_fpn_t dfp, const int32_t* img, const int32_t* pid, int n, const float* dout,
+                                         ttdg_stream_t stream) {
+  TTDG_REQUIRE(img && pid && dout && n >= 0, "node_gather_bwd_nhwc: bad arguments");
+  if (int e = check_fpn(dfp)) return e;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL((node_gather_nhwc_kernel<true>), dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, dfp, img, pid, n,
+                     const_cast<float*>(dout));
+  return ttdg_launch_status("node_gather_bwd_nhwc");
 }

@@ -37,6 +37,18 @@ class _timed:
         return False
 
 
+def is_channels_last(t):
+    """A 4-D tensor stored (N, H, W, C) and NOT also NCHW-contiguous (1 x 1 maps / one channel are both: NCHW code paths apply)."""
+    return t.dim() == 4 and not t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def like_layout(t, ref):
+    """``t`` as a dense tensor with the memory layout of ``ref`` (contiguous or channels-last)."""
+    if is_channels_last(ref):
+        return t if is_channels_last(t) or (t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last)) else t.contiguous(memory_format=torch.channels_last)
+    return t.contiguous()
+
+
 # ------------------------------------------------------------------------------------------- GEMM
 def gemm(A, sam, sak, B, sbn, sbk, Cout, scm, scn, M, N, K, bias=None, alpha=1.0, beta=0.0,
          a_off=0, b_off=0, c_off=0):
@@ -105,16 +117,19 @@ def row_scale_multi(tensors, scales):
         raise ValueError("row_scale_multi: %d tensors, %d scale vectors" % (len(tensors), len(scales)))
     if not tensors:
         return []
-    ins, offs, total = [], [], 0
+    ins, offs, total, cl = [], [], 0, []
     for t, sc in zip(tensors, scales):
-        check_f32(t, sc)
+        # rows = dim 0 is the outermost index of a contiguous AND of a channels-last filter (O, kh, kw, I): the kernel sees storage order
+        cl.append(is_channels_last(t))
+        check_f32(t.permute(0, 2, 3, 1) if cl[-1] else t, sc)
         if sc.numel() != t.shape[0] or sc.device != t.device:
             raise ValueError("row_scale_multi: scale of %d entries for a tensor of %d rows" % (sc.numel(), t.shape[0]))
         ins.append(t)
         offs.append(total)
         total += (t.numel() + 63) // 64 * 64               # every result starts on a 256-byte boundary, like an allocation of its own
     flat = torch.empty(total, device=tensors[0].device, dtype=torch.float32)
-    outs = [flat[o:o + t.numel()].view(t.shape) for o, t in zip(offs, ins)]
+    outs = [flat[o:o + t.numel()].view(t.shape[0], t.shape[2], t.shape[3], t.shape[1]).permute(0, 3, 1, 2) if c else flat[o:o + t.numel()].view(t.shape)
+            for o, t, c in zip(offs, ins, cl)]                # results keep the layout of their inputs
     items = []
     for t, sc, o in zip(ins, scales, outs):
         it = _lib.RowScale()
@@ -142,7 +157,8 @@ class FoldFiltersFn(torch.autograd.Function):
     def backward(ctx, *grads):
         live = [i for i, g in enumerate(grads) if g is not None]
         out = [None] * len(grads)
-        for i, r in zip(live, row_scale_multi([grads[i].contiguous() for i in live], [ctx.scales[i] for i in live])):
+        dense = [g if (g.is_contiguous() or is_channels_last(g)) else g.contiguous() for g in (grads[i] for i in live)]
+        for i, r in zip(live, row_scale_multi(dense, [ctx.scales[i] for i in live])):
             out[i] = r
         return (None,) + tuple(out)
 
@@ -545,26 +561,29 @@ class NodeGatherFn(torch.autograd.Function):
         Cc = feats[0].shape[1]
         fp = _lib.Fpn()
         fp.n, fp.C = len(feats), Cc
+        nhwc = all(f.is_contiguous(memory_format=torch.channels_last) for f in feats) and any(is_channels_last(f) for f in feats)
         for l, f in enumerate(feats):
-            if f.dtype != torch.float32 or not f.is_contiguous():
-                raise TypeError("FPN maps must be contiguous float32 NCHW")
+            if f.dtype != torch.float32 or not (f.is_contiguous(memory_format=torch.channels_last) if nhwc else f.is_contiguous()):
+                raise TypeError("FPN maps must be dense float32, all NCHW or all channels-last")
             fp.h[l], fp.w[l], fp.feat[l] = f.shape[2], f.shape[3], ptr(f)
         out = torch.empty(n, Cc, device=feats[0].device, dtype=torch.float32)
-        call("ttdg_node_gather_fwd", fp, ptr(img), ptr(pid), n, ptr(out), stream())
+        call("ttdg_node_gather_fwd_nhwc" if nhwc else "ttdg_node_gather_fwd", fp, ptr(img), ptr(pid), n, ptr(out), stream())
         ctx.save_for_backward(img, pid)
         ctx.shapes = [tuple(f.shape) for f in feats]
+        ctx.nhwc = nhwc
         return out
 
     @staticmethod
     def backward(ctx, dout):
         img, pid = ctx.saved_tensors
         dout = dout.contiguous()
-        grads = [torch.zeros(s, device=dout.device, dtype=torch.float32) for s in ctx.shapes]
+        fmt = torch.channels_last if ctx.nhwc else torch.contiguous_format
+        grads = [torch.empty(s, device=dout.device, dtype=torch.float32, memory_format=fmt).zero_() for s in ctx.shapes]
         fp = _lib.Fpn()
         fp.n, fp.C = len(grads), ctx.shapes[0][1]
         for l, g in enumerate(grads):
             fp.h[l], fp.w[l], fp.feat[l] = g.shape[2], g.shape[3], ptr(g)
-        call("ttdg_node_gather_bwd", fp, ptr(img), ptr(pid), img.numel(), ptr(dout), stream())
+        call("ttdg_node_gather_bwd_nhwc" if ctx.nhwc else "ttdg_node_gather_bwd", fp, ptr(img), ptr(pid), img.numel(), ptr(dout), stream())
         return (None, None, *grads)
 
 
@@ -617,6 +636,9 @@ def to_nhwc(feats):
     out = []
     for f in feats:
         f = f.detach()
+        if f.dtype == torch.float32 and f.dim() == 4 and f.is_contiguous(memory_format=torch.channels_last) and (is_channels_last(f) or f.shape[1] == 1):
+            out.append(f.permute(0, 2, 3, 1))              # a channels-last map IS the (B, H, W, C) tensor: a view, no transposition
+            continue
         if f.dtype != torch.float32 or not f.is_contiguous():
             f = f.float().contiguous()
         B, Cc, H, W = f.shape
@@ -706,6 +728,19 @@ def nms_collect(launched):
 def bias_act_(y, bias=None, residual=None, bias2=None, relu=True):
     """In place on a contiguous fp32 NCHW tensor: y <- act((y + bias[c]) + (residual + bias2[c])).  No autograd: where
     gradients flow use BiasActFn."""
+    if is_channels_last(y):          # (N, H, W, C) storage: the channel is the fastest index
+        if residual is not None and (residual.shape != y.shape or residual.stride() != y.stride()):
+            raise ValueError("bias_act_: residual must have the shape and the channels-last layout of y")
+        for t in (y, bias, residual, bias2):
+            if t is not None and t.dtype != torch.float32:
+                raise TypeError("bias_act_: float32 tensors only (got %s)" % t.dtype)
+        for t in (bias, bias2):
+            if t is not None and not t.is_contiguous():
+                raise TypeError("bias_act_: contiguous bias vectors only")
+        Cc = y.shape[1]
+        with _timed("bias_act", y.numel() * 4 * (3 if residual is not None else 2)):
+            call("ttdg_bias_act_nhwc", ptr(y), ptr(bias), ptr(residual), ptr(bias2), y.numel() // Cc, Cc, int(bool(relu)), stream())
+        return y
     for t in (y, bias, residual, bias2):
         if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
             raise TypeError("bias_act_: contiguous float32 tensors only (got %s)" % t.dtype)
@@ -734,7 +769,7 @@ class BiasActFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         (out,) = ctx.saved_tensors
-        gout = gout.contiguous()
+        gout = like_layout(gout, out)                   # element-wise over storage: both operands in the layout of the activation
         if gout.dtype != torch.float32:
             raise TypeError("BiasActFn: float32 gradients only")
         gin = torch.empty_like(out)
