@@ -84,6 +84,8 @@ def parse(argv=None):
                     "convolution shape it meets (minutes) and records the winners in its user find-db (MIOPEN_USER_DB_PATH)")
     ap.add_argument("--sync-debug", default="", help="debug: after the headline pass, repeat it with torch.cuda.set_sync_debug_mode('warn') and write the "
                     "host-synchronising call sites (file:line inside the package, counts per adapted batch) to this path")
+    ap.add_argument("--copy-debug", default="", help="debug: after the headline pass, repeat it under a dispatch mode that records every tensor copy of "
+                    ">= 256 K elements (shape, strides, call site) and write the table to this path")
     ap.add_argument("--torch-profile", default="", help="debug: after the headline pass, repeat it under torch.profiler and write the per-operator table to this path")
     ap.add_argument("--plumbing-only", action="store_true",
                     help="launch, rendezvous, sharding and the collectives of the bench without any GPU work (CPU test of --gpus N)")
@@ -247,6 +249,9 @@ def _pairs(sizes):
     return [(sizes[a], sizes[b]) for a in range(len(sizes)) for b in range(a + 1)]
 
 
+BIAS_ACT_KERNEL = "bias_act_nhwc_kernel" if os.environ.get("TTDG_CHANNELS_LAST", "1") != "0" else "bias_act_plane_kernel"      # the epilogue kernel of the active layout
+
+
 def kernel_rooflines(run):
     """Algorithmic work per launch (formulas restated in DESIGN.md §5) / HIP-event time on the launch stream.
     gagm: per iteration 2u*sum(n_g^2) + 4Mu^2 + 2M^2u + projector (5*K_sk*sum(max(n_g,u)^2) Sinkhorn, ~n^2*u LAP), times the
@@ -284,7 +289,7 @@ def kernel_rooflines(run):
         r = {"kernel": {"gagm": "gagm_kernel", "sgd": "sgd_multi_tensor_kernel", "affinity_fwd": "affinity_fwd_kernel",
                         "affinity_bwd": "affinity_bwd_kernel(+finish)", "sinkhorn_pairs_fwd": "sinkhorn_pairs_fwd_kernel",
                         "sinkhorn_pairs_bwd": "sinkhorn_pairs_bwd_kernel", "pair_stage_fwd": "pair_stage_fwd_kernel",
-                        "pair_stage_bwd": "pair_stage_bwd_kernel", "bias_act": "bias_act_plane_kernel", "relu_bwd": "relu_bwd_kernel",
+                        "pair_stage_bwd": "pair_stage_bwd_kernel", "bias_act": BIAS_ACT_KERNEL, "relu_bwd": "relu_bwd_kernel",
                         "roi_align_nhwc": "roi_align_nhwc_kernel", "row_scale_multi": "row_scale_multi_kernel"}[nm],
              "bound": "hbm" if hbm else "mfma", "achieved": ach, "peak": peak, "unit": "GB/s" if hbm else "TFLOP/s", "frac": ach / peak,
              "traffic": pmc_traffic(nm), "launches": e["n"], "avg_launch_ms": e["t"] / e["n"] * 1e3, "total_ms": e["t"] * 1e3,
@@ -591,13 +596,39 @@ def gpu_main(args, rank, world, local):
             f.write("# host-synchronising calls over W=%d warm-up + K=%d adapted batches (TTA steps, then the Dice pass), torch.cuda.set_sync_debug_mode('warn')\n" % (W, K))
             for (where, msg), n in sites.most_common():
                 f.write("%6d  (%.1f / batch)  %s   [%s]\n" % (n, n / (W + K), where, msg))
+    if args.copy_debug and world == 1:
+        import collections
+        import traceback
+        from torch.utils._python_dispatch import TorchDispatchMode
+        seen = collections.Counter()
+
+        class Copies(TorchDispatchMode):
+            def __torch_dispatch__(self, func, types, a=(), kw=None):
+                name = str(func)
+                if ("copy" in name or "clone" in name or "contiguous" in name) and a and isinstance(a[0], torch.Tensor) and a[0].is_cuda and a[0].numel() >= 262144:
+                    src = a[1] if len(a) > 1 and isinstance(a[1], torch.Tensor) else a[0]
+                    frames = [f for f in traceback.extract_stack() if os.sep + "ttdg-mgm_amd" + os.sep in f.filename]
+                    where = " <- ".join("%s:%d" % (os.path.basename(f.filename), f.lineno) for f in reversed(frames[-3:])) or "(autograd / outside the package)"
+                    seen[(name, tuple(a[0].shape), tuple(src.stride()), tuple(a[0].stride()) if "copy_" in name else str(kw), where)] += 1
+                return func(*a, **(kw or {}))
+        with Copies():
+            timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, world, device, tf)
+        with open(args.copy_debug, "w") as f:
+            f.write("# tensor copies >= 256 K elements over W=%d + K=%d adapted batches: count, op, shape, source strides, destination strides / kwargs, call site\n" % (W, K))
+            for key, n in sorted(seen.items(), key=lambda kv: -kv[1] * torch.Size(kv[0][1]).numel()):
+                f.write("%5d  %s\n" % (n, "  ".join(str(x) for x in key)))
     if args.torch_profile and world == 1:
         from torch.profiler import ProfilerActivity, profile
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
             timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, world, device, tf)
         with open(args.torch_profile, "w") as f:
             f.write("# torch.profiler over W=%d warm-up + K=%d adapted batches (TTA steps + Dice pass), operators by device time\n" % (W, K))
             f.write(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=70, max_name_column_width=70))
+            f.write("\n\n# copies by call site (aten::copy_ with device time, grouped by the Python stack)\n")
+            cps = [e for e in prof.key_averages(group_by_stack_n=6) if e.key == "aten::copy_" and e.self_device_time_total > 0]
+            for e in sorted(cps, key=lambda e: -e.self_device_time_total)[:25]:
+                where = " <- ".join(fr.split("/")[-1] for fr in e.stack[:6] if "ttdg" in fr or "bench.py" in fr or "torch/nn/functional" in fr)
+                f.write("calls %5d  self device %9.1f us  avg %7.1f us   %s\n" % (e.count, e.self_device_time_total, e.self_device_time_total / e.count, where[:300]))
             f.write("\n\n# by call count\n")
             rows = sorted(prof.key_averages(), key=lambda e: -e.count)[:60]
             for e in rows:

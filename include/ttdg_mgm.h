@@ -299,6 +299,9 @@ typedef struct {
 } ttdg_rpn_level_t;
 int ttdg_rpn_select(const ttdg_rpn_level_t* levels, int nlevels, int B, int A, const float* sizes, int K, float* boxes,
                     float* scores, ttdg_stream_t stream);
+/* the same with channels-last head outputs: logits (B, H, W, A), deltas (B, H, W, 4A) in storage */
+int ttdg_rpn_select_nhwc(const ttdg_rpn_level_t* levels, int nlevels, int B, int A, const float* sizes, int K, float* boxes,
+                         float* scores, ttdg_stream_t stream);
 int ttdg_box_inference(const float* logits, const float* deltas, const float* rois, const float* sizes, int N, int C,
                        float wx, float wy, float ww, float wh, float score_thresh, float* boxes, float* scores,
                        ttdg_stream_t stream);

@@ -1158,6 +1158,11 @@ def test_fused_rpn_selection_equals_per_level_topk_and_decode(dev):
             finally:
                 ops.RPN_SELECT = True
         (bf, sf), (bp, sp) = out[True], out[False]
+        # channels-last head outputs (what the channels-last backbone hands over) take the kNhwc instantiation: same slots, bit for bit
+        CL = torch.channels_last
+        bn, sn = torch.full((B, K, 4), -7.0, device=dev), torch.full((B, K), -7.0, device=dev)
+        ops.rpn_select([t.contiguous(memory_format=CL) for t in logits], [t.contiguous(memory_format=CL) for t in deltas], anchors, ks, st, bn, sn)
+        assert torch.equal(bn.cpu(), bf) and torch.equal(sn.cpu().nan_to_num(nan=7.0), sf.nan_to_num(nan=7.0))
         # (a) the kernel's own rule - descending score, ascending (h, w, a) index on ties, -0.0 == +0.0, NaN first - restated on
         #     the CPU: a stable descending sort of the raster, then the host backend's decode.  Every slot must coincide.
         bc, sc_ = torch.empty(B, K, 4), torch.empty(B, K)

@@ -344,10 +344,15 @@ def test_continual_tta_trajectory_matches_cpu_port(trained):
     print("after %d continual steps: device %s (%d masks) host %s (%d masks)" % (K, rg, len(evg.dice_scores), rc, len(evc.dice_scores)))
     # ---- gates
     for g in names:
-        bound0 = max(1e-4, TRAJ_FACTOR * e_ref[g]["host32"])
+        # what fp32 arithmetic loses in group g: the host's own fp32-vs-float64 distance at step 0.  The matching layers sit on
+        # top of the FPN: their gradients inherit the relative error of the node features, so their unit is the larger of their own
+        # and the FPN's (on the host the two differ by 20x; the device's convolutions - Winograd / NHWC implicit GEMM - round
+        # differently from the host's direct ones, which moves the features, not the matching arithmetic)
+        unit = max(e_ref[g]["host32"], e_ref["fpn"]["host32"]) if g == "affinity" and "fpn" in e_ref else e_ref[g]["host32"]
+        bound0 = max(1e-4, TRAJ_FACTOR * unit)
         assert e_ref[g]["device"] <= bound0, ("step 0 vs float64", g, e_ref[g], bound0)
         for row in rec:
-            bound = max(1e-4, TRAJ_FACTOR * e_ref[g]["host32"]) * (row["step"] + 1)
+            bound = max(1e-4, TRAJ_FACTOR * unit) * (row["step"] + 1)
             # (a group that has barely moved - the affinity layers: 2e-4 after three steps on parameters of size 2 - is compared in
             #  units of the parameters' own rounding: the fused SGD kernel's fma and torch's mul + add may differ by one ulp per step)
             v = row["groups"][g]

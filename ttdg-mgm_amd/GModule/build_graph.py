@@ -66,7 +66,9 @@ class PrototypeComputation(object):
         flat = torch.cat([torch.arange(c, dtype=torch.int64) + k * cap for k, c in enumerate(counts)]).to(dev, non_blocking=True)
         pid = sel_idx.view(-1)[flat].contiguous()
         lab = sel_lab.view(-1)[flat].to(torch.int64)
-        feats = [f if (f.dtype == torch.float32 and f.is_contiguous()) else f.float().contiguous() for f in features]
+        # dense fp32 maps in either layout go to the gather as they are (the backbone hands over channels-last maps; all levels share it)
+        cl = all(f.dim() == 4 and f.is_contiguous(memory_format=torch.channels_last) for f in features)
+        feats = [f if (f.dtype == torch.float32 and (cl or f.is_contiguous())) else f.float().contiguous() for f in features]
         rows = ops.NodeGatherFn.apply(img, pid, *feats)
         nodes = list(torch.split(rows, counts, dim=0))
         labs = list(torch.split(lab, counts, dim=0))

@@ -110,6 +110,7 @@ SIGNATURES = {
     "ttdg_nms_grouped": (C.c_int, [_P, _P, _I, _I, _I, _F, _P, _P, _S]),
     "ttdg_rpn_decode": (C.c_int, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _S]),
     "ttdg_rpn_select": (C.c_int, [C.POINTER(RpnLevel), _I, _I, _I, _P, _I, _P, _P, _S]),
+    "ttdg_rpn_select_nhwc": (C.c_int, [C.POINTER(RpnLevel), _I, _I, _I, _P, _I, _P, _P, _S]),
     "ttdg_box_inference": (C.c_int, [_P, _P, _P, _P, _I, _I, _F, _F, _F, _F, _F, _P, _P, _S]),
     "ttdg_roi_align_multilevel": (C.c_int, [Fpn, Levels, _P, _I, _I, _F, _I, _I, _P, _S]),
     "ttdg_debug_set_roi_align_sliced": (C.c_int, [_I]),

@@ -383,6 +383,9 @@ __device__ __forceinline__ void rs_for_each(const float* __restrict__ x, int n, 
   }
 }
 
+// kNhwc: the head outputs are channels-last - logits (B, H, W, A), deltas (B, H, W, 4A) in storage: a row of logits IS the (h, w, a)
+// raster (memory index == raster index), a candidate's four deltas are adjacent.
+template <bool kNhwc>
 __global__ __launch_bounds__(RS_THREADS) void rpn_select_kernel(RsLevels lv, int B, int A, const float* __restrict__ sizes, int K,
                                                                 float* __restrict__ boxes, float* __restrict__ scores) {
   extern __shared__ __attribute__((aligned(16))) unsigned char rs_smem[];
@@ -441,8 +444,8 @@ __global__ __launch_bounds__(RS_THREADS) void rpn_select_kernel(RsLevels lv, int
       if (lane == 0) base = atomicAdd(&sh_cnt, (unsigned)__popcll(m));
       base = __shfl(base, 0);
       if (take) {
-        const int a = i / HW, hw = i - a * HW;
-        const unsigned id = (unsigned)(hw * A + a);
+        unsigned id = (unsigned)i;
+        if (!kNhwc) { const int a = i / HW, hw = i - a * HW; id = (unsigned)(hw * A + a); }
         sel[base + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)key << 32) | (unsigned long long)(0xFFFFFFFFu - id);
       }
     }
@@ -453,10 +456,10 @@ __global__ __launch_bounds__(RS_THREADS) void rpn_select_kernel(RsLevels lv, int
     const int C = (n + RS_THREADS - 1) / RS_THREADS;
     const int lo = tid * C, hi = min(n, lo + C);
     unsigned c = 0;
-    for (int id = lo; id < hi; ++id) c += rs_key(x[(id % A) * HW + id / A]) == theta;
+    for (int id = lo; id < hi; ++id) c += rs_key(x[kNhwc ? id : (id % A) * HW + id / A]) == theta;
     unsigned r = rs_prefix_excl(c, wsum);
     for (int id = lo; id < hi && r < need; ++id)
-      if (rs_key(x[(id % A) * HW + id / A]) == theta) {
+      if (rs_key(x[kNhwc ? id : (id % A) * HW + id / A]) == theta) {
         sel[nabove + r] = ((unsigned long long)theta << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)id);
         ++r;
       }
@@ -485,10 +488,17 @@ __global__ __launch_bounds__(RS_THREADS) void rpn_select_kernel(RsLevels lv, int
     const float sc = rs_unkey((unsigned)(e >> 32));
     const unsigned id = 0xFFFFFFFFu - (unsigned)(e & 0xFFFFFFFFull);
     const int a = (int)(id % (unsigned)A), hw = (int)(id / (unsigned)A);
-    const float* d = L.deltas + ((size_t)b * A * 4 + (size_t)a * 4) * plane + hw;
+    float d0, d1, d2, d3;
+    if (kNhwc) {
+      const float4 dv = reinterpret_cast<const float4*>(L.deltas + ((size_t)b * plane + hw) * (size_t)(4 * A))[a];
+      d0 = dv.x; d1 = dv.y; d2 = dv.z; d3 = dv.w;
+    } else {
+      const float* d = L.deltas + ((size_t)b * A * 4 + (size_t)a * 4) * plane + hw;
+      d0 = d[0]; d1 = d[plane]; d2 = d[2 * plane]; d3 = d[3 * plane];
+    }
     const float4 an = reinterpret_cast<const float4*>(L.anchors)[id];
     float4 o;
-    const bool fin = det_decode(an.x, an.y, an.z, an.w, d[0], d[plane], d[2 * plane], d[3 * plane], 1.f, 1.f, 1.f, 1.f, ih, iw, o);
+    const bool fin = det_decode(an.x, an.y, an.z, an.w, d0, d1, d2, d3, 1.f, 1.f, 1.f, 1.f, ih, iw, o);
     const bool ok = fin && isfinite(sc) && (o.z - o.x > 0.f) && (o.w - o.y > 0.f);
     const size_t oi = (size_t)b * K + L.col0 + j;
     reinterpret_cast<float4*>(boxes)[oi] = ok ? o : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -496,8 +506,8 @@ __global__ __launch_bounds__(RS_THREADS) void rpn_select_kernel(RsLevels lv, int
   }
 }
 
-extern "C" int ttdg_rpn_select(const ttdg_rpn_level_t* levels, int nlevels, int B, int A, const float* sizes, int K, float* boxes,
-                               float* scores, ttdg_stream_t stream) {
+static int rpn_select_launch(const ttdg_rpn_level_t* levels, int nlevels, int B, int A, const float* sizes, int K, float* boxes,
+                             float* scores, ttdg_stream_t stream, bool nhwc) {
   TTDG_REQUIRE(levels && sizes && boxes && scores, "rpn_select: null pointer");
   TTDG_REQUIRE(nlevels >= 1 && nlevels <= TTDG_RPN_LEVELS_MAX && B >= 0 && A > 0 && K >= 0, "rpn_select: bad sizes");
   RsLevels lv;
@@ -511,9 +521,25 @@ extern "C" int ttdg_rpn_select(const ttdg_rpn_level_t* levels, int nlevels, int 
     lv.l[i] = l;
   }
   if (B == 0) return 0;
-  TTDG_ALLOW_LDS(rpn_select_kernel, RS_LDS_BYTES);
-  hipLaunchKernelGGL(rpn_select_kernel, dim3(B * nlevels), dim3(RS_THREADS), RS_LDS_BYTES, (hipStream_t)stream, lv, B, A, sizes, K, boxes, scores);
+  if (nhwc) {
+    TTDG_ALLOW_LDS(rpn_select_kernel<true>, RS_LDS_BYTES);
+    hipLaunchKernelGGL(rpn_select_kernel<true>, dim3(B * nlevels), dim3(RS_THREADS), RS_LDS_BYTES, (hipStream_t)stream, lv, B, A, sizes, K, boxes, scores);
+  } else {
+    TTDG_ALLOW_LDS(rpn_select_kernel<false>, RS_LDS_BYTES);
+    hipLaunchKernelGGL(rpn_select_kernel<false>, dim3(B * nlevels), dim3(RS_THREADS), RS_LDS_BYTES, (hipStream_t)stream, lv, B, A, sizes, K, boxes, scores);
+  }
   return ttdg_launch_status("rpn_select");
+}
+
+extern "C" int ttdg_rpn_select(const ttdg_rpn_level_t* levels, int nlevels, int B, int A, const float* sizes, int K, float* boxes,
+                               float* scores, ttdg_stream_t stream) {
+  return rpn_select_launch(levels, nlevels, B, A, sizes, K, boxes, scores, stream, false);
+}
+extern "C" int ttdg_rpn_select_nhwc(const ttdg_rpn_level_t* levels, int nlevels, int B, int A, const float* sizes, int K, float* boxes,
+                                    float* scores, ttdg_stream_t stream) {
+  for (int i = 0; levels && i < nlevels && i < TTDG_RPN_LEVELS_MAX; ++i)
+    TTDG_REQUIRE(((uintptr_t)levels[i].deltas & 15) == 0, "rpn_select_nhwc: deltas must be 16-byte aligned");
+  return rpn_select_launch(levels, nlevels, B, A, sizes, K, boxes, scores, stream, true);
 }
 
 // Box head inference (detectron2 fast_rcnn_inference [3P] up to the NMS): per proposal softmax over C+1 logits, per

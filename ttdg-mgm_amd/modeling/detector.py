@@ -106,8 +106,7 @@ class PseudoLabRPN(nn.Module):
         # proposals carry no gradient (compute_loss=False, rpn.py:16-56): no tape, and the fused epilogues in the TTA step too
         with torch.set_grad_enabled(torch.is_grad_enabled() and not _bb.FUSED_HEADS):
             logits, deltas = self.rpn_head(feats)
-        # the selection kernel reads the head outputs as (B, A, H, W) / (B, 4A, H, W): dense NCHW copies of channels-last outputs (small)
-        logits, deltas = [t.contiguous() for t in logits], [t.contiguous() for t in deltas]
+
         dev = feats[0].device
         anchors = self._anchors([f.shape[-2:] for f in feats], dev)
         N, L = feats[0].shape[0], len(feats)

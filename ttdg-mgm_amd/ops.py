@@ -561,7 +561,7 @@ class NodeGatherFn(torch.autograd.Function):
         Cc = feats[0].shape[1]
         fp = _lib.Fpn()
         fp.n, fp.C = len(feats), Cc
-        nhwc = all(f.is_contiguous(memory_format=torch.channels_last) for f in feats) and any(is_channels_last(f) for f in feats)
+        nhwc = all(f.dim() == 4 and f.is_contiguous(memory_format=torch.channels_last) for f in feats) and any(is_channels_last(f) for f in feats)
         for l, f in enumerate(feats):
             if f.dtype != torch.float32 or not (f.is_contiguous(memory_format=torch.channels_last) if nhwc else f.is_contiguous()):
                 raise TypeError("FPN maps must be dense float32, all NCHW or all channels-last")
@@ -845,8 +845,12 @@ def rpn_select(logits, deltas, anchors, ks, sizes_t, boxes, scores):
     every (image, level) in descending order, decoded + clipped + tested into their column block of boxes (B, K, 4) / scores
     (B, K) (-inf = rejected, box zeroed).  Falls back to the per-level path for inputs the kernel does not take."""
     B, A = logits[0].shape[0], logits[0].shape[1]
+    heads = list(logits) + list(deltas)
+    nhwc = all(t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) for t in heads) and any(is_channels_last(t) for t in heads)
+    if not nhwc:
+        logits, deltas = [t.contiguous() for t in logits], [t.contiguous() for t in deltas]
     fused = RPN_SELECT and len(logits) <= _lib.RPN_LEVELS_MAX and max(ks) <= _lib.RPN_SELECT_MAX_K and \
-        all(t.dtype == torch.float32 and t.is_contiguous() for ts in (logits, deltas, anchors) for t in ts) and all(lg.shape[1] == A for lg in logits)
+        all(t.dtype == torch.float32 for t in heads) and all(t.dtype == torch.float32 and t.is_contiguous() for t in anchors) and all(lg.shape[1] == A for lg in logits)
     col = 0
     if not fused:
         for lg, dl, an, k in zip(logits, deltas, anchors, ks):
@@ -861,7 +865,8 @@ def rpn_select(logits, deltas, anchors, ks, sizes_t, boxes, scores):
         it.H, it.W, it.k, it.col0 = lg.shape[2], lg.shape[3], int(k), col
         items.append(it)
         col += k
-    call("ttdg_rpn_select", (_lib.RpnLevel * len(items))(*items), len(items), B, A, ptr(sizes_t), boxes.shape[1], ptr(boxes), ptr(scores), stream())
+    call("ttdg_rpn_select_nhwc" if nhwc else "ttdg_rpn_select", (_lib.RpnLevel * len(items))(*items), len(items), B, A, ptr(sizes_t), boxes.shape[1],
+         ptr(boxes), ptr(scores), stream())
 
 
 def _grouped_flags(bx, sc, gf, ngroups, max_group, thr):

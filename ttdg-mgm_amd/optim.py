@@ -41,7 +41,11 @@ class FusedSGD(torch.optim.Optimizer):
                 if p.dtype != torch.float32 or not dense:
                     raise TypeError("FusedSGD handles dense float32 parameters")
                 # the update is element-wise: any dense layout works as long as p, grad and buffer share it
-                g = p.grad if p.grad.stride() == p.stride() else torch.empty_like(p).copy_(p.grad)
+                # (same storage order, not same stride tuple: a 1 x 1 filter is contiguous AND channels-last with two different tuples)
+                gr = p.grad
+                same = gr.stride() == p.stride() or (p.is_contiguous() and gr.is_contiguous()) or \
+                    (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) and gr.is_contiguous(memory_format=torch.channels_last))
+                g = gr if same else torch.empty_like(p).copy_(gr)
                 st = self.state[p]
                 first = "momentum_buffer" not in st
                 if first:
