@@ -8,6 +8,18 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
+def _ship(vals):
+    """Tensors cross the process boundary BY VALUE (numpy arrays): a torch tensor on a multiprocessing queue travels as a
+    shared-memory handle that the receiver fetches from the sender's resource sharer - which is gone when the worker has
+    already exited (ConnectionResetError, seen under load)."""
+    return tuple(v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v for v in vals)
+
+
+def _unship(vals):
+    import numpy as np
+    return tuple(torch.from_numpy(v) if isinstance(v, np.ndarray) else v for v in vals)
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -92,8 +104,8 @@ def _sync_worker(rank, world, port, q, layout):
         loss = _toy_loss(all_nodes, w)
         loss.backward()
         su.allreduce_grads([backbone.weight, backbone.bias, unused, only0], [w])
-        q.put((rank, float(loss), [tuple(t.shape) for t in all_nodes], [l.tolist() for l in all_labs], backbone.weight.grad.clone(),
-               backbone.bias.grad.clone(), w.grad.clone(), unused.grad is None, only0.grad.clone()))
+        q.put(_ship((rank, float(loss), [tuple(t.shape) for t in all_nodes], [l.tolist() for l in all_labs], backbone.weight.grad.clone(),
+                     backbone.bias.grad.clone(), w.grad.clone(), unused.grad is None, only0.grad.clone())))
     finally:
         dist.destroy_process_group()
 
@@ -109,7 +121,7 @@ def test_sync_universe_gather_and_gradient_allreduce(layout):
     procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q, layout)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=120) for _ in range(2)), key=lambda t: t[0])
+    res = sorted((_unship(q.get(timeout=120)) for _ in range(2)), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -186,8 +198,8 @@ def _overlap_worker(rank, world, port, q, layout):
                 red.remove()
         same = all((a is None and b is None) or torch.equal(a, b) for ga, gb in zip(out["posthoc"], out["overlap"]) for a, b in zip(ga, gb))
         none_pattern = [[g is None for g in step] for step in out["overlap"]]
-        q.put((rank, same, out["launched_in_backward"], out["nbuckets"], out["overlap"][-1][0].clone(), out["overlap"][-1][-3] is None, out["late"],
-               none_pattern == [[g is None for g in step] for step in out["posthoc"]], [step[-2] is None for step in out["overlap"]]))
+        q.put(_ship((rank, same, out["launched_in_backward"], out["nbuckets"], out["overlap"][-1][0].clone(), out["overlap"][-1][-3] is None, out["late"],
+                     none_pattern == [[g is None for g in step] for step in out["posthoc"]], [step[-2] is None for step in out["overlap"]])))
     finally:
         dist.destroy_process_group()
 
@@ -205,7 +217,7 @@ def test_overlapped_gradient_allreduce_equals_posthoc_bit_for_bit():
     procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q, layout)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=180) for _ in range(2)), key=lambda t: t[0])
+    res = sorted((_unship(q.get(timeout=180)) for _ in range(2)), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -252,7 +264,7 @@ def test_sync_universe_keeps_ranks_in_lockstep_on_uneven_shards():
     procs = [ctx.Process(target=_lockstep_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=120) for _ in range(2)), key=lambda t: t[0])
+    res = sorted((_unship(q.get(timeout=120)) for _ in range(2)), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
