@@ -427,3 +427,46 @@ def test_disk_stream_ring_slots(tmp_path):
                     assert torch.equal(a["mask"], b["mask"]) and torch.equal(a["bbox"], b["bbox"]) and a["category_id"] == b["category_id"]
                 seen += 1
         assert seen == 23
+
+
+def test_shipped_miopen_db_is_staged_to_a_private_writable_copy(monkeypatch, tmp_path):
+    """The package ships MIOpen find-db / perf-db records for the bench shapes (ttdg-mgm_amd/miopen_db) and points
+    MIOPEN_USER_DB_PATH at a COPY under the temp directory (MIOpen writes to its user db path; ranks may race: atomic renames,
+    directory named after the content).  An explicit MIOPEN_USER_DB_PATH or TTDG_MIOPEN_DB=0 leaves the environment alone."""
+    import os
+    import tempfile
+    import ttdg_mgm_amd as pkg
+    files = sorted(f for f in os.listdir(pkg.MIOPEN_DB) if f.endswith(".txt"))
+    assert len(files) == 2 and any(f.endswith(".ufdb.txt") for f in files) and any(f.endswith(".udb.txt") for f in files)
+    assert all(f.startswith("gfx950") for f in files)                     # keyed by device: ignored on anything else
+    monkeypatch.setattr(tempfile, "tempdir", str(tmp_path))
+    dst = pkg._stage_miopen_db()
+    assert dst.startswith(str(tmp_path)) and dst.rstrip("/").endswith("miopen_db") and sorted(os.listdir(dst)) == files
+    for f in files:
+        assert open(os.path.join(dst, f), "rb").read() == open(os.path.join(pkg.MIOPEN_DB, f), "rb").read()
+    with open(os.path.join(dst, files[0]), "a") as fh:                     # MIOpen appends records: a second staging keeps them
+        fh.write("x=y\n")
+    assert pkg._stage_miopen_db() == dst and open(os.path.join(dst, files[0])).read().endswith("x=y\n")
+    assert not [f for f in os.listdir(dst) if f.endswith(".tmp")]
+    # the switches
+    for env, want in (({"TTDG_MIOPEN_DB": "0"}, None), ({"MIOPEN_USER_DB_PATH": "/somewhere/else"}, "/somewhere/else"), ({}, dst)):
+        env = dict(env)
+        pkg._configure_miopen_db(env)
+        assert env.get("MIOPEN_USER_DB_PATH") == want
+
+
+def test_layout_helpers():
+    """ops.is_channels_last / like_layout: what the layout dispatch of the epilogue, gather and fold wrappers rests on."""
+    from ttdg_mgm_amd import ops
+    CL = torch.channels_last
+    a = torch.zeros(2, 8, 5, 6)
+    assert not ops.is_channels_last(a) and ops.is_channels_last(a.contiguous(memory_format=CL))
+    assert not ops.is_channels_last(torch.zeros(2, 8, 1, 1).contiguous(memory_format=CL))        # both layouts at once: NCHW code paths apply
+    assert not ops.is_channels_last(torch.zeros(2, 1, 5, 6).contiguous(memory_format=CL))
+    assert not ops.is_channels_last(torch.zeros(4, 6)) and not ops.is_channels_last(a[:, ::2])
+    b = torch.arange(2 * 8 * 5 * 6, dtype=torch.float32).view(2, 8, 5, 6)
+    for ref in (a, a.contiguous(memory_format=CL)):
+        for src in (b, b.contiguous(memory_format=CL), b.permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2)):
+            out = ops.like_layout(src, ref)
+            assert torch.equal(out, b) and out.stride() == ref.stride()
+    assert ops.like_layout(b, a) is b and ops.like_layout(b.contiguous(memory_format=CL), a.contiguous(memory_format=CL)).is_contiguous(memory_format=CL)

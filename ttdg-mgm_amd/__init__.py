@@ -45,8 +45,12 @@ def _stage_miopen_db():
     return dst
 
 
-if _os.environ.get("TTDG_MIOPEN_DB", "1") != "0" and "MIOPEN_USER_DB_PATH" not in _os.environ and _os.path.isdir(MIOPEN_DB):
-    try:
-        _os.environ["MIOPEN_USER_DB_PATH"] = _stage_miopen_db() or MIOPEN_DB
-    except OSError:
-        _os.environ["MIOPEN_USER_DB_PATH"] = MIOPEN_DB
+def _configure_miopen_db(env=_os.environ):
+    if env.get("TTDG_MIOPEN_DB", "1") != "0" and "MIOPEN_USER_DB_PATH" not in env and _os.path.isdir(MIOPEN_DB):
+        try:
+            env["MIOPEN_USER_DB_PATH"] = _stage_miopen_db() or MIOPEN_DB
+        except OSError:
+            env["MIOPEN_USER_DB_PATH"] = MIOPEN_DB
+
+
+_configure_miopen_db()
