@@ -542,7 +542,9 @@ def gpu_main(args, rank, world, local):
     assert _det._backend is _ops, "the GPU legs must run on the HIP operators (detector._backend was re-pointed)"
     if args.gagm_threads or args.roi_align_mode != 3:
         from ttdg_mgm_amd import _lib
-        _lib.load().ttdg_debug_set_gagm_threads(args.gagm_threads)
+        if args.gagm_threads == 256:
+            from ttdg_mgm_amd import ops as _ops
+            _ops.GAGM_VARIANT |= _lib.GAGM_256_THREADS
         _ops.ROI_ALIGN_NHWC = args.roi_align_mode == 3
         _lib.load().ttdg_debug_set_roi_align_sliced(min(args.roi_align_mode, 2))
     if args.roi_xcd_chunks or args.flat_bias_act or args.roi_chunk:

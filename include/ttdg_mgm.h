@@ -160,7 +160,18 @@ typedef struct {
   int32_t start_hungarian;   /* non-zero: the first stage already uses the Hungarian projector (parity tests) */
   int32_t no_cycle_skip;     /* non-zero: disable the exact Hungarian-stage cycle shortcut (parity tests) */
   int32_t profile;           /* non-zero: info[9..13] receive cycle-counter ticks/64 spent in B, S, V, projection, convergence */
+  int32_t variant;           /* 0 = the product path.  A/B and parity-test selectors, per call (the library keeps no switches):
+                              *   TTDG_GAGM_LDS_PROJECTORS    round 1's LDS-exchange Sinkhorn projectors for graphs of <= 64 nodes
+                              *   TTDG_GAGM_FORCE_LARGE       the multi-workgroup solver even where one workgroup would do
+                              *   TTDG_GAGM_FORCE_SINGLE      the single-workgroup kernel wherever it can run (every graph <= 128 nodes)
+                              *   TTDG_GAGM_256_THREADS       single-workgroup kernel built for 256 threads (graphs <= 64 nodes)
+                              *   TTDG_GAGM_COLUMN_PROJECTOR  multi-workgroup solver: round 3's column-per-thread Sinkhorn projector */
 } ttdg_gagm_cfg_t;
+#define TTDG_GAGM_LDS_PROJECTORS 1
+#define TTDG_GAGM_FORCE_LARGE 2
+#define TTDG_GAGM_FORCE_SINGLE 4
+#define TTDG_GAGM_256_THREADS 8
+#define TTDG_GAGM_COLUMN_PROJECTOR 16
 size_t ttdg_gagm_workspace_bytes(int M);
 int ttdg_gagm_solve(const float* Apack, const float* W, const float* U0, ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg,
                     float* U, int32_t* info, void* ws, ttdg_stream_t stream);
@@ -171,15 +182,6 @@ int ttdg_gagm_solve(const float* Apack, const float* W, const float* U0, ttdg_gr
 int ttdg_lap_batched(const float* s, int b, int r, int c, float* x, ttdg_stream_t stream);
 /* benchmarking aid: 0 = compiler-lowered fp64 arg-min (default), 1 = hand-scheduled inline asm; affects ttdg_lap_batched only */
 int ttdg_debug_set_lap_variant(int v);
-/* benchmarking aid: total node count from which ttdg_gagm_solve takes the multi-workgroup solver even though every graph
- * fits the single-workgroup kernel (<= 0 restores the built-in default) */
-int ttdg_debug_set_gagm_large_from(int total_nodes);
-/* A/B hook: workgroup size of the single-workgroup solver (256 = one wavefront per SIMD, no register spills; anything else
- * = the default 512, which is faster: gagm.hip). */
-int ttdg_debug_set_gagm_threads(int threads);
-/* A/B hook: bit 0 set = graphs of up to 64 nodes use round 1's LDS-exchange Sinkhorn projectors (two copies of the matrix,
- * potentials through LDS) instead of the block-layout one (gagm.hip: sk_wave_project_blk). */
-int ttdg_debug_set_gagm_flags(int flags);
 /* micro-benchmark hook: `reps` projections (mode 0 Sinkhorn with the product's block-layout projector, 1 LAP, 2 the
  * LDS-exchange Sinkhorn projectors of round 1) of G graphs x n nodes from LDS, one wavefront per
  * graph, as inside ttdg_gagm_solve; ticks[0] receives the shader-cycle count. */

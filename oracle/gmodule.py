@@ -138,7 +138,7 @@ def gagm(A, W, U0, ms, n_univ=UNIV_SIZE, quad_weight=QUAD_WEIGHT, init_tau=GA_TA
     entered from GA_GM.forward :223-244 (W detached :225).
 
     ``trace`` (optional dict) receives 'V0' (first-iteration V), 'iters' (per-stage
-    iteration counts) and 'stages' (projector/tau per stage) for parity tests.  ``max_stages`` > 0 (test hook, not
+    iteration counts), 'stages' (projector/tau per stage) and 'states' (U at the end of every stage) for parity tests.  ``max_stages`` > 0 (test hook, not
     in the reference) returns the state after that many stages of the schedule.  ``perturb`` (test hook, not in the
     reference): callable ``U = perturb(U, stage, i)`` applied to every Sinkhorn-stage projection - rounding-sized noise
     injected where a second implementation's projector would round differently (tests/golden/make_golden.py uses it to
@@ -152,7 +152,7 @@ def gagm(A, W, U0, ms, n_univ=UNIV_SIZE, quad_weight=QUAD_WEIGHT, init_tau=GA_TA
     projector = "sinkhorn"
     nstages = 0
     if trace is not None:
-        trace.update(iters=[], stages=[])
+        trace.update(iters=[], stages=[], states=[])
     while True:
         for i in range(max_iter):
             lastU2, lastU = lastU, U
@@ -178,6 +178,7 @@ def gagm(A, W, U0, ms, n_univ=UNIV_SIZE, quad_weight=QUAD_WEIGHT, init_tau=GA_TA
         if trace is not None:
             trace["iters"].append(i + 1)
             trace["stages"].append((projector, tau))
+            trace["states"].append(U.clone())                 # the state the NEXT stage starts from
         nstages += 1
         if projector == "hungarian" or (max_stages and nstages >= max_stages):
             break

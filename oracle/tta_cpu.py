@@ -114,7 +114,7 @@ class _CpuBackend:
         return paste_masks_in_image_torch(masks.reshape(masks.shape[0], 1, masks.shape[-2], masks.shape[-1]), boxes, (H, W), threshold)
 
 
-def _model_and_batches(n_steps, batch, size, teacher_forced, weights=None):
+def _model_and_batches(n_steps, batch, size, teacher_forced, weights=None, first_batch=0, perturb=None):
     from ttdg_mgm_amd import data
     from ttdg_mgm_amd.config import get_cfg
     from ttdg_mgm_amd.modeling import build_model, detector
@@ -122,17 +122,26 @@ def _model_and_batches(n_steps, batch, size, teacher_forced, weights=None):
     cfg.MODEL.DEVICE = "cpu"
     cfg.TEST.BATCH = batch
     name = "synthfundus_cpu_baseline"
-    data.register_synthetic(name, n_steps * batch, size=size, cfg_id=2)        # the first images of bench.py's stream
+    data.register_synthetic(name, (first_batch + n_steps) * batch, size=size, cfg_id=2)        # the first images of bench.py's stream
     torch.manual_seed(0)
     model = build_model(cfg)
     model.teacher_forced = teacher_forced
-    batches = list(data.build_detection_test_loader(cfg, name))
+    batches = list(data.build_detection_test_loader(cfg, name))[first_batch:]
     if weights:
         from ttdg_mgm_amd.engine.checkpoint import load_weights
         load_weights(model, weights)
     else:
         from ttdg_mgm_amd.modeling import calibrate_frozen_bn
         calibrate_frozen_bn(model, batches[0])
+    if perturb:
+        # a rounding-sized relative perturbation of every trainable tensor (drift studies: how far does the port's OWN
+        # free-running trajectory move when its arithmetic is disturbed at the level of one fp32 ulp?)
+        eps, seed = perturb
+        g = torch.Generator().manual_seed(int(seed))
+        with torch.no_grad():
+            for q in model.parameters():
+                if q.requires_grad:
+                    q.mul_(1 + eps * torch.randn(q.shape, generator=g))
     return cfg, model, batches, detector, name
 
 
@@ -178,11 +187,11 @@ def _one_rep(model, cfg, batches, name):
     return dt, res
 
 
-def run(n_steps, batch, size, teacher_forced=True, weights=None, reps=3, warmup=1):
+def run(n_steps, batch, size, teacher_forced=True, weights=None, reps=3, warmup=1, first_batch=0, perturb=None):
     """``warmup`` untimed-for-the-median repetitions, then ``reps`` timed ones, every repetition from the same initial
     weights (the state dict is restored outside the timed part).  Returns times, warm-up times and the Dice of the FIRST
     repetition (checkpoint -> n TTA steps -> eval), which is what bench.py compares with the GPU."""
-    cfg, model, batches, detector, name = _model_and_batches(n_steps, batch, size, teacher_forced, weights)
+    cfg, model, batches, detector, name = _model_and_batches(n_steps, batch, size, teacher_forced, weights, first_batch, perturb)
     init = {k: v.detach().clone() for k, v in model.state_dict().items()}
     saved = detector._backend
     detector._backend = _CpuBackend

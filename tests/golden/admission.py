@@ -125,24 +125,57 @@ def census(A, W, U0, sizes):
     reference algorithm's own spread."""
     from ttdg_mgm_amd import synth
     sizes = list(sizes)
-    t32 = {}
-    runs = [og.gagm(A, W, U0, sizes, trace=t32), og.gagm(A.double(), W.double(), U0.double(), sizes).float()]
+    traces = [dict() for _ in range(8)]
+    t32 = traces[0]
+    runs = [og.gagm(A, W, U0, sizes, trace=t32), og.gagm(A.double(), W.double(), U0.double(), sizes, trace=traces[1]).float()]
     for k, eps in enumerate((1e-7, 1e-6)):
         g = synth.gen(9100 + k)
-        runs.append(og.gagm(A, W * (1 + eps * synth.normal(g, tuple(W.shape))), U0 * (1 + eps * synth.normal(g, tuple(U0.shape))), sizes))
+        runs.append(og.gagm(A, W * (1 + eps * synth.normal(g, tuple(W.shape))), U0 * (1 + eps * synth.normal(g, tuple(U0.shape))), sizes,
+                            trace=traces[2 + k]))
     for k, eps in enumerate((1e-6, 1e-6, 1e-5, 1e-5)):
-        runs.append(og.gagm(A, W, U0, sizes, perturb=noise_hook(eps, 200 + k)))
+        runs.append(og.gagm(A, W, U0, sizes, perturb=noise_hook(eps, 200 + k), trace=traces[4 + k]))
     X0 = runs[0] @ runs[0].t()
     stable = all(bool(torch.equal(U @ U.t(), X0)) for U in runs[1:])
     return dict(stable=stable, U32=runs[0], iters32=t32["iters"], objectives=[float((W * (U @ U.t())).sum()) for U in runs],
-                losses=[perm_loss_of(W, U, sizes) for U in runs])
+                losses=[perm_loss_of(W, U, sizes) for U in runs], stage_states=[[u.float() for u in t["states"]] for t in traces],
+                stage_iters=[list(t["iters"]) for t in traces])
 
 
-def within_spread(value, samples, rel=1e-2):
-    """value in [min - range, max + range] of the reference's own answers, plus a relative floor of 1 %: six runs under-sample
-    the spread (five of them may coincide), and ONE reassigned node moves <W, U U^T> by up to 2 G max(W) ~ 0.3-0.5 % at the
-    bench's sizes, the loss by about as much - the floor admits a handful of reassigned nodes, no more."""
+def stage_agreement(stage_states):
+    """Per stage k of the schedule (0-based; the last one is the Hungarian stage): the largest |U_k(run) - U_k(run 0)| over the
+    reference algorithm's own runs - how well the STATE at the end of stage k is defined by the inputs (the
+    state, not the iteration count).  Runs that ended early (fewer stages) count as disagreeing."""
+    n = max(len(s) for s in stage_states)
+    out = []
+    for k in range(n):
+        if any(len(s) <= k for s in stage_states):
+            out.append(float("inf"))
+            continue
+        out.append(max(float((s[k] - stage_states[0][k]).abs().max()) for s in stage_states[1:]))
+    return out
+
+
+def within_spread(value, samples, rel=0.0):
+    """value inside [min, max] of the reference algorithm's own answers (no +- one spread; ``rel`` = an
+    optional relative margin, 0 by default)."""
     lo, hi = min(samples), max(samples)
-    r = hi - lo
     slack = rel * max(abs(lo), abs(hi), 1e-12)
-    return lo - r - slack <= value <= hi + r + slack
+    return lo - slack <= value <= hi + slack
+
+
+def midrank(value, samples):
+    """Rank of ``value`` among samples + [value] (1 = smallest), ties at mid-rank.  If a second implementation of the algorithm is
+    exchangeable with the reference's own runs, this is uniform on 1 .. len(samples) + 1."""
+    below = sum(1 for x in samples if x < value)
+    ties = sum(1 for x in samples if x == value)
+    return below + (ties + 2) / 2.0
+
+
+def rank_sum_z(values, samples_per_step):
+    """Wilcoxon-type statistic over steps: (sum of mid-ranks - expectation) / standard deviation without ties (ties only shrink the
+    true deviation: conservative).  |z| large = the device's values sit systematically above / below the reference's own answers."""
+    n = len(values)
+    k = len(samples_per_step[0]) + 1
+    tot = sum(midrank(v, s) for v, s in zip(values, samples_per_step))
+    mean, var = n * (k + 1) / 2.0, n * (k * k - 1) / 12.0
+    return (tot - mean) / var ** 0.5

@@ -307,6 +307,7 @@ def test_supervised_matching_branch(setup):
         m(inputs, branch="supervised_target")
 
 
+@pytest.mark.multiprocess
 def test_sync_universe_step_equals_single_process_step():
     """Mode S (engine/sync_universe.py): 2 ranks x 2 images, one all-gather of the node embeddings + gradient all-reduce,
     against the single-process step on the same 4 images (tools/mode_s_check.py; two ranks share the GPU over gloo)."""
@@ -327,12 +328,18 @@ def test_sync_universe_step_equals_single_process_step():
         assert c["replicas_identical"] and c["replicated_loss_identical"] and c["same_gradient_set"], c
         assert abs(c["loss"] - c["loss_single_process"]) <= 1e-5 * max(1.0, abs(c["loss_single_process"])), c
         assert c["max_param_update"] > 1e-6, c                                  # the step did move the weights
-        # split: the vendor's convolution backward on 2 + 2 images vs on 4 (different algorithm, ~1 % on single elements)
-        # + 2 ulp of an O(1) fp32 parameter (the vendor's convolution backward is not run-to-run deterministic: a 1-ulp
-        # difference in p - lr * buf is 6e-8 whatever the size of the update)
-        assert c["max_param_diff_vs_single_process"] <= (0.03 if name == "split" else 1e-3) * c["max_param_update"] + 1.2e-7, c
+        # Both sides run the vendor's convolutions in their deterministic mode (tools/mode_s_check.py), and the tool repeats the
+        # single-process step to measure what is left of run-to-run movement ("single_process_rerun").  A parameter difference is
+        # counted only BEYOND 4 ulp of the parameter itself, element by element: p - lr * buf rounds to p's own grid, so one ulp of
+        # an O(1) weight (1.2e-7, 2.4e-7 from |p| = 2) says nothing about the step.  What remains is held to 1e-3 of the largest
+        # update for idle_rank (the same four images through the same kernels; only the reduction differs) and to 3 % for split
+        # (the convolution backward on 2 + 2 images vs on 4 is a different algorithm: ~1 % on single elements).
+        rel = 0.03 if name == "split" else 1e-3
+        noise = res["single_process_rerun"]["max_param_diff_beyond_4ulp"]
+        assert c["max_param_diff_beyond_4ulp"] <= rel * c["max_param_update"] + 2.0 * noise, (c, res["single_process_rerun"])
 
 
+@pytest.mark.multiprocess
 def test_train_net_eval_only_on_coco_json(tmp_path):
     """``train_net.py --eval-only`` end to end: COCO-json dataset written here (PNG images, polygon + RLE
     ground truth), a checkpoint in detectron2's {"model": ...} layout, two test datasets -> TTA + Dice per dataset, the
@@ -382,6 +389,7 @@ def test_train_net_eval_only_on_coco_json(tmp_path):
         assert set(v) == {"Dice Coefficient", "Enhanced Alignment Metric", "Structural Similarity Metric"}
 
 
+@pytest.mark.multiprocess
 def test_streaming_disk_loader_on_the_device_matches_the_resident_loader(tmp_path):
     """The loader path of bench.py's `ab.loader_inclusive`: a dataset pre-rendered to disk, read by worker
     processes into the shared page-locked ring, DMA from the ring slot, resize on the device.  Every item equals the resident

@@ -87,6 +87,45 @@ def test_gemm_all_layouts(dev, M, N, K):
     assert maxerr(C3, (0.5 * ref.t() + 2.0).float()) <= tol * 4
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 512, 256), (256, 256, 2048), (70, 130, 33), (64, 64, 32), (65, 63, 31), (5, 300, 129)])
+def test_gemm_pipelined_staging_every_operand_layout(dev, M, N, K):
+    """[r4] csrc/gemm.hip stages the next K slab global -> registers -> LDS behind the MFMAs, with 16-byte loads where the operand
+    allows them.  Every staging path - k-contiguous, m-contiguous and general strides for either operand, 16-byte loads legal or not
+    (odd leading dimension, base pointer off by one element), ragged edges in M, N and K, the split-K entry (256 x 256 x 2048) -
+    against the float64 product; and the k order of an accumulator does not depend on the path: all layouts of one product return
+    the SAME bits."""
+    from ttdg_mgm_amd import ops
+    g = synth.gen(M * 7 + N * 3 + K)
+    A, B = synth.normal(g, (M, K)).to(dev), synth.normal(g, (N, K)).to(dev)
+    ref = (A.double() @ B.double().t()).float()
+    tol = (2e-6 * K ** 0.5 * 4 + 1e-6) * 4
+    outs = []
+
+    def run(a, sam, sak, b, sbn, sbk, a_off=0, b_off=0):
+        C = torch.empty(M, N, device=dev)
+        ops.gemm(a, sam, sak, b, sbn, sbk, C, N, 1, M, N, K, a_off=a_off, b_off=b_off)
+        assert maxerr(C, ref) <= tol
+        outs.append(C)
+    At, Bt = A.t().contiguous(), B.t().contiguous()
+    run(A, K, 1, B, K, 1)                                    # NT: both k-contiguous
+    run(At, 1, M, Bt, 1, N)                                  # TN: both m-contiguous
+    run(A, K, 1, Bt, 1, N)                                   # NN
+    run(At, 1, M, B, K, 1)                                   # TT
+    # 16-byte loads illegal: odd leading dimension / base pointer off by one element
+    Aw = torch.zeros(M, K + 1, device=dev); Aw[:, :K] = A
+    Bw = torch.zeros(N, K + 3, device=dev); Bw[:, 1:K + 1] = B
+    run(Aw, K + 1, 1, Bw, K + 3, 1, b_off=1)
+    Atw = torch.zeros(K, M + 1, device=dev); Atw[:, 1:] = At
+    run(Atw, 1, M + 1, Bt, 1, N, a_off=1)
+    # general strides: neither index has unit stride
+    A2 = torch.zeros(M, 2 * K, device=dev); A2[:, ::2] = A
+    B2 = torch.zeros(N, 3 * K, device=dev); B2[:, ::3] = B
+    run(A2, 2 * K, 2, B2, 3 * K, 3)
+    run(A2, 2 * K, 2, B, K, 1)
+    for C in outs[1:]:
+        assert torch.equal(C, outs[0]), "the accumulation order must not depend on the operand layout"
+
+
 def test_gemm_grouped_all_layouts_and_two_segments(dev):
     """csrc/gemm_grouped.hip: up to eight products in one launch (32 x 32 tiles, K split over the wavefronts), every operand
     layout (NT / TN / NN, transposed C, column offsets), bias / alpha / beta, a second K segment, empty and ragged shapes - each
@@ -815,6 +854,34 @@ def test_fused_sgd_vs_oracle(dev):
         assert maxerr(p, r) <= 1e-6
 
 
+def test_fused_sgd_follows_a_layout_change_of_the_parameter(dev):
+    """the backbone moves its filters to channels-last in place on its first fp32 GPU forward (and ``load_state_dict``
+    brings momentum buffers in the layout they were saved in).  A buffer made BEFORE such a change must be re-laid: the kernel is
+    element-wise over storage order.  Two steps with a layout change of the parameter (and an NCHW gradient) in between, against
+    the oracle's step on the logical values."""
+    from oracle import gmodule as og
+    from ttdg_mgm_amd.optim import FusedSGD
+    g = synth.gen(321)
+    shape = (24, 16, 3, 3)
+    p0 = synth.normal(g, shape)
+    ref_p, buf = [p0.clone()], [None]
+    dp = torch.nn.Parameter(p0.clone().to(dev))
+    opt = FusedSGD([dp], lr=0.005, momentum=0.9, weight_decay=1e-4)
+    for step in range(3):
+        gr = synth.normal(g, shape)
+        if step == 1:                           # the parameter changes its storage order; the buffer of step 0 is NCHW
+            dp.data = dp.data.contiguous(memory_format=torch.channels_last)
+        if step == 2:                           # a buffer restored in the other layout (load_state_dict)
+            st = opt.state[dp]
+            st["momentum_buffer"] = st["momentum_buffer"].contiguous()
+        dp.grad = gr.to(dev)                    # NCHW gradient for a channels-last parameter from step 1 on
+        opt.step()
+        og.sgd_step(ref_p, [gr], buf, 0.005, 0.9, 1e-4)
+        assert dp.is_contiguous(memory_format=torch.channels_last) == (step >= 1)
+        assert maxerr(dp, ref_p[0]) <= 1e-6, step
+        assert maxerr(opt.state[dp]["momentum_buffer"], buf[0]) <= 1e-6, step
+
+
 # ------------------------------------------------------------------------------------------- detection helpers (N1)
 def test_nms_vs_oracle(dev):
     from oracle import detection as od
@@ -947,6 +1014,39 @@ def test_large_solver_matches_host_driven_statement(dev, sizes, seed):
         else:
             LEDGER["large_solver.hungarian_step_identical"] += 1
     print(sizes, "Sinkhorn-projector steps: worst (native, host-driven) deviation from the fp64 statement = (%.3e, %.3e)" % worst)
+
+
+@pytest.mark.parametrize("sizes,seed", [((256,) * 8, 610), ((129, 64, 300, 33), 611), ((512, 40, 65), 612), ((520, 100), 613)])
+def test_large_solver_sinkhorn_projectors_agree_with_the_float64_step(dev, sizes, seed):
+    """[r4] The multi-workgroup solver's Sinkhorn projector is now the block-layout one over all wavefronts of the workgroup
+    (gagm_large.hip: gl_project_blk - one exponential per entry per sweep pair, row sums met in LDS once per pair); round 3's
+    column-per-thread projector stays behind cfg.variant = TTDG_GAGM_COLUMN_PROJECTOR (and serves graphs of more than 512 nodes).
+    One solver step from U0 and from a sharpened state at every temperature of the schedule: BOTH within the derived gate of the
+    float64 statement of the step, every block size class (CB = 2, 4, 8; ragged last block; a < 33-node graph beside large ones;
+    the 1024-thread build)."""
+    from oracle import gmodule as og
+    from ttdg_mgm_amd import _lib, ops
+    A, W, U0 = cases.gagm_inputs(sizes, seed)
+    ap, Wd, gr = _pack(A, sizes).to(dev), W.to(dev), ops.graphs(sizes)
+    Ad, Wdd = A.double(), W.double()
+    state = U0
+    for tau in (0.1, 0.05, 0.025, 0.0125, 0.00625):
+        Ud = state.double()
+        B64 = Ad @ Ud
+        V64 = (B64 @ (Ud.t() @ B64) + Wdd @ Ud) / len(sizes)
+        U64 = og._project_sinkhorn(V64, list(sizes), 32, tau, 20)
+        if len(sizes) == 2:
+            U64[:sizes[0]] = torch.eye(sizes[0], 32, dtype=torch.float64)
+        # the float32 oracle on the same state: what the reference's own fp32 path loses against the float64 statement
+        B32 = A @ state
+        U32 = og._project_sinkhorn((B32 @ (state.t() @ B32) + W @ state) / len(sizes), list(sizes), 32, tau, 20)
+        if len(sizes) == 2:
+            U32[:sizes[0]] = torch.eye(sizes[0], 32)
+        for name, var in (("block", 0), ("column", _lib.GAGM_COLUMN_PROJECTOR)):
+            Ug, Vg = ops.gagm_one_step(ap, Wd, state.to(dev).contiguous(), gr, list(sizes), tau, variant=var | _lib.GAGM_FORCE_LARGE)
+            assert maxerr(Vg, V64.float()) <= TOL * max(1.0, float(V64.abs().max()))
+            derived_gate("large solver, %s projector, tau %g" % (name, tau), Ug, U32, U64, quiet=True)
+        state = U64.float()                       # the next temperature starts from the sharpened state
 
 
 def test_cfg3_scale_front_end_and_large_solver(dev):

@@ -149,17 +149,59 @@ def test_cfg2_full_size_tta_step_matches_host_pipeline(trained):
     c = admission.census(otr["A"], otr["Wds"], otr["U0"], [len(x) for x in nodes])
     Ud = tr3["Ub"].cpu()
     print("host solve rounding-stable:", c["stable"])
+    sizes = [len(x) for x in nodes]
     if c["stable"]:
         assert torch.equal(Ud @ Ud.t(), c["U32"] @ c["U32"].t()), "permutation matrices differ from the host pipeline"
         assert it_dev[:5] == it_ref[:5]
     else:
-        assert admission.within_spread(float((otr["Wds"] * (Ud @ Ud.t())).sum()), c["objectives"])
-        assert admission.within_spread(admission.perm_loss_of(otr["Wds"], Ud, [len(x) for x in nodes]), c["losses"])
+        _not_worse_than_every_reference_answer(float((otr["Wds"] * (Ud @ Ud.t())).sum()), c["objectives"], sizes)
+    # (4c) the STATE at the end of every stage of the schedule on which the reference's own runs agree
+    st = _stage_statement(c, _device_stage_states(tr3["apack"], tr3["Wds"], tr3["U0"], sizes, len(c["stage_states"][0]) - 1))
+    print("stage states:", st)
+    assert sum(x["defined"] for x in st) >= 1
+    for x in st:
+        assert not x["defined"] or x["device"] <= STATE_TOL, st
+
+
+STATE_TOL = 1e-4               # BASELINE.json north_star: "permutation matrices ... within 1e-4 fp32" - applied to the solver's STATE
+
+
+def _device_stage_states(apack, W, U0, sizes, nstages):
+    """U at the end of stage 1 .. nstages of the schedule, from the product solver (ttdg_gagm_solve with cfg.max_stages = k)."""
+    from ttdg_mgm_amd import ops
+    sizes = [int(n) for n in sizes]
+    gr = ops.graphs(sizes)
+    return [ops.gagm_solve(apack, W, U0, gr, sizes, ops.gagm_cfg(max_stages=k))[0].cpu() for k in range(1, nstages + 1)]
+
+
+def _stage_statement(c, dev_states):
+    """compare the STATE, not the count.  For every Sinkhorn stage k (tau = 0.1, 0.05, 0.025, 0.0125, 0.00625):
+    ``spread`` = the largest |U_k(run) - U_k(float32 run)| over the reference algorithm's own eight runs (admission.census),
+    ``defined`` = spread <= STATE_TOL (the inputs determine the state to the tolerance the comparison is made at),
+    ``device`` = |U_k(device) - U_k(float32 oracle)|_max."""
+    import admission
+    spread = admission.stage_agreement(c["stage_states"])
+    ref = c["stage_states"][0]
+    out = []
+    for k, Ud in enumerate(dev_states):
+        out.append(dict(stage=k, spread=spread[k], defined=bool(spread[k] <= STATE_TOL), device=float((Ud - ref[k]).abs().max()),
+                        ref32_vs_ref64=float((c["stage_states"][1][k] - ref[k]).abs().max()) if len(c["stage_states"][1]) > k else None))
+    return out
+
+
+def _not_worse_than_every_reference_answer(obj, ref_objs, sizes):
+    """The solver MAXIMISES <W, U U^T>.  Hard per-batch statement where the reference's answer is not well defined: the device's
+    objective is not below the WORST of the reference's own eight answers by more than one reassigned node (moving one node of
+    one graph to another universe column changes <= 2 (G - 1) entries of U U^T in each direction, each weighted by a Wds entry
+    <= 1: at most 4 (G - 1)).  No upper gate: an objective above the reference's best is a better answer, not an error."""
+    G = len(sizes)
+    assert obj >= min(ref_objs) - 4.0 * (G - 1), (obj, ref_objs)
 
 
 CENSUS_STEPS = 16
-CENSUS_MIN_STRONG = 0          # recorded (profiles/r03_trained_census.json): 0 of 16 - under per-projection rounding noise the reference's own
-                               # answer is not well defined on ANY batch of this regime; all 16 take the spread statement
+CENSUS_MIN_DEFINED_STATES = 40  # of 16 x 3 stage-end states (tau = 0.1, 0.05, 0.025) on which the reference's own eight runs must agree to
+                                # STATE_TOL for the state statement to be non-vacuous: a property of the REFERENCE ALGORITHM on the bench's inputs
+                                # (its final answer is well defined on 0 of 16 batches - profiles/r03_trained_census.json - its early states are)
 
 
 def test_trained_regime_solver_census(trained):
@@ -199,10 +241,12 @@ def test_trained_regime_solver_census(trained):
             assert torch.equal(Ud @ Ud.t(), c["U32"] @ c["U32"].t()), (step, "permutations differ where the reference's answer is well defined")
             assert it[:5] == c["iters32"][:5], (step, it, c["iters32"])
         else:
-            assert admission.within_spread(obj, c["objectives"]), (step, obj, c["objectives"])
-            assert admission.within_spread(ld, c["losses"]), (step, ld, c["losses"])
+            _not_worse_than_every_reference_answer(obj, c["objectives"], sizes)
+        st = _stage_statement(c, _device_stage_states(tr["apack"], tr["Wds"], tr["U0"], sizes, len(c["stage_states"][0]) - 1))
+        for x in st:
+            assert not x["defined"] or x["device"] <= STATE_TOL, (step, st)
         rec.append(dict(step=step, sizes=sizes, strong=bool(c["stable"]), device_iters=it, oracle_iters=c["iters32"], objective_device=obj,
-                        objective_oracle_runs=c["objectives"], loss_device=ld, loss_oracle_runs=c["losses"],
+                        objective_oracle_runs=c["objectives"], loss_device=ld, loss_oracle_runs=c["losses"], stage_states=st,
                         device_equals_oracle32=bool(torch.equal(Ud @ Ud.t(), c["U32"] @ c["U32"].t()))))
     # the reproducible part of the trajectory holds in the live regime too: the stages at tau = 0.1, 0.05, 0.025 take the
     # reference's iteration counts on EVERY step, the tau = 0.0125 stage on most (recorded: 15 of 16)
@@ -210,15 +254,35 @@ def test_trained_regime_solver_census(trained):
     n4 = sum(r["device_iters"][:4] == r["oracle_iters"][:4] for r in rec)
     assert n4 >= CENSUS_STEPS - 4, n4
     nstrong = sum(r["strong"] for r in rec)
+    # ---- the state statement (asserted above element by element): how much of it was there to assert
+    ndef = [sum(1 for r in rec if len(r["stage_states"]) > k and r["stage_states"][k]["defined"]) for k in range(5)]
+    worst = [max([r["stage_states"][k]["device"] for r in rec if len(r["stage_states"]) > k and r["stage_states"][k]["defined"]] or [0.0]) for k in range(5)]
+    # the reference's own runs define the state at the end of the tau = 0.1, 0.05 and 0.025 stages on (nearly) every batch
+    assert sum(ndef[:3]) >= CENSUS_MIN_DEFINED_STATES, ndef
+    # ---- where the final answer is not well defined: is the device exchangeable with the reference's own runs?  Rank of the
+    # device's objective / loss among the eight reference answers of the same batch, summed over the batches (Wilcoxon-type;
+    # |z| <= 3.5 is a < 5e-4 two-sided event for an exchangeable implementation): a solver whose answers are systematically worse
+    # (or whose loss is systematically off) than the reference's fails this, whatever the per-batch spread
+    weak = [r for r in rec if not r["strong"]]
+    z_obj = admission.rank_sum_z([r["objective_device"] for r in weak], [r["objective_oracle_runs"] for r in weak]) if weak else 0.0
+    z_loss = admission.rank_sum_z([r["loss_device"] for r in weak], [r["loss_oracle_runs"] for r in weak]) if weak else 0.0
+    assert z_obj >= -3.5, z_obj                  # one-sided: never systematically below the reference's objective
+    assert abs(z_loss) <= 3.5, z_loss
+    outside = sum(not admission.within_spread(r["objective_device"], r["objective_oracle_runs"]) for r in weak) + \
+        sum(not admission.within_spread(r["loss_device"], r["loss_oracle_runs"]) for r in weak)
     summary = dict(steps=len(rec), strong=nstrong, weak=len(rec) - nstrong, first_three_stage_counts_identical=len(rec), first_four_stage_counts_identical=n4, device_equals_oracle32=sum(r["device_equals_oracle32"] for r in rec),
-                   mean_iterations=sum(sum(r["device_iters"]) for r in rec) / len(rec), records=rec)
+                   mean_iterations=sum(sum(r["device_iters"]) for r in rec) / len(rec),
+                   stage_states_defined_by_the_reference=ndef, stage_states_worst_device_deviation=worst, state_tolerance=STATE_TOL,
+                   rank_sum_z_objective=z_obj, rank_sum_z_loss=z_loss, outside_reference_min_max=outside, min_max_checks=2 * len(weak),
+                   records=rec)
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "trained_census.json"), "w") as f:
         json.dump(summary, f, indent=1)
-    print("trained-regime census: identical permutations asserted on %d of %d steps, spread statement on %d; device == float32 oracle on %d"
-          % (nstrong, len(rec), len(rec) - nstrong, summary["device_equals_oracle32"]))
-    assert len(rec) == CENSUS_STEPS and nstrong >= CENSUS_MIN_STRONG
+    print("trained-regime census: stage states defined by the reference (of %d batches) %s, worst device deviation there %s; final answer well "
+          "defined on %d; rank-sum z objective %.2f loss %.2f; outside the reference's min-max %d of %d checks"
+          % (len(rec), ndef, ["%.1e" % w for w in worst], nstrong, z_obj, z_loss, outside, 2 * len(weak)))
+    assert len(rec) == CENSUS_STEPS
 
 
 TRAJ_STEPS = int(os.environ.get("TTDG_TRAJ_STEPS", "8"))

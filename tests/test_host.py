@@ -318,9 +318,14 @@ def test_reference_yaml_decodes_like_yacs(tmp_path):
     a str: yacs decodes them, so must merge_from_file; command-line overrides go through the same architecture guard."""
     cfg = get_cfg()
     p = tmp_path / "t.yaml"
-    p.write_text('DATASETS:\n  TEST: ("A_train", "B_test")\nTEST:\n  BATCH: 4\nSOLVER:\n  BASE_LR: "0.01"\n')
+    p.write_text('DATASETS:\n  TEST: ("A_train", "B_test")\nTEST:\n  BATCH: 4\nSOLVER:\n  BASE_LR: "0.01"\nOUTPUT_DIR: "true"\nMODEL:\n  WEIGHTS: "null"\n')
     cfg.merge_from_file(str(p))
     assert cfg.DATASETS.TEST == ["A_train", "B_test"] and cfg.TEST.BATCH == 4 and cfg.SOLVER.BASE_LR == 0.01
+    # a QUOTED yaml string that is not a Python literal stays a string in a file merge (yacs keeps it when literal_eval fails) ...
+    assert cfg.OUTPUT_DIR == "true" and cfg.MODEL.WEIGHTS == "null"
+    # ... the yaml-scalar reading is for command-line values only
+    cfg.merge_from_list(["TEST.TTT", "true"])
+    assert cfg.TEST.TTT is True
     with pytest.raises(ValueError):
         cfg.merge_from_list(["MODEL.MASK_ON", "False"])
 
@@ -431,23 +436,29 @@ def test_disk_stream_ring_slots(tmp_path):
 
 def test_shipped_miopen_db_is_staged_to_a_private_writable_copy(monkeypatch, tmp_path):
     """The package ships MIOpen find-db / perf-db records for the bench shapes (ttdg-mgm_amd/miopen_db) and points
-    MIOPEN_USER_DB_PATH at a COPY under the temp directory (MIOpen writes to its user db path; ranks may race: atomic renames,
-    directory named after the content).  An explicit MIOPEN_USER_DB_PATH or TTDG_MIOPEN_DB=0 leaves the environment alone."""
+    MIOPEN_USER_DB_PATH at a COPY under the user's cache directory (MIOpen writes to its user db path; ranks may race: atomic
+    renames, directory named after the content; 0700 and owned by this user - ADVICE r3: not a predictable world-writable /tmp
+    path).  An explicit MIOPEN_USER_DB_PATH or TTDG_MIOPEN_DB=0 leaves the environment alone."""
     import os
-    import tempfile
+    import stat
     import ttdg_mgm_amd as pkg
     files = sorted(f for f in os.listdir(pkg.MIOPEN_DB) if f.endswith(".txt"))
     assert len(files) == 2 and any(f.endswith(".ufdb.txt") for f in files) and any(f.endswith(".udb.txt") for f in files)
     assert all(f.startswith("gfx950") for f in files)                     # keyed by device: ignored on anything else
-    monkeypatch.setattr(tempfile, "tempdir", str(tmp_path))
+    monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path))
     dst = pkg._stage_miopen_db()
-    assert dst.startswith(str(tmp_path)) and dst.rstrip("/").endswith("miopen_db") and sorted(os.listdir(dst)) == files
+    assert dst.startswith(str(tmp_path / "ttdg_mgm_amd")) and "miopen_db_" in os.path.basename(dst) and sorted(os.listdir(dst)) == files
+    for d in (dst, os.path.dirname(dst)):
+        st = os.stat(d)
+        assert st.st_uid == os.getuid() and stat.S_IMODE(st.st_mode) == 0o700
     for f in files:
         assert open(os.path.join(dst, f), "rb").read() == open(os.path.join(pkg.MIOPEN_DB, f), "rb").read()
     with open(os.path.join(dst, files[0]), "a") as fh:                     # MIOpen appends records: a second staging keeps them
         fh.write("x=y\n")
     assert pkg._stage_miopen_db() == dst and open(os.path.join(dst, files[0])).read().endswith("x=y\n")
     assert not [f for f in os.listdir(dst) if f.endswith(".tmp")]
+    os.chmod(os.path.dirname(dst), 0o777)                                  # someone loosened the parent: tightened again
+    assert pkg._stage_miopen_db() == dst and stat.S_IMODE(os.stat(os.path.dirname(dst)).st_mode) == 0o700
     # the switches
     for env, want in (({"TTDG_MIOPEN_DB": "0"}, None), ({"MIOPEN_USER_DB_PATH": "/somewhere/else"}, "/somewhere/else"), ({}, dst)):
         env = dict(env)

@@ -17,10 +17,10 @@ def main():
     dev = torch.device("cuda:0")
     if len(sys.argv) > 3:
         from ttdg_mgm_amd import _lib
-        _lib.load().ttdg_debug_set_gagm_flags(int(sys.argv[3]))
+        ops.GAGM_VARIANT |= _lib.GAGM_LDS_PROJECTORS if int(sys.argv[3]) & 1 else 0
     if len(sys.argv) > 4:
         from ttdg_mgm_amd import _lib
-        _lib.load().ttdg_debug_set_gagm_threads(int(sys.argv[4]))
+        ops.GAGM_VARIANT |= _lib.GAGM_256_THREADS if int(sys.argv[4]) == 256 else 0
     dump = torch.load(path, weights_only=True)
     tot_us, tot_it = 0.0, 0
     for k, d in enumerate(dump):

@@ -26,17 +26,16 @@ for G in (4, 8, 16, 32):
     W, U0 = W.to(dev), U0.to(dev)
     gr = ops.graphs(sizes)
     row = []
-    for name, thr in (("single-workgroup", 1 << 30), ("multi-workgroup", 1)):
-        lib.ttdg_debug_set_gagm_large_from(thr)
-        U, info, _ = ops.gagm_solve(apack, W, U0, gr, sizes)
+    for name, var in (("single-workgroup", _lib.GAGM_FORCE_SINGLE), ("multi-workgroup", _lib.GAGM_FORCE_LARGE)):
+        cfg = ops.gagm_cfg(variant=var)
+        U, info, _ = ops.gagm_solve(apack, W, U0, gr, sizes, cfg)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(3):
-            U, info, _ = ops.gagm_solve(apack, W, U0, gr, sizes)
+            U, info, _ = ops.gagm_solve(apack, W, U0, gr, sizes, cfg)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 3
         it = info.cpu().tolist()
         iters = sum(it[:6])
         row.append((name, dt * 1e3, iters, dt / max(iters, 1) * 1e6, float(U.sum())))
-    lib.ttdg_debug_set_gagm_large_from(0)
     print("G=%2d M=%4d " % (G, sum(sizes)) + "  ".join("%s %.2f ms (%d it, %.1f us/it, |U|=%d)" % r for r in row), flush=True)

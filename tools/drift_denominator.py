@@ -1,0 +1,105 @@
+"""Free-running drift with a denominator.  From the bench's checkpoint, K continual FREE-RUNNING adaptation
+steps (own detections, own solve, weights and momentum carried over) on a stream, then the Dice pass over the same batches
+(reference engine/trainer.py:452,469-485).  The solver's last Sinkhorn stage is rounding-chaotic in this regime, so
+two exact implementations do not walk the same trajectory: what can be asked is that the DEVICE lies inside the spread of the
+CPU port's OWN answers under rounding-sized disturbances -
+    thread counts (another reduction order in every convolution / GEMM): 4, 16, 64
+    a 1e-7-relative perturbation of every trainable tensor (16 and 64 threads)
+- and that the device's own run-to-run spread (the vendor convolutions are not bit-reproducible) is of the same size.
+usage: drift_denominator.py [K=32] [streams=3] [device_runs=4]     -> one JSON document on stdout."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch  # noqa: E402
+
+VARIANTS = [("threads4", 4, None), ("threads16", 16, None), ("threads64", 64, None), ("threads16_eps1e-7", 16, (1e-7, 11)),
+            ("threads64_eps1e-7", 64, (1e-7, 12))]
+KEYS = ("Dice Coefficient", "Enhanced Alignment Metric", "Structural Similarity Metric")
+
+
+def cpu_children(K, first_batch, path, variants=VARIANTS):
+    out = []
+    for name, threads, pert in variants:
+        code = ("import json, sys, torch; sys.path.insert(0, %r); torch.set_num_threads(%d); from oracle import tta_cpu; "
+                "r = tta_cpu.run(%d, 4, 512, teacher_forced=False, weights=%r, reps=1, warmup=0, first_batch=%d, perturb=%r); "
+                "print('CPUJSON' + json.dumps(r))" % (ROOT, threads, K, path, first_batch, pert))
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        out.append((name, subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env, cwd=ROOT)))
+    return out
+
+
+def device_run(cfg, path, batches, dicts):
+    from ttdg_mgm_amd.engine import BaselineTrainer
+    from ttdg_mgm_amd.engine.checkpoint import load_weights
+    from ttdg_mgm_amd.engine.trainer import run_eval_batches
+    from ttdg_mgm_amd.evaluation import DiceEvaluator
+    model = BaselineTrainer.build_model(cfg)
+    load_weights(model, path)
+    opt = BaselineTrainer.build_optimizer(cfg, model)
+    model.train()
+    model.multi_matching_unsup.eval()          # attention dropout off, as in the CPU port
+    for b in batches:
+        BaselineTrainer.tta_step(model, opt, b)
+    ev = DiceEvaluator("drift_ds", cfg.TEST.DICE_THRES, dataset_dicts=dicts)
+    model.eval()
+    run_eval_batches(model, batches, ev, 1, 1)
+    return dict(ev.evaluate(), kept=len(ev.dice_scores))
+
+
+def spread(rows):
+    return {k: dict(min=min(r[k] for r in rows), max=max(r[k] for r in rows), mean=sum(r[k] for r in rows) / len(rows)) for k in KEYS}
+
+
+def study(K, streams, device_runs, cfg, dev, path, variants=VARIANTS, log=lambda m: None):
+    from ttdg_mgm_amd import data
+    from ttdg_mgm_amd.engine import BaselineTrainer
+    out = []
+    for s in range(streams):
+        t0 = time.perf_counter()
+        kids = cpu_children(K, s * K, path, variants)
+        data.register_synthetic("drift_ds", (s + 1) * K * 4, size=512, cfg_id=2)
+        BaselineTrainer.rank, BaselineTrainer.world, BaselineTrainer.device = 0, 1, dev
+        loader = BaselineTrainer.build_test_loader(cfg, "drift_ds")
+        batches = list(loader)[s * K:]
+        dicts = [it["dataset_dict"] for b in batches for it in b]
+        devs = [device_run(cfg, path, batches, dicts) for _ in range(device_runs)]
+        cpus = {}
+        for name, child in kids:
+            stdout, _ = child.communicate(timeout=6000)
+            r = json.loads([l for l in stdout.splitlines() if l.startswith("CPUJSON")][-1][7:])
+            cpus[name] = dict(r["dice"], seconds=r["times"][0])
+        cs, ds = spread(list(cpus.values())), spread(devs)
+        row = dict(stream=s, first_image=s * K * 4, steps=K, cpu_port=cpus, device=devs, cpu_spread=cs, device_spread=ds,
+                   device_inside_cpu_min_max={k: all(cs[k]["min"] <= d[k] <= cs[k]["max"] for d in devs) for k in KEYS},
+                   device_mean_minus_cpu_mean={k: ds[k]["mean"] - cs[k]["mean"] for k in KEYS},
+                   cpu_range={k: cs[k]["max"] - cs[k]["min"] for k in KEYS}, device_range={k: ds[k]["max"] - ds[k]["min"] for k in KEYS},
+                   wall_s=time.perf_counter() - t0)
+        log("stream %d: cpu %s | device %s" % (s, {k: (round(cs[k]["min"], 3), round(cs[k]["max"], 3)) for k in KEYS[:1]},
+                                                   [round(d[KEYS[0]], 3) for d in devs]))
+        out.append(row)
+    return out
+
+
+def main():
+    K = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    streams = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    device_runs = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    import synth_checkpoint as sc
+    from ttdg_mgm_amd.config import get_cfg
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "test_segment.yaml"))
+    dev = torch.device("cuda:0")
+    cfg.MODEL.DEVICE = "cuda:0"
+    path, rep = sc.get_or_make(cfg, dev, log=lambda m: None)
+    rows = study(K, streams, device_runs, cfg, dev, path, log=lambda m: print(m, file=sys.stderr, flush=True))
+    print(json.dumps(dict(steps=K, streams=rows, host_cores=os.cpu_count()), indent=1, default=str))
+
+
+if __name__ == "__main__":
+    main()

@@ -20,10 +20,26 @@ __version__ = "0.1.0"
 MIOPEN_DB = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "miopen_db")
 
 
+def _private_dir(path):
+    """``path`` as a directory that belongs to this user and nobody else can write to (0700), or None."""
+    import stat
+    try:
+        _os.makedirs(path, mode=0o700, exist_ok=True)
+        st = _os.lstat(path)
+        if not stat.S_ISDIR(st.st_mode) or st.st_uid != _os.getuid():
+            return None
+        if st.st_mode & 0o077:
+            _os.chmod(path, 0o700)
+        return path
+    except OSError:
+        return None
+
+
 def _stage_miopen_db():
     """MIOpen also WRITES to its user db directory (records for shapes it meets, lock and time-stamp files): give it a private
-    copy under the temp directory - named after the content, so a new db in the tree is picked up - and keep the tree clean
-    (and usable from a read-only checkout).  Several ranks may race here: every file appears by an atomic rename."""
+    copy - under the user's cache directory (0700, ownership checked; a fresh ``mkdtemp`` if that cannot be had), named after the
+    content, so a new db in the tree is picked up - and keep the tree clean (and usable from a read-only checkout).  Several ranks
+    may race here: every file appears by an atomic rename, and only files of this user are trusted."""
     import hashlib
     import shutil
     import tempfile
@@ -34,11 +50,18 @@ def _stage_miopen_db():
     for f in files:
         with open(_os.path.join(MIOPEN_DB, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
-    dst = _os.path.join(tempfile.gettempdir(), "ttdg_miopen_db_%d_%s_miopen_db" % (_os.getuid(), h.hexdigest()[:12]))
-    _os.makedirs(dst, exist_ok=True)
+    cache = _os.environ.get("XDG_CACHE_HOME") or _os.path.join(_os.path.expanduser("~"), ".cache")
+    base = _private_dir(_os.path.join(cache, "ttdg_mgm_amd"))
+    dst = _private_dir(_os.path.join(base, "miopen_db_" + h.hexdigest()[:12])) if base else None
+    if dst is None:
+        dst = tempfile.mkdtemp(prefix="ttdg_miopen_db_")          # 0700, ours, unpredictable
     for f in files:
         d = _os.path.join(dst, f)
-        if not _os.path.exists(d):
+        try:
+            ours = _os.lstat(d).st_uid == _os.getuid() and not _os.path.islink(d)
+        except OSError:
+            ours = None                                            # missing
+        if ours is None or not ours:
             tmp = "%s.%d.tmp" % (d, _os.getpid())
             shutil.copyfile(_os.path.join(MIOPEN_DB, f), tmp)
             _os.replace(tmp, d)

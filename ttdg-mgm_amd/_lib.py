@@ -22,10 +22,14 @@ class Graphs(C.Structure):
     _fields_ = [("G", C.c_int32), ("off", C.c_int32 * (MAX_GRAPHS + 1))]
 
 
+GAGM_LDS_PROJECTORS, GAGM_FORCE_LARGE, GAGM_FORCE_SINGLE, GAGM_256_THREADS, GAGM_COLUMN_PROJECTOR = 1, 2, 4, 8, 16    # ttdg_gagm_cfg_t.variant
+
+
 class GagmCfg(C.Structure):
     _fields_ = [("tau0", C.c_float), ("gamma", C.c_float), ("min_tau", C.c_float), ("tol", C.c_float),
                 ("quad_weight", C.c_float), ("max_iter", C.c_int32), ("sk_iter", C.c_int32),
-                ("max_stages", C.c_int32), ("start_hungarian", C.c_int32), ("no_cycle_skip", C.c_int32), ("profile", C.c_int32)]
+                ("max_stages", C.c_int32), ("start_hungarian", C.c_int32), ("no_cycle_skip", C.c_int32), ("profile", C.c_int32),
+                ("variant", C.c_int32)]
 
 
 class Levels(C.Structure):
@@ -92,9 +96,6 @@ SIGNATURES = {
     "ttdg_gagm_solve": (C.c_int, [_P, _P, _P, Graphs, GagmCfg, _P, _P, _P, _S]),
     "ttdg_lap_batched": (C.c_int, [_P, _I, _I, _I, _P, _S]),
     "ttdg_debug_set_lap_variant": (C.c_int, [_I]),
-    "ttdg_debug_set_gagm_large_from": (C.c_int, [_I]),
-    "ttdg_debug_set_gagm_threads": (C.c_int, [_I]),
-    "ttdg_debug_set_gagm_flags": (C.c_int, [_I]),
     "ttdg_debug_project": (C.c_int, [_P, _I, _I, _F, _I, _I, _I, _P, _P, _S]),
     "ttdg_perm_loss_workspace_bytes": (C.c_size_t, [Graphs]),
     "ttdg_perm_loss_fwd_bwd": (C.c_int, [_P, _P, Graphs, _F, _F, _P, _P, _P, _P, _S]),

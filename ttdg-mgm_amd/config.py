@@ -28,7 +28,8 @@ class CfgNode(dict):
             else:
                 # yacs decodes string leaves as Python literals: the reference yamls write tuples that way
                 # (`TEST: ("REFUGE_train", ...)` reaches yaml.safe_load as a str)
-                self[k] = _decode(v) if isinstance(v, str) else v
+                # - literals only: a quoted YAML string such as "true", "null" or "1e3" stays the string the file says it is
+                self[k] = _decode(v, yaml_scalars=False) if isinstance(v, str) else v
 
     def merge_from_file(self, path):
         with open(path) as f:
@@ -48,14 +49,16 @@ class CfgNode(dict):
         check_supported(self)
 
 
-def _decode(v):
-    """Command-line values as yacs reads them: a Python literal when it parses as one ("('a',)", "0.001", "True"), else
-    yaml scalars ("true", "null"), else the string itself."""
+def _decode(v, yaml_scalars=True):
+    """String values as yacs reads them: a Python literal when it parses as one ("('a',)", "0.001", "True"), else - for
+    command-line values only - yaml scalars ("true", "null"), else the string itself."""
     import ast
     try:
         out = ast.literal_eval(v)
         return list(out) if isinstance(out, tuple) else out
     except (ValueError, SyntaxError):
+        if not yaml_scalars:
+            return v
         try:
             return yaml.safe_load(v)
         except yaml.YAMLError:

@@ -898,12 +898,7 @@ int ttdg_gagm_large_solve(const float* Apack, const float* W, const float* U0, t
 // total node count above which graphs that WOULD fit the single-workgroup kernel still take the multi-workgroup solver:
 // the single workgroup streams the M x M matrix W once per iteration, which stops paying once W has left LDS and the
 // per-iteration W U product outgrows one CU (Mode S: the gathered multi-graph of 8 ranks is ~1000 nodes)
-static int g_gagm_large_from = GAGM_LARGE_FROM_DEFAULT;
-static int g_gagm_threads = 0;   // 0 / 512 = the default 512 threads; 256 = the spill-free one-wavefront-per-SIMD build (A/B runs)
-extern "C" int ttdg_debug_set_gagm_threads(int threads) { g_gagm_threads = (threads == 256 || threads == 512) ? threads : 0; return 0; }
-static int g_gagm_flags = 0;     // bit 0: graphs of 32..64 nodes take the generic register projector instead of sk_wave_project_mid (A/B, parity tests)
-extern "C" int ttdg_debug_set_gagm_flags(int flags) { g_gagm_flags = flags; return 0; }
-extern "C" int ttdg_debug_set_gagm_large_from(int total_nodes) { g_gagm_large_from = total_nodes > 0 ? total_nodes : GAGM_LARGE_FROM_DEFAULT; return 0; }
+// [r4] the A/B selectors travel in cfg.variant (include/ttdg_mgm.h): the library keeps no process-global switches for the solver
 
 extern "C" size_t ttdg_gagm_workspace_bytes(int M) {
   const size_t small = ga_ws_hist_off(M) * sizeof(float) + (size_t)GA_HIST * M + 64;
@@ -923,7 +918,10 @@ extern "C" int ttdg_gagm_solve(const float* Apack, const float* W, const float* 
     cmax = n > cmax ? n : cmax;
     asz += n * n;
   }
-  if (cmax > 128 || gr.off[gr.G] >= g_gagm_large_from)   // beyond one CU: the multi-workgroup solver (gagm_large.hip), same schedule and outputs
+  const bool fits_single = cmax <= 128 && gr.off[gr.G] <= 4096;
+  const bool large = !fits_single || (cfg.variant & TTDG_GAGM_FORCE_LARGE) ||
+                     (gr.off[gr.G] >= GAGM_LARGE_FROM_DEFAULT && !(cfg.variant & TTDG_GAGM_FORCE_SINGLE));
+  if (large)   // beyond one CU: the multi-workgroup solver (gagm_large.hip), same schedule and outputs
     return ttdg_gagm_large_solve(Apack, W, U0, gr, cfg, U, info, ws, (hipStream_t)stream);
   TTDG_LIMIT(gr.off[gr.G] <= 4096, "gagm: more than 4096 nodes in total");
   const int cmaxp = (cmax + 63) & ~63;
@@ -932,7 +930,7 @@ extern "C" int ttdg_gagm_solve(const float* Apack, const float* W, const float* 
   // the Sinkhorn / LAP loops); the spill-free 256-thread build (one wavefront per SIMD, 440 VGPRs) was measured SLOWER on
   // the bench (30.2 vs 27.1 us per iteration, 67.9 vs 72.0 images/s): B = A U and the convergence sweep want the eight
   // wavefronts.  It stays selectable for A/B runs (ttdg_debug_set_gagm_threads).
-  const int threads = (cmax <= 64 && g_gagm_threads == 256) ? 256 : 512;
+  const int threads = (cmax <= 64 && (cfg.variant & TTDG_GAGM_256_THREADS)) ? 256 : 512;
   const int waves = threads / 64;
   const int cw = cmax <= 64 ? 1 : 2;
   const size_t fixed = ga_fixed_lds_bytes(cmaxp, waves, cw, M);
@@ -946,7 +944,7 @@ extern "C" int ttdg_gagm_solve(const float* Apack, const float* W, const float* 
 #define GA_LAUNCH_T(L, WL, AL, C, T)                                                                                 \
   do {                                                                                                               \
     TTDG_ALLOW_LDS((gagm_kernel<L, WL, AL, T, C>), bytes);                                                           \
-    hipLaunchKernelGGL((gagm_kernel<L, WL, AL, T, C>), dim3(1), dim3(T), bytes, st, Apack, W, U0, gr, cfg, U, info, (float*)ws, cmaxp, g_gagm_flags); \
+    hipLaunchKernelGGL((gagm_kernel<L, WL, AL, T, C>), dim3(1), dim3(T), bytes, st, Apack, W, U0, gr, cfg, U, info, (float*)ws, cmaxp, cfg.variant & TTDG_GAGM_LDS_PROJECTORS); \
   } while (0)
 #define GA_LAUNCH(L, WL, AL, C)                                          \
   do {                                                                   \

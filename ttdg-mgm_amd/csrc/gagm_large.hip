@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void gagm_large_mul_kernel(const float* __rest
 
 #define GL_PTHREADS 1024
 #define GL_PWAVES (GL_PTHREADS / 64)
-#define GL_VL_OFF 1024   /* floats of dynamic LDS in front of the V_g tile (projector scratch) */
+#define GL_VL_OFF 1280   /* floats of dynamic LDS in front of the V_g tile (projector scratch: gl_project_blk needs 2 * 16 * 36 + 16) */
 
 // ---- Sinkhorn projector of one graph block with n >= 32 nodes: rows = universe (32), columns = nodes -----------------
 // One column per thread, held in registers (32 values): the column sweep is lane-local and exact (in-lane max); the row
@@ -369,6 +369,179 @@ __device__ __forceinline__ void gl_project_cols(const float* vl, int n, float sc
       out[k] = v;
     }
   }
+}
+
+// ---- [r4] block-layout Sinkhorn projector over ALL wavefronts of the workgroup (graphs of 33 .. 64 * 8 * PW / 8 nodes) --------
+// gl_project_cols above keeps one column per THREAD: every row sweep is 33 wavefront reductions of a 33-register line plus two
+// LDS hops and four barriers (3.5 us per sweep at 8 x 256).  Here the oriented problem (rows = 32 universe slots, columns =
+// nodes) is dealt out as in the single-workgroup solver's projector (gagm.hip: sk_wave_project_blk): lane (bi = lane >> 3,
+// bj = lane & 7) of wavefront w owns rows 4 bi .. 4 bi + 3 and columns 8 (w + PW b) + bj, b < CB = ceil(n / (8 PW)).  A sweep PAIR
+// evaluates e = exp2(L - f - g) ONCE: the row sweep needs s_a = sum_q e (in-lane sum, 3-step DPP butterfly over bj, then the
+// PW wavefront partials meet in LDS: 33 floats per wavefront, one barrier, summed in a fixed order - deterministic), the
+// column sweep exp2(L - f_new - g) = e / s_a - a multiply - summed over the lane's rows and a butterfly over bi: columns never
+// leave their wavefront.  The (n - 32) identical dummy rows are one replicated row.  As in every register projector the
+// previous potentials stabilise the exponentials; the first pair, and any pair in which a sum leaves [2^-60, 1e6] (a second
+// barrier settles that across the wavefronts), runs in the exact max-subtracted form.  Same map as sk_forward on r = 32,
+// c = n, mult = n - 32.
+template <int PW>
+struct GlXchg {
+  float* buf;      // 2 x PW x 36 floats (rows 0..31, dummy at 32), ping-pong
+  int* flag;       // PW words
+  int phase;
+  __device__ __forceinline__ float* slot() { float* b = buf + (phase & 1) * (PW * 36); ++phase; return b; }
+};
+
+template <int PW, bool kMax>
+__device__ __forceinline__ void gl_rows_meet(GlXchg<PW>& x, float (&v)[4], float& vd, int wave, int bi, int bj, int lane) {
+  float* b = x.slot();
+  if (bj == 0) *reinterpret_cast<float4*>(b + wave * 36 + 4 * bi) = make_float4(v[0], v[1], v[2], v[3]);
+  if (lane == 0) b[wave * 36 + 32] = vd;
+  __syncthreads();
+  float4 acc = *reinterpret_cast<const float4*>(b + 4 * bi);
+  float ad = b[32];
+#pragma unroll
+  for (int w = 1; w < PW; ++w) {
+    const float4 t = *reinterpret_cast<const float4*>(b + w * 36 + 4 * bi);
+    const float td = b[w * 36 + 32];
+    if (kMax) { acc.x = fmaxf(acc.x, t.x); acc.y = fmaxf(acc.y, t.y); acc.z = fmaxf(acc.z, t.z); acc.w = fmaxf(acc.w, t.w); ad = fmaxf(ad, td); }
+    else { acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; ad += td; }
+  }
+  v[0] = acc.x; v[1] = acc.y; v[2] = acc.z; v[3] = acc.w; vd = ad;
+}
+
+template <int PW, int CB>
+__device__ __forceinline__ void gl_project_blk(const float* vl, int n, float scale, int iters, float* __restrict__ Unew, float* smem) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, bi = lane >> 3, bj = lane & 7;
+  GlXchg<PW> x;
+  x.buf = smem; x.flag = (int*)(smem + 2 * PW * 36); x.phase = 0;
+  const float D = SK_DUMMY;
+  const int mult = n - NU;                   // > 0 on this path
+  const int cbu = (n + 8 * PW - 1) / (8 * PW);
+  float L[4][CB], f[4], g[CB], fd = 0.f;
+  bool cused[CB];
+#pragma unroll
+  for (int b = 0; b < CB; ++b) {
+    const int q = 8 * (wave + PW * b) + bj;
+    cused[b] = b < cbu && q < n;
+    g[b] = 0.f;
+    const float* col = vl + (cused[b] ? q : 0) * 33 + 4 * bi;      // V_g tile in LDS, row stride 33
+#pragma unroll
+    for (int a = 0; a < 4; ++a) L[a][b] = cused[b] ? col[a] * scale : -INFINITY;
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a) f[a] = 0.f;
+  for (int it = 0; it < iters; it += 2) {
+    const bool cols_too = it + 1 < iters;
+    float fn[4], gn[CB], fdn = fd;
+    bool exact = it == 0;
+    if (!exact) {
+      float e[4][CB], s[4], ed[CB], sd = 0.f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        float acc = 0.f;
+#pragma unroll
+        for (int b = 0; b < CB; ++b)
+          if (b < cbu) { e[a][b] = fast_exp2((L[a][b] - f[a]) - g[b]); acc += e[a][b]; }
+        s[a] = bj_sum(acc);
+      }
+#pragma unroll
+      for (int b = 0; b < CB; ++b)
+        if (b < cbu) { ed[b] = cused[b] ? fast_exp2((D - fd) - g[b]) : 0.f; sd += ed[b]; }
+      sd = bj_sum(sd);
+      gl_rows_meet<PW, false>(x, s, sd, wave, bi, bj, lane);
+      float lo = sd, hi = sd, r[4];
+      fdn = fd + fast_log2(sd);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        lo = fminf(lo, s[a]); hi = fmaxf(hi, s[a]);
+        fn[a] = f[a] + fast_log2(s[a]);
+        r[a] = __builtin_amdgcn_rcpf(s[a]);
+      }
+      if (cols_too) {
+        const float rd = (float)mult * __builtin_amdgcn_rcpf(sd);
+#pragma unroll
+        for (int b = 0; b < CB; ++b)
+          if (b < cbu) {
+            float acc = (e[0][b] * r[0] + e[1][b] * r[1]) + (e[2][b] * r[2] + e[3][b] * r[3]);
+            acc = bi_sum(acc);
+            acc += ed[b] * rd;
+            const float cu = cused[b] ? acc : 1.f;
+            lo = fminf(lo, cu); hi = fmaxf(hi, cu);
+            gn[b] = cused[b] ? g[b] + fast_log2(acc) : 0.f;
+          }
+      }
+      // the column sums are wavefront-local: the decision to redo the pair exactly must be the workgroup's
+      const bool bad = __ballot(!(lo >= 8.6736174e-19f && hi <= 1.0e6f)) != 0ull;
+      if (lane == 0) x.flag[wave] = bad ? 1 : 0;
+      __syncthreads();
+      int any = 0;
+#pragma unroll
+      for (int w = 0; w < PW; ++w) any |= x.flag[w];
+      exact = any != 0;
+    }
+    if (exact) {
+      // rows, max-subtracted: two meetings (maxima, then sums)
+      float m[4], md = -INFINITY;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        float t = -INFINITY;
+#pragma unroll
+        for (int b = 0; b < CB; ++b) if (b < cbu) t = fmaxf(t, L[a][b] - g[b]);
+        m[a] = bj_max(t);
+      }
+#pragma unroll
+      for (int b = 0; b < CB; ++b) if (b < cbu && cused[b]) md = fmaxf(md, -g[b]);
+      md = bj_max(md);
+      gl_rows_meet<PW, true>(x, m, md, wave, bi, bj, lane);
+      float sa[4], sdd = 0.f;
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const float ms = (m[a] == -INFINITY) ? 0.f : m[a];
+        m[a] = ms;
+        float acc = 0.f;
+#pragma unroll
+        for (int b = 0; b < CB; ++b) if (b < cbu) acc += fast_exp2((L[a][b] - g[b]) - ms);
+        sa[a] = bj_sum(acc);
+      }
+#pragma unroll
+      for (int b = 0; b < CB; ++b) if (b < cbu && cused[b]) sdd += fast_exp2(-g[b] - md);
+      sdd = bj_sum(sdd);
+      gl_rows_meet<PW, false>(x, sa, sdd, wave, bi, bj, lane);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) fn[a] = m[a] + fast_log2(sa[a]);
+      fdn = D + md + fast_log2(sdd);
+      if (cols_too) {
+        const float td = D - fdn;
+#pragma unroll
+        for (int b = 0; b < CB; ++b)
+          if (b < cbu) {
+            float mm = fmaxf(fmaxf(L[0][b] - fn[0], L[1][b] - fn[1]), fmaxf(L[2][b] - fn[2], L[3][b] - fn[3]));
+            mm = fmaxf(bi_max(mm), td);
+            float acc = (fast_exp2((L[0][b] - fn[0]) - mm) + fast_exp2((L[1][b] - fn[1]) - mm)) +
+                        (fast_exp2((L[2][b] - fn[2]) - mm) + fast_exp2((L[3][b] - fn[3]) - mm));
+            acc = bi_sum(acc);
+            acc += (float)mult * fast_exp2(td - mm);
+            gn[b] = cused[b] ? mm + fast_log2(acc) : 0.f;
+          }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) f[a] = fn[a];
+    fd = fdn;
+    if (cols_too) {
+#pragma unroll
+      for (int b = 0; b < CB; ++b) if (b < cbu) g[b] = gn[b];
+    }
+  }
+  // U[q][p] = exp2(L - f_p - g_q): node q's four universe slots 4 bi .. 4 bi + 3 are one 16-byte store
+#pragma unroll
+  for (int b = 0; b < CB; ++b)
+    if (cused[b]) {
+      float4 o;
+      o.x = fast_exp2((L[0][b] - f[0]) - g[b]); o.y = fast_exp2((L[1][b] - f[1]) - g[b]);
+      o.z = fast_exp2((L[2][b] - f[2]) - g[b]); o.w = fast_exp2((L[3][b] - f[3]) - g[b]);
+      *reinterpret_cast<float4*>(Unew + (size_t)(8 * (wave + PW * b) + bj) * NU + 4 * bi) = o;
+    }
 }
 
 // After the projection of graph g: the G == 2 identity pin (:358-359), the graph's two squared norms for the stage
@@ -530,8 +703,14 @@ __global__ __launch_bounds__(PT) void gagm_large_project_kernel(ttdg_graphs_t gr
       pb.mult = pb.c - pb.r;
       pb.pot = nullptr; pb.potld = 0;
       sk_forward<true>(pb, gl_smem, cfg.sk_iter);
-    } else {
+    } else if (n > 8 * PW * 8 || (cfg.variant & TTDG_GAGM_COLUMN_PROJECTOR)) {      // wider than 8 column blocks per lane (cannot happen below 513 / 1025 nodes), or the A/B switch
       gl_project_cols(vl, n, pb.scale, cfg.sk_iter, Unew, gl_smem);
+    } else if (n <= 8 * PW * 2) {
+      gl_project_blk<PW, 2>(vl, n, pb.scale, cfg.sk_iter, Unew, gl_smem);
+    } else if (n <= 8 * PW * 4) {
+      gl_project_blk<PW, 4>(vl, n, pb.scale, cfg.sk_iter, Unew, gl_smem);
+    } else {
+      gl_project_blk<PW, 8>(vl, n, pb.scale, cfg.sk_iter, Unew, gl_smem);
     }
   } else {
     // Hungarian stage: one wavefront runs the scipy-exact LAP on the LDS tile of V_g.  (With 1024 threads per workgroup

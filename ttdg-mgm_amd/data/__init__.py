@@ -197,12 +197,19 @@ class TestLoader:
                         n = len(it["dataset_dict"]["annotations"])
                         if n:
                             it["dataset_dict"]["device_masks"] = dm[k:k + n]
+                            if direct:       # the host masks are VIEWS of the ring slot, which goes back to a worker once this upload
+                                # has completed: nobody may read them later (evaluator fallbacks) - hand out the device copy instead
+                                for j, a in enumerate(it["dataset_dict"]["annotations"]):
+                                    a["mask"] = dm[k + j]
                         k += n
                 else:
                     for it in items:
                         anns = it["dataset_dict"]["annotations"]
                         if anns and "device_masks" not in it["dataset_dict"]:
                             it["dataset_dict"]["device_masks"] = torch.stack([a["mask"] for a in anns]).pin_memory().to(self.device, non_blocking=True)
+                if direct:
+                    for it in items:
+                        it["dataset_dict"].pop("image", None)      # a view of the ring slot as well; the batch carries the device image
                 ev = torch.cuda.Event()
                 ev.record(stream)
                 if slot is not None and self._disk.ring is not None:

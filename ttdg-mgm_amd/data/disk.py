@@ -76,10 +76,15 @@ class _Ring:
         self.pinned = False
         if register and torch.cuda.is_available():
             rt = torch.cuda.cudart()
-            ok = True
+            done = []
             for t in (self.images, self.masks):
-                ok = ok and int(rt.cudaHostRegister(t.data_ptr(), t.numel() * t.element_size(), 0)) == 0
-            self.pinned = ok
+                if int(rt.cudaHostRegister(t.data_ptr(), t.numel() * t.element_size(), 0)) != 0:
+                    for u in done:               # all or nothing: a half-registered ring would leak the first registration
+                        rt.cudaHostUnregister(u.data_ptr())
+                    done = None
+                    break
+                done.append(t)
+            self.pinned = done is not None
 
     def __del__(self):
         if getattr(self, "pinned", False):

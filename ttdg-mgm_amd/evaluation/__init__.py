@@ -175,6 +175,7 @@ class DiceEvaluator:
     def _centroid(m):
         """(mean row, mean column) of the set pixels of a boolean map - what dice_metric.py:196-200 derives from the GT -
         from the row / column histograms (exact: integer sums), NaN for an empty map."""
+        m = m.cpu()                      # a streamed item may carry its ground truth as device tensors only
         rows, cols = m.sum(1, dtype=torch.int64), m.sum(0, dtype=torch.int64)
         cnt = int(rows.sum())
         if cnt == 0:

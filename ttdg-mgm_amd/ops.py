@@ -308,20 +308,24 @@ def mha_adjacency(q, k, gr, sizes, scale, drop_p=0.0, seed=0, zero_diag=True):
 
 
 def gagm_cfg(tau0=0.1, gamma=0.5, min_tau=1e-2, tol=1e-3, quad_weight=0.5, max_iter=200, sk_iter=20,
-             max_stages=0, start_hungarian=False, profile=False, no_cycle_skip=False):
+             max_stages=0, start_hungarian=False, profile=False, no_cycle_skip=False, variant=0):
     c = _lib.GagmCfg()
     c.tau0, c.gamma, c.min_tau, c.tol, c.quad_weight = tau0, gamma, min_tau, tol, quad_weight
     c.max_iter, c.sk_iter = int(max_iter), int(sk_iter)
     c.max_stages, c.start_hungarian, c.profile = int(max_stages), int(bool(start_hungarian)), int(bool(profile))
     c.no_cycle_skip = int(bool(no_cycle_skip))
+    c.variant = int(variant) | GAGM_VARIANT       # per-call A/B selector (_lib.GAGM_*); GAGM_VARIANT = what bench.py's A/B flags set
     return c
 
 
-def gagm_one_step(apack, W, Ucur, gr, sizes, tau=None, quad_weight=0.5, sk_iter=20):
+GAGM_VARIANT = 0
+
+
+def gagm_one_step(apack, W, Ucur, gr, sizes, tau=None, quad_weight=0.5, sk_iter=20, variant=0):
     """One application of the solver's map U -> project(V(U)) (parity tests): Sinkhorn projector at ``tau``,
     Hungarian projector when ``tau`` is None.  Returns (U_next, V)."""
     cfg = gagm_cfg(tau0=(tau or 1.0), quad_weight=quad_weight, max_iter=1, sk_iter=sk_iter, max_stages=1,
-                   start_hungarian=tau is None)
+                   start_hungarian=tau is None, variant=variant)
     U, info, V0 = gagm_solve(apack, W, Ucur, gr, sizes, cfg)
     return U, V0
 

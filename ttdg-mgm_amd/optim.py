@@ -14,6 +14,15 @@ from ._lib import call, ptr, stream
 CHUNK = 65536  # elements per workgroup
 
 
+def _same_storage_order(p, t):
+    """True when ``t`` walks memory in the same element order as the dense parameter ``p``."""
+    if t.stride() == p.stride():
+        return True
+    if p.is_contiguous() and t.is_contiguous():
+        return True
+    return p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) and t.is_contiguous(memory_format=torch.channels_last)
+
+
 class FusedSGD(torch.optim.Optimizer):
     def __init__(self, params, lr, momentum=0.9, weight_decay=0.0):
         if momentum <= 0:
@@ -42,14 +51,17 @@ class FusedSGD(torch.optim.Optimizer):
                     raise TypeError("FusedSGD handles dense float32 parameters")
                 # the update is element-wise: any dense layout works as long as p, grad and buffer share it
                 # (same storage order, not same stride tuple: a 1 x 1 filter is contiguous AND channels-last with two different tuples)
-                gr = p.grad
-                same = gr.stride() == p.stride() or (p.is_contiguous() and gr.is_contiguous()) or \
-                    (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) and gr.is_contiguous(memory_format=torch.channels_last))
-                g = gr if same else torch.empty_like(p).copy_(gr)
+                g = p.grad if _same_storage_order(p, p.grad) else torch.empty_like(p).copy_(p.grad)
                 st = self.state[p]
                 first = "momentum_buffer" not in st
                 if first:
                     st["momentum_buffer"] = torch.empty_like(p)       # preserves p's strides
+                elif not _same_storage_order(p, st["momentum_buffer"]):
+                    # the parameter changed layout after the buffer was made (the backbone moves its filters to channels-last on its
+                    # first fp32 GPU forward; ``load_state_dict`` brings buffers in the layout they were saved in): re-lay the buffer,
+                    # or the kernel would pair p[i] with the momentum of another element
+                    st["momentum_buffer"] = torch.empty_like(p).copy_(st["momentum_buffer"])
+                    self._chunk_key = None
                 todo.append((p, g, st["momentum_buffer"], group["weight_decay"], first))
         if not todo:
             return None
