@@ -326,10 +326,23 @@ def test_continual_tta_trajectory_matches_cpu_port(trained):
       per step:   identical node selection, |loss_dev - loss_host|, and for every updated tensor group (res3, res4, res5, FPN,
                   affinity) the distance of the device's parameters from the host's, relative to how far the host's
                   parameters have moved from the checkpoint;
-      the gate:   derived, not chosen - at step 0 the host step is repeated in FLOAT64 (same detections, same pseudo-labels):
-                  e_ref = what the float32 host step itself loses against it; the device must stay within
-                  TRAJ_FACTOR * e_ref * (k + 1) of the host at step k (two float32 implementations drift apart linearly at
-                  most while the trajectory is stable), and within TRAJ_FACTOR * e_ref of the float64 truth at step 0;
+      the gate:   derived ONCE, one formula for every group and step, every term printed:
+                      |theta_dev - theta_host|_max(g, k)  <=  TRAJ_FACTOR * E_g * sum_{j<=k} step_move_j(g)  +  (k + 1) * ulp_g
+                  E_g         = what ONE float32 host step loses against the SAME step in float64 (same detections, same
+                                pseudo-labels), relative to the step's own movement - measured at step 0.  The matching layers
+                                sit on top of the FPN: their gradient inherits the relative error of the node features, so
+                                E_affinity = max(own, E_fpn).
+                  step_move_j = the host's largest parameter change in step j.  With momentum a relative gradient error e in
+                                step j moves the parameters by e times what that gradient itself moves them over the following
+                                steps: errors add like the movements do, hence the SUM of per-step movements (not (k + 1) times
+                                the net displacement, which round 3 used and which shrinks when steps cancel).
+                  ulp_g       = the spacing of float32 at the group's largest parameter: p - lr * buf is rounded to p's grid
+                                once per step on each side (two half-ulp roundings) whatever the size of the update - the only
+                                term that matters for the affinity layers (they move 2e-4 in eight steps on parameters of size 2).
+                  TRAJ_FACTOR = 4: two fp32 implementations with different summation orders (Winograd / implicit-GEMM
+                                convolutions on the device, direct ones on the host) may each be E_g from the truth in opposite
+                                directions (2x), with a factor 2 for E_g being measured on one step only.
+                  and at step 0 the device itself must be within TRAJ_FACTOR * E_g of the float64 truth;
       afterwards: free-running eval-mode Dice / E / S of both adapted models on two held-out batches, within 1e-3 relative
                   (BASELINE north_star), same number of kept masks.
     Everything is written to gpurun_out/trajectory.json."""
@@ -352,6 +365,7 @@ def test_continual_tta_trajectory_matches_cpu_port(trained):
     bufs = [None] * len([q for q in cpu.parameters() if q.requires_grad])
     opt = BaselineTrainer.build_optimizer(cfg, gpu)
     rec, e_ref = [], None
+    prev_h, cum_move = {n: p.clone() for n, p in theta0.items()}, {g: 0.0 for g in groups}
     for k in range(K):
         batch = batches[k]
         if k == 0:
@@ -372,9 +386,13 @@ def test_continual_tta_trajectory_matches_cpu_port(trained):
         row = dict(step=k, sizes=hsizes, loss_host=float(loss_h), loss_device=float(loss_d.detach()), solver_iters_host=otr["iters"], groups={})
         for g, ns in names.items():
             move = max(float((th_h[n].detach() - theta0[n]).abs().max()) for n in ns)
+            smove = max(float((th_h[n].detach() - prev_h[n]).abs().max()) for n in ns)       # this step's own movement
+            cum_move[g] += smove
             diff = max(float((th_d[n] - th_h[n].detach()).abs().max()) for n in ns)
-            ulp = 2.0 ** -23 * max(float(th_h[n].detach().abs().max()) for n in ns)          # rounding unit of the group's largest parameter
-            row["groups"][g] = dict(moved=move, device_minus_host=diff, rel=diff / max(move, 1e-30), param_ulp=ulp)
+            pmax = max(float(th_h[n].detach().abs().max()) for n in ns)
+            ulp = float(np.spacing(np.float32(pmax)))                                         # float32 grid at the group's largest parameter
+            row["groups"][g] = dict(moved=move, step_move=smove, sum_step_moves=cum_move[g], device_minus_host=diff, rel=diff / max(move, 1e-30), param_ulp=ulp)
+        prev_h = {n: p.detach().clone() for n, p in th_h.items()}
         if k == 0:
             e_ref = {}
             for g, ns in names.items():
@@ -406,21 +424,21 @@ def test_continual_tta_trajectory_matches_cpu_port(trained):
     with open(os.path.join(ROOT, "gpurun_out", "trajectory.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("after %d continual steps: device %s (%d masks) host %s (%d masks)" % (K, rg, len(evg.dice_scores), rc, len(evc.dice_scores)))
-    # ---- gates
+    # ---- gates (the formula of the docstring; every term is in trajectory.json)
+    worst = {}
     for g in names:
-        # what fp32 arithmetic loses in group g: the host's own fp32-vs-float64 distance at step 0.  The matching layers sit on
-        # top of the FPN: their gradients inherit the relative error of the node features, so their unit is the larger of their own
-        # and the FPN's (on the host the two differ by 20x; the device's convolutions - Winograd / NHWC implicit GEMM - round
-        # differently from the host's direct ones, which moves the features, not the matching arithmetic)
-        unit = max(e_ref[g]["host32"], e_ref["fpn"]["host32"]) if g == "affinity" and "fpn" in e_ref else e_ref[g]["host32"]
-        bound0 = max(1e-4, TRAJ_FACTOR * unit)
-        assert e_ref[g]["device"] <= bound0, ("step 0 vs float64", g, e_ref[g], bound0)
+        E = max(e_ref[g]["host32"], e_ref["fpn"]["host32"]) if g == "affinity" else e_ref[g]["host32"]
+        assert e_ref[g]["device"] <= TRAJ_FACTOR * E + 1e-4, ("step 0 vs float64", g, e_ref[g], E)
         for row in rec:
-            bound = max(1e-4, TRAJ_FACTOR * unit) * (row["step"] + 1)
-            # (a group that has barely moved - the affinity layers: 2e-4 after three steps on parameters of size 2 - is compared in
-            #  units of the parameters' own rounding: the fused SGD kernel's fma and torch's mul + add may differ by one ulp per step)
             v = row["groups"][g]
-            assert v["rel"] <= bound or v["device_minus_host"] <= 2 * (row["step"] + 1) * v["param_ulp"], (row["step"], g, v, bound)
+            bound = TRAJ_FACTOR * E * v["sum_step_moves"] + (row["step"] + 1) * v["param_ulp"]
+            v["bound"], v["E"] = bound, E
+            worst[g] = max(worst.get(g, 0.0), v["device_minus_host"] / bound)
+            assert v["device_minus_host"] <= bound, (row["step"], g, v)
+    print("trajectory gate: worst |device - host| / bound per group:", {g: "%.2f" % w for g, w in worst.items()})
+    out["worst_fraction_of_bound"] = worst
+    with open(os.path.join(ROOT, "gpurun_out", "trajectory.json"), "w") as f:
+        json.dump(out, f, indent=1)
     lb = max(1e-4, TRAJ_FACTOR * e_ref["loss"]["host32"])
     assert e_ref["loss"]["device"] <= lb, e_ref["loss"]
     for row in rec:

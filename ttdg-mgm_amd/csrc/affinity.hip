@@ -42,18 +42,21 @@ __device__ __forceinline__ float fma_abs(float w, float x, float acc) {
   return acc;
 }
 
-__device__ __forceinline__ bool tile_needed(const ttdg_graphs_t& gr, int i0, int j0, int M) {
-  // the tile holds a wanted pair iff graph(last row) >= graph(first col)
-  const int il = min(i0 + TILE, M) - 1;
-  return graph_of(gr, il) >= graph_of(gr, j0);
-}
 
 __global__ __launch_bounds__(256) void affinity_fwd_kernel(const float* __restrict__ P, const float* __restrict__ Q,
                                                            const float* __restrict__ w2, int H, ttdg_graphs_t gr,
                                                            int kslice, float* __restrict__ part) {
   const int M = gr.off[gr.G];
-  const int i0 = blockIdx.y * TILE, j0 = blockIdx.x * TILE;
-  if (!tile_needed(gr, i0, j0, M)) return;
+  // [r4] compact launch: blockIdx.x enumerates ONLY the wanted tiles, tile row by tile row (row ti wants the column tiles below
+  // the end of its last row's graph).  Round 3 launched the full nt x nt grid and let 44 % of the workgroups return at once: all
+  // 1024 were placed on the CUs in one static round (capacity 5 per CU), so a CU's share of WORKING tiles ranged from 0 to 4.
+  int ti = 0, tj = blockIdx.x;
+  for (;; ++ti) {
+    const int nc = (gr.off[graph_of(gr, min(ti * TILE + TILE, M) - 1) + 1] + TILE - 1) / TILE;
+    if (tj < nc) break;
+    tj -= nc;
+  }
+  const int i0 = ti * TILE, j0 = tj * TILE;
   __shared__ __attribute__((aligned(16))) float Ps[TILE][LDK];
   __shared__ __attribute__((aligned(16))) float Qs[TILE][LDK];
   __shared__ __attribute__((aligned(16))) float Ws[BK];
@@ -139,7 +142,13 @@ extern "C" int ttdg_affinity_pairwise_fwd(const float* P, const float* Q, const 
   TTDG_REQUIRE(ksplit >= 1 && H % (ksplit * BK) == 0, "affinity_fwd: H must be a multiple of ksplit*32");
   const int M = gr.off[gr.G];
   const int nt = (M + TILE - 1) / TILE;
-  hipLaunchKernelGGL(affinity_fwd_kernel, dim3(nt, nt, ksplit), dim3(256), 0, (hipStream_t)stream, P, Q, w2, H, gr,
+  int wanted = 0;                                   // same enumeration as the kernel's
+  for (int ti = 0, g = 0; ti < nt; ++ti) {
+    const int last = (ti * TILE + TILE < M ? ti * TILE + TILE : M) - 1;
+    while (last >= gr.off[g + 1]) ++g;
+    wanted += (gr.off[g + 1] + TILE - 1) / TILE;
+  }
+  hipLaunchKernelGGL(affinity_fwd_kernel, dim3(wanted, 1, ksplit), dim3(256), 0, (hipStream_t)stream, P, Q, w2, H, gr,
                      H / ksplit, part);
   return ttdg_launch_status("affinity_fwd");
 }
