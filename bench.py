@@ -735,7 +735,7 @@ def gpu_main(args, rank, world, local):
         "tta_only_images_per_s": images / main["tta"], "dice": main["dice"], "kept_masks": main["kept_masks"],
         "tta_steps_taken": main["steps_taken"],
         "vendor_convolutions": ("MIOpen immediate mode, solvers from the find-db shipped in ttdg-mgm_amd/miopen_db (tools/tune_miopen.sh; A/B: --no-miopen-db)"
-                                if os.environ.get("MIOPEN_USER_DB_PATH", "").rstrip("/").endswith("miopen_db") and not args.miopen_search else
+                                if os.path.basename(os.environ.get("MIOPEN_USER_DB_PATH", "").rstrip("/")).startswith(("miopen_db", "ttdg_miopen_db")) and not args.miopen_search else
                                 "MIOpen timing its solvers in this process (--miopen-search)" if args.miopen_search else "MIOpen immediate mode, heuristic solver choice"),
     }
     if roofs:
