@@ -150,7 +150,9 @@ int ttdg_mha_adjacency(const float* q, const float* k, int d, ttdg_graphs_t gr, 
  * (multi_graph_matching.py:223-244, 300-389 with num_clusters == 1; utils/hungarian.py:8-66 ->
  * scipy.optimize.linear_sum_assignment [3P] re-implemented on device, one wavefront per LAP.)
  * Apack as above, W = Wds (M x M), U0 (M x 32).  U (M x 32) receives the 0/1 matching.
- * info (int32[16], device): [0..5] iterations per stage, [6] total, [7] stages run, [8] status.
+ * info (int32[16], device): [0..5] iterations per stage, [6] total, [7] stages run, [8] status (0 = ok; the cooperative
+ * multi-workgroup kernel: 1 = a grid barrier timed out, 2 = the stage machine did not stop - U is then NaN); multi-workgroup solver:
+ * [12] Hungarian-stage LAPs solved with a uniqueness certificate, [13] LAPs that fell back to the scipy-order solver.
  * ws: workspace of ttdg_gagm_workspace_bytes(M) bytes; its first 2*M*32 floats receive the
  * first-iteration V and the first projected U (parity tests). */
 typedef struct {
@@ -165,13 +167,21 @@ typedef struct {
                               *   TTDG_GAGM_FORCE_LARGE       the multi-workgroup solver even where one workgroup would do
                               *   TTDG_GAGM_FORCE_SINGLE      the single-workgroup kernel wherever it can run (every graph <= 128 nodes)
                               *   TTDG_GAGM_256_THREADS       single-workgroup kernel built for 256 threads (graphs <= 64 nodes)
-                              *   TTDG_GAGM_COLUMN_PROJECTOR  multi-workgroup solver: round 3's column-per-thread Sinkhorn projector */
+                              *   TTDG_GAGM_COLUMN_PROJECTOR  multi-workgroup solver: round 3's column-per-thread Sinkhorn projector
+                              *   TTDG_GAGM_ONE_LAUNCH        multi-workgroup solver: the whole solve in one cooperative launch (device-side iteration
+                              *                               loop, grid barriers, no host synchronisation; bit-identical, measured slower -
+                              *                               default: two launches per iteration enqueued by the host in chunks)
+                              *   TTDG_GAGM_SCIPY_ORDER_LAP   multi-workgroup solver: every Hungarian-stage LAP by the one-wavefront scipy-order
+                              *                               solver (default: warm-started workgroup LAP + uniqueness certificate,
+                              *                               csrc/lap_certified.h, scipy-order only when the certificate fails) */
 } ttdg_gagm_cfg_t;
 #define TTDG_GAGM_LDS_PROJECTORS 1
 #define TTDG_GAGM_FORCE_LARGE 2
 #define TTDG_GAGM_FORCE_SINGLE 4
 #define TTDG_GAGM_256_THREADS 8
 #define TTDG_GAGM_COLUMN_PROJECTOR 16
+#define TTDG_GAGM_SCIPY_ORDER_LAP 32
+#define TTDG_GAGM_ONE_LAUNCH 64
 size_t ttdg_gagm_workspace_bytes(int M);
 int ttdg_gagm_solve(const float* Apack, const float* W, const float* U0, ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg,
                     float* U, int32_t* info, void* ws, ttdg_stream_t stream);

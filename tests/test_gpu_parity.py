@@ -87,7 +87,8 @@ def test_gemm_all_layouts(dev, M, N, K):
     assert maxerr(C3, (0.5 * ref.t() + 2.0).float()) <= tol * 4
 
 
-@pytest.mark.parametrize("M,N,K", [(2048, 512, 256), (256, 256, 2048), (70, 130, 33), (64, 64, 32), (65, 63, 31), (5, 300, 129)])
+@pytest.mark.parametrize("M,N,K", [(2048, 512, 256), (256, 256, 2048), (70, 130, 33), (64, 64, 32), (65, 63, 31), (5, 300, 129),
+                                   (64, 64, 36), (128, 64, 68), (64, 128, 96), (72, 68, 100), (64, 64, 132), (60, 64, 164), (64, 64, 4)])   # 1..6 slabs: every tail of the ring of three
 def test_gemm_pipelined_staging_every_operand_layout(dev, M, N, K):
     """[r4] csrc/gemm.hip stages the next K slab global -> registers -> LDS behind the MFMAs, with 16-byte loads where the operand
     allows them.  Every staging path - k-contiguous, m-contiguous and general strides for either operand, 16-byte loads legal or not
@@ -124,6 +125,17 @@ def test_gemm_pipelined_staging_every_operand_layout(dev, M, N, K):
     run(A2, 2 * K, 2, B, K, 1)
     for C in outs[1:]:
         assert torch.equal(C, outs[0]), "the accumulation order must not depend on the operand layout"
+
+
+@pytest.mark.parametrize("M,N", [(2048, 512), (7, 3), (130, 70), (513, 16), (64, 17)])
+def test_colsum_bias_gradient_kernel(dev, M, N):
+    """csrc/gemm.hip colsum_kernel (bias gradients of the affinity MLP, reference utils/affinity.py:37-40 through autograd):
+    against the float64 column sums, and deterministic (fixed-order LDS reduction: two runs return the same bits)."""
+    from ttdg_mgm_amd import ops
+    X = synth.normal(synth.gen(M * 31 + N), (M, N)).to(dev)
+    a, b = ops.colsum(X), ops.colsum(X)
+    assert torch.equal(a, b)
+    assert maxerr(a, X.double().sum(0).float()) <= 1e-6 * M ** 0.5 * 4 + 1e-6
 
 
 def test_gemm_grouped_all_layouts_and_two_segments(dev):
@@ -1047,6 +1059,97 @@ def test_large_solver_sinkhorn_projectors_agree_with_the_float64_step(dev, sizes
             assert maxerr(Vg, V64.float()) <= TOL * max(1.0, float(V64.abs().max()))
             derived_gate("large solver, %s projector, tau %g" % (name, tau), Ug, U32, U64, quiet=True)
         state = U64.float()                       # the next temperature starts from the sharpened state
+
+
+def _scipy_projection(V, sizes):
+    """utils/hungarian.py:8-66 on every graph block of V: scipy.optimize.linear_sum_assignment on the negated block."""
+    from scipy.optimize import linear_sum_assignment
+    out, o = torch.zeros_like(V), 0
+    for n in sizes:
+        r, c = linear_sum_assignment(V[o:o + n].numpy() * -1)
+        out[o + torch.from_numpy(r), torch.from_numpy(c)] = 1.0
+        o += n
+    return out
+
+
+@pytest.mark.parametrize("sizes,seed", [((256,) * 8, 620), ((129, 64, 300, 33, 40), 621), ((512, 40, 65), 622), ((520, 100, 257), 623)])
+def test_large_solver_certified_lap_equals_scipy_and_the_scipy_order_solver(dev, sizes, seed):
+    """[r4] Hungarian stage of the multi-workgroup solver: warm-started workgroup LAP with a uniqueness certificate
+    (csrc/lap_certified.h), the one-wavefront scipy-order solver only where the certificate fails (info[13]).
+    (a) one step from U0: the projection IS scipy's on the device's own V (reference utils/hungarian.py:63), both LAP paths;
+    (b) a whole Hungarian stage entered directly, cycle shortcut off (every iteration a LAP, the duals carried over): identical
+        permutations and iteration counts with cfg.variant = TTDG_GAGM_SCIPY_ORDER_LAP; the certified count is reported;
+    (c) exact ties (every node of a graph identical: uniform adjacency, W = 0): no certificate can exist - every LAP must fall
+        back, and the answer is still the scipy-order one."""
+    from ttdg_mgm_amd import _lib, ops
+    A, W, U0 = cases.gagm_inputs(sizes, seed)
+    ap, Wd, gr = _pack(A, sizes).to(dev), W.to(dev), ops.graphs(sizes)
+    U0d = U0.to(dev).contiguous()
+    big = sum(1 for n in sizes if 32 < n <= 512)
+    # (a)
+    for var in (0, _lib.GAGM_SCIPY_ORDER_LAP):
+        Ug, Vg = ops.gagm_one_step(ap, Wd, U0d, gr, list(sizes), None, variant=var | _lib.GAGM_FORCE_LARGE)
+        assert torch.equal(Ug.cpu(), _scipy_projection(Vg.cpu(), sizes)), var
+    # (b)
+    res = {}
+    for var in (0, _lib.GAGM_SCIPY_ORDER_LAP):
+        cfg = ops.gagm_cfg(start_hungarian=True, max_stages=1, no_cycle_skip=True, max_iter=24, variant=var | _lib.GAGM_FORCE_LARGE)
+        Ub, info, _ = ops.gagm_solve(ap, Wd, U0d, gr, list(sizes), cfg)
+        res[var] = (Ub.cpu(), info.cpu().tolist())
+    (Uf, inf_f), (Us, inf_s) = res[0], res[_lib.GAGM_SCIPY_ORDER_LAP]
+    assert torch.equal(Uf, Us) and inf_f[:8] == inf_s[:8], (inf_f, inf_s)
+    assert inf_s[12] == 0 and inf_s[13] == 0
+    assert inf_f[12] + inf_f[13] == big * inf_f[6], (inf_f, big)
+    assert inf_f[12] >= 0.7 * big * inf_f[6], inf_f                   # generic inputs: the optimum is unique (the rest: attempts given up after the pricing step)
+    print(sizes, "Hungarian stage: %d iterations, %d certified LAPs, %d fallbacks" % (inf_f[6], inf_f[12], inf_f[13]))
+    # (c)
+    At = torch.zeros_like(A)
+    o = 0
+    for n in sizes:
+        At[o:o + n, o:o + n] = 1.0 / n
+        o += n
+    apt, Wt = _pack(At, sizes).to(dev), torch.zeros_like(Wd)
+    res = {}
+    for var in (0, _lib.GAGM_SCIPY_ORDER_LAP):
+        cfg = ops.gagm_cfg(start_hungarian=True, max_stages=1, no_cycle_skip=True, max_iter=3, variant=var | _lib.GAGM_FORCE_LARGE)
+        Ub, info, V0 = ops.gagm_solve(apt, Wt, U0d, gr, list(sizes), cfg)
+        res[var] = (Ub.cpu(), info.cpu().tolist(), V0.cpu())
+    (Uf, inf_f, V0f), (Us, inf_s, _) = res[0], res[_lib.GAGM_SCIPY_ORDER_LAP]
+    o = 0
+    for n in sizes:
+        assert float((V0f[o:o + n] - V0f[o:o + 1]).abs().max()) == 0.0, "the tie construction needs bit-identical rows of V"
+        o += n
+    assert torch.equal(Uf, Us) and inf_f[:8] == inf_s[:8], (inf_f, inf_s)
+    assert inf_f[12] == 0 and inf_f[13] == big * inf_f[6], inf_f
+    U1 = ops.gagm_one_step(apt, Wt, U0d, gr, list(sizes), None, variant=_lib.GAGM_FORCE_LARGE)[0]
+    assert torch.equal(U1.cpu(), _scipy_projection(V0f, sizes)), "all-ties block: scipy's own tie rules decide"
+
+
+@pytest.mark.parametrize("sizes,seed", [((256,) * 8, 630), ((129, 64, 300, 33, 40), 631), ((520, 100, 257), 632), ((200, 150), 633),
+                                        ((20, 33, 40), 634), ((96,) * 12, 635)])
+def test_large_solver_one_cooperative_launch_equals_the_two_launch_form(dev, sizes, seed):
+    """[r4] cfg.variant = TTDG_GAGM_ONE_LAUNCH runs the multi-workgroup solver's whole schedule in ONE cooperative launch
+    (gagm_large_persistent_kernel: device-side iteration loop, grid barrier between the mul and the projection phase, no host
+    synchronisation); the default stays round 2's form (two launches per iteration, enqueued in chunks with a host read per chunk -
+    measured faster, see the kernel's header).  Same arithmetic in the same order: the
+    permutations, every iteration count, the first-iteration V and the first projected U must be IDENTICAL BITS - on the full
+    schedule, on a schedule stopped after the Sinkhorn stages (fractional U), and on a Hungarian stage entered directly.
+    Covers the 512- and the 1024-thread build, G = 2 (identity pin), graphs below 33 nodes beside large ones, more graphs than
+    K slices, and a workgroup count below / above the number of (row tile, K slice) items."""
+    from ttdg_mgm_amd import _lib, ops
+    A, W, U0 = cases.gagm_inputs(sizes, seed)
+    ap, Wd, gr = _pack(A, sizes).to(dev), W.to(dev), ops.graphs(sizes)
+    U0d = U0.to(dev).contiguous()
+    for kw in (dict(max_iter=30), dict(max_stages=3), dict(start_hungarian=True, max_stages=1, max_iter=12, no_cycle_skip=True),
+               dict(start_hungarian=True, max_stages=1, max_iter=40)):
+        out = []
+        for var in (_lib.GAGM_ONE_LAUNCH, 0):
+            Ub, info, V0 = ops.gagm_solve(ap, Wd, U0d, gr, list(sizes), ops.gagm_cfg(variant=var | _lib.GAGM_FORCE_LARGE, **kw))
+            out.append((Ub.cpu(), info.cpu().tolist(), V0.cpu().clone(), ops.gagm_solve.last_U1.cpu().clone()))
+        (Ua, ia, Va, U1a), (Ub_, ib, Vb, U1b) = out
+        assert ia[8] == 0 and ib[8] == 0, (ia, ib)
+        assert ia[:8] == ib[:8] and ia[12:16] == ib[12:16], (kw, ia, ib)
+        assert torch.equal(Va, Vb) and torch.equal(U1a, U1b) and torch.equal(Ua, Ub_), kw
 
 
 def test_cfg3_scale_front_end_and_large_solver(dev):

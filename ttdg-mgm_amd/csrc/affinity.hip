@@ -57,12 +57,16 @@ __global__ __launch_bounds__(256) void affinity_fwd_kernel(const float* __restri
     tj -= nc;
   }
   const int i0 = ti * TILE, j0 = tj * TILE;
-  __shared__ __attribute__((aligned(16))) float Ps[TILE][LDK];
-  __shared__ __attribute__((aligned(16))) float Qs[TILE][LDK];
-  __shared__ __attribute__((aligned(16))) float Ws[BK];
+  // [r4] the next K slab travels global -> registers while the current one is consumed from LDS (two LDS buffers, one barrier
+  // per slab).  Round 3 loaded, stored, synchronised and only then computed: with ~2 workgroups per CU at cfg-3 (576 tiles on
+  // 256 CUs) nobody covered the ~1 us round trip in front of every 1.3 us of arithmetic.  Loads are unconditional (a row
+  // beyond M reads row 0 and is zeroed on its way to LDS): a load under a branch is waited for at the join.
+  __shared__ __attribute__((aligned(16))) float Ps[2][TILE][LDK];
+  __shared__ __attribute__((aligned(16))) float Qs[2][TILE][LDK];
+  __shared__ __attribute__((aligned(16))) float Ws[2][BK];
   __shared__ float Arow[TILE], Brow[TILE];     // sum_k h_k P_ik / Q_jk over this K slice
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  const int kbeg = blockIdx.z * kslice;
+  const int kbeg = blockIdx.z * kslice, kend = kbeg + kslice;
 
   float acc[4][4];
 #pragma unroll
@@ -72,35 +76,59 @@ __global__ __launch_bounds__(256) void affinity_fwd_kernel(const float* __restri
   float pa[2] = {0.f, 0.f}, qa[2] = {0.f, 0.f};
 
   const int lrow = tid >> 3, lk = (tid & 7) * 4;  // staging map: 8 lanes x float4 cover one 32-wide row
-  for (int k0 = kbeg; k0 < kbeg + kslice; k0 += BK) {
-    const float4 wv = *reinterpret_cast<const float4*>(w2 + k0 + lk);
+  bool pok[2], qok[2];
+  const float* prow[2];
+  const float* qrow[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int row = lrow + 32 * r;
+    pok[r] = i0 + row < M;
+    qok[r] = j0 + row < M;
+    prow[r] = P + (size_t)(pok[r] ? i0 + row : 0) * H + lk;
+    qrow[r] = Q + (size_t)(qok[r] ? j0 + row : 0) * H + lk;
+  }
+  float4 pv[2], qv[2], wv;
+#define AFF_LOAD(K0)                                                     \
+  {                                                                      \
+    wv = *reinterpret_cast<const float4*>(w2 + (K0) + lk);               \
+    _Pragma("unroll") for (int r = 0; r < 2; ++r) {                      \
+      pv[r] = *reinterpret_cast<const float4*>(prow[r] + (K0));          \
+      qv[r] = *reinterpret_cast<const float4*>(qrow[r] + (K0));          \
+    }                                                                    \
+  }
+  AFF_LOAD(kbeg)
+  int buf = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += BK, buf ^= 1) {
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       const int row = lrow + 32 * r;
-      float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), qv = pv;
-      if (i0 + row < M) pv = *reinterpret_cast<const float4*>(P + (size_t)(i0 + row) * H + k0 + lk);
-      if (j0 + row < M) qv = *reinterpret_cast<const float4*>(Q + (size_t)(j0 + row) * H + k0 + lk);
-      *reinterpret_cast<float4*>(&Ps[row][lk]) = pv;
-      *reinterpret_cast<float4*>(&Qs[row][lk]) = qv;
-      pa[r] = fmaf(wv.x, pv.x, fmaf(wv.y, pv.y, fmaf(wv.z, pv.z, fmaf(wv.w, pv.w, pa[r]))));
-      qa[r] = fmaf(wv.x, qv.x, fmaf(wv.y, qv.y, fmaf(wv.z, qv.z, fmaf(wv.w, qv.w, qa[r]))));
+      const float4 p4 = pok[r] ? pv[r] : zero4, q4 = qok[r] ? qv[r] : zero4;
+      *reinterpret_cast<float4*>(&Ps[buf][row][lk]) = p4;
+      *reinterpret_cast<float4*>(&Qs[buf][row][lk]) = q4;
+      pa[r] = fmaf(wv.x, p4.x, fmaf(wv.y, p4.y, fmaf(wv.z, p4.z, fmaf(wv.w, p4.w, pa[r]))));
+      qa[r] = fmaf(wv.x, q4.x, fmaf(wv.y, q4.y, fmaf(wv.z, q4.z, fmaf(wv.w, q4.w, qa[r]))));
     }
-    if (tid < BK) Ws[tid] = 0.5f * w2[k0 + tid];
-    __syncthreads();
+    if (tid < 8) *reinterpret_cast<float4*>(&Ws[buf][lk]) = make_float4(0.5f * wv.x, 0.5f * wv.y, 0.5f * wv.z, 0.5f * wv.w);
+    __syncthreads();          // slab k0 is in LDS; the other buffer was last read before the previous barrier
+    {
+      const int kn = k0 + BK < kend ? k0 + BK : k0;          // past the end: the same slab again (never stored)
+      AFF_LOAD(kn)
+    }
 #pragma unroll 2
     for (int kk = 0; kk < BK; kk += 4) {
       f32x2 p[4][2], q[4][2];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
-        const float4 v = *reinterpret_cast<const float4*>(&Ps[ty + 16 * a][kk]);
+        const float4 v = *reinterpret_cast<const float4*>(&Ps[buf][ty + 16 * a][kk]);
         p[a][0] = (f32x2){v.x, v.y}; p[a][1] = (f32x2){v.z, v.w};
       }
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const float4 v = *reinterpret_cast<const float4*>(&Qs[tx + 16 * b][kk]);
+        const float4 v = *reinterpret_cast<const float4*>(&Qs[buf][tx + 16 * b][kk]);
         q[b][0] = (f32x2){v.x, v.y}; q[b][1] = (f32x2){v.z, v.w};
       }
-      const float4 w = *reinterpret_cast<const float4*>(&Ws[kk]);
+      const float4 w = *reinterpret_cast<const float4*>(&Ws[buf][kk]);
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -112,8 +140,8 @@ __global__ __launch_bounds__(256) void affinity_fwd_kernel(const float* __restri
           acc[a][b] = fma_abs(w.w, x1.y, acc[a][b]);
         }
     }
-    __syncthreads();
   }
+#undef AFF_LOAD
   // row sums of the linear half: the 8 lanes that staged a row hold its partial dot products
 #pragma unroll
   for (int r = 0; r < 2; ++r) {

@@ -26,6 +26,7 @@
 // max_iter-1 would land on (bit-identical to running them all).
 #include "lap_device.h"
 #include "sinkhorn_device.h"
+#include "lap_certified.h"
 
 #define NU 32
 #define GL_TILE 32
@@ -55,6 +56,11 @@ struct GlWs {
   int32_t* res;  // control word after the last enqueued iteration (host-visible copy source), 16 words
   unsigned long long* hg;      // per-graph state hashes of the latest projection (64)
   unsigned long long* hhash;   // whole-state hash per Hungarian-stage iteration (GL_HIST)
+  double* lapv;                // Hungarian stage: column duals of every graph's last certified LAP (M), warm start of the next
+  int32_t* lapok;              // per graph: lapv holds the duals of the previous iteration (64)
+  int32_t* lapstat;            // [0] certified LAPs, [1] scipy-order fallbacks of this solve, [2] pricing rounds, [3] augmented rows (cfg.profile)
+  unsigned* bar;               // persistent kernel: [0] grid-barrier arrivals, [1] barrier timeout flag
+  unsigned long long* prof;    // cfg.profile: cycles summed over graphs and iterations - operands + S, V, Sinkhorn projector, certified LAP, scipy-order LAP, norms / hash
   unsigned char* hist;         // state codes, GL_HIST x M bytes
   int M, ntiles, ks, Kc;
 };
@@ -66,7 +72,8 @@ static inline int gl_ntiles(const ttdg_graphs_t& gr) {
 }
 
 static inline size_t gl_ws_floats(int M, int ntiles, int ks) {
-  return (size_t)M * NU * (size_t)(7 + ks) + (size_t)ntiles * NU * NU + 128 + 32 + 16 + 2 * (64 + GL_HIST) + (size_t)GL_HIST * ((M + 3) / 4) + 8;
+  return (size_t)M * NU * (size_t)(7 + ks) + (size_t)ntiles * NU * NU + 128 + 32 + 16 + 2 * (64 + GL_HIST) + 2 * (size_t)M + 64 + 8 + 16 + 8 +
+         (size_t)GL_HIST * ((M + 3) / 4) + 8;
 }
 
 // upper bound over every partition of M nodes into <= 64 graphs (ttdg_gagm_workspace_bytes takes only M)
@@ -90,7 +97,12 @@ static GlWs gl_carve(float* ws, const ttdg_graphs_t& gr) {
   w.res = (int32_t*)(w.dn + 128 + 32);
   w.hg = (unsigned long long*)(w.dn + 128 + 32 + 16);      // 8-byte aligned: every block above is a multiple of 2 floats
   w.hhash = w.hg + 64;
-  w.hist = (unsigned char*)(w.hhash + GL_HIST);
+  w.lapv = (double*)(w.hhash + GL_HIST);
+  w.lapok = (int32_t*)(w.lapv + M);
+  w.lapstat = w.lapok + 64;
+  w.prof = (unsigned long long*)(w.lapstat + 8);
+  w.bar = (unsigned*)(w.prof + 8);
+  w.hist = (unsigned char*)(w.bar + 8);
   return w;
 }
 
@@ -167,6 +179,7 @@ __global__ __launch_bounds__(256) void gagm_large_init_kernel(const float* __res
     c.jump = 0; c.cyc_p = 0; c.cyc_i = 0; c.pad = 0;
     w.ctl[0] = c;
     w.ctl[1] = c;
+    for (int k = 0; k < 8; ++k) { w.lapstat[k] = 0; w.prof[k] = 0ull; w.bar[k] = 0u; }
   }
 }
 
@@ -185,17 +198,20 @@ __device__ __forceinline__ void gl_load_chunk(const float* __restrict__ Asrc, in
   }
 }
 
-__global__ __launch_bounds__(256) void gagm_large_mul_kernel(const float* __restrict__ Apack, const float* __restrict__ W,
-                                                             ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg, GlWs w, int t) {
-  __shared__ __attribute__((aligned(16))) float s_a[4 * GL_TILE * 33];   // per-wavefront A tiles, then the 4 accumulator planes
-  __shared__ float s_bt[GL_TILE * 33], s_ut[GL_TILE * 33];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, G = gr.G, M = w.M;
+// One (row tile, K slice) item of the mul phase on a sub-group of 256 threads (4 wavefronts).  `sub` = index of the sub-group
+// inside the workgroup (the two-launch kernel has one, the persistent kernel PT / 256), `tid` = thread index inside the
+// sub-group, `active` = this sub-group has an item (an idle one still meets the workgroup barriers).  smem: GL_MUL_LDS floats.
+#define GL_MUL_LDS (4 * GL_TILE * 33 + 2 * GL_TILE * 33)
+__device__ __forceinline__ void gl_mul_item(const float* __restrict__ Apack, const float* __restrict__ W, const ttdg_graphs_t& gr,
+                                            const GlWs& w, const GlCtl& ctl, int item_tile, int z, bool active, int tid, float* smem) {
+  float* s_a = smem;                                  // per-wavefront A tiles, then the 4 accumulator planes
+  float* s_bt = smem + 4 * GL_TILE * 33;
+  float* s_ut = s_bt + GL_TILE * 33;
+  const int wave = tid >> 6, lane = tid & 63, M = w.M;
   const size_t MU = (size_t)M * NU;
-  const GlCtl ctl = gl_control(w, G, cfg, t, blockIdx.x == 0 && blockIdx.y == 0);
-  if (ctl.done) return;
   const float* U = w.ring + (size_t)(ctl.total % 3) * MU;
 
-  int tile = blockIdx.x, g = 0;
+  int tile = active ? item_tile : 0, g = 0;
   size_t aoff = 0;
   for (;; ++g) {
     const int n = gr.off[g + 1] - gr.off[g], nt = (n + GL_TILE - 1) / GL_TILE;
@@ -204,13 +220,13 @@ __global__ __launch_bounds__(256) void gagm_large_mul_kernel(const float* __rest
     aoff += (size_t)n * n;
   }
   const int o = gr.off[g], n = gr.off[g + 1] - o;
-  const int row0 = o + tile * GL_TILE, nrows = min(GL_TILE, o + n - row0);
-  const int z = blockIdx.y;
+  const int row0 = o + tile * GL_TILE, nrows = active ? min(GL_TILE, o + n - row0) : 0;
   const bool wpart = z < w.ks;
   const float* Asrc; const float* Ub;
   int lda, kbeg, kend;
   if (wpart) { Asrc = W + (size_t)row0 * M; lda = M; kbeg = z * w.Kc; kend = min(M, kbeg + w.Kc); Ub = U; }
   else       { Asrc = Apack + aoff + (size_t)tile * GL_TILE * n; lda = n; kbeg = 0; kend = n; Ub = U + (size_t)o * NU; }
+  if (!active) kend = kbeg;
 
   float* sa = s_a + wave * (GL_TILE * 33);
   const int li = lane & 31, kh = lane >> 5;
@@ -248,16 +264,24 @@ __global__ __launch_bounds__(256) void gagm_large_mul_kernel(const float* __rest
       s_ut[row * 33 + col] = ok ? U[(size_t)(row0 + row) * NU + col] : 0.f;
     }
   }
-  if (wpart) return;
   __syncthreads();
+  if (wpart || !active) return;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {            // this tile's share of S = U^T B
     const int e = tid + 256 * j, u = e >> 5, v = e & 31;
     float s = 0.f;
 #pragma unroll
     for (int r = 0; r < GL_TILE; ++r) s = fmaf(s_ut[r * 33 + u], s_bt[r * 33 + v], s);
-    w.Sp[(size_t)blockIdx.x * (NU * NU) + e] = s;
+    w.Sp[(size_t)item_tile * (NU * NU) + e] = s;
   }
+}
+
+__global__ __launch_bounds__(256) void gagm_large_mul_kernel(const float* __restrict__ Apack, const float* __restrict__ W,
+                                                             ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg, GlWs w, int t) {
+  __shared__ __attribute__((aligned(16))) float s_mul[GL_MUL_LDS];
+  const GlCtl ctl = gl_control(w, gr.G, cfg, t, blockIdx.x == 0 && blockIdx.y == 0);
+  if (ctl.done) return;
+  gl_mul_item(Apack, W, gr, w, ctl, blockIdx.x, blockIdx.y, true, threadIdx.x, s_mul);
 }
 
 #define GL_PTHREADS 1024
@@ -605,20 +629,25 @@ __device__ __forceinline__ void gl_finish_projection(const ttdg_graphs_t& gr, co
 // 128-VGPR cap made the register-resident Sinkhorn column + its 33 partial lines spill into scratch inside the sweep
 // loop), 1024 for graphs of 513..768 nodes (one column per thread).
 template <int PT>
-__global__ __launch_bounds__(PT) void gagm_large_project_kernel(ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg, GlWs w, int t) {
-  extern __shared__ __attribute__((aligned(16))) float gl_smem[];
+__device__ __forceinline__ void gl_project_graph(const ttdg_graphs_t& gr, const ttdg_gagm_cfg_t& cfg, const GlWs& w, const GlCtl& s_c,
+                                                 const int g, float* gl_smem) {
   __shared__ __attribute__((aligned(16))) float s_S[NU * NU];
   __shared__ __attribute__((aligned(16))) float s_brow[(PT / 64) * 64];
-  __shared__ GlCtl s_c;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, G = gr.G, M = w.M;
   const size_t MU = (size_t)M * NU;
-  if (tid == 0) s_c = w.ctl[(t + 1) & 1];
-  __syncthreads();
-  if (s_c.done) return;
   const int total = s_c.total;
   const bool hung = s_c.hung != 0;
   const float tau = s_c.tau;
-  const int g = blockIdx.x, o = gr.off[g], n = gr.off[g + 1] - o;
+  const int o = gr.off[g], n = gr.off[g + 1] - o;
+  long long tph = cfg.profile ? (long long)__builtin_readcyclecounter() : 0;      // phase clock (thread 0 adds to w.prof)
+#define GL_PHASE(k)                                                                       \
+  if (cfg.profile && tid == 0) {                                                          \
+    const long long now = (long long)__builtin_readcyclecounter();                        \
+    atomicAdd(&w.prof[k], (unsigned long long)(now - tph));                               \
+    if ((k) == 3) atomicMax(&w.prof[6], (unsigned long long)(now - tph));                 \
+    if ((k) == 4) atomicMax(&w.prof[7], (unsigned long long)(now - tph));                 \
+    tph = now;                                                                            \
+  }
   const float* Ucur = w.ring + (size_t)(total % 3) * MU + (size_t)o * NU;
   float* Unew = w.ring + (size_t)((total + 1) % 3) * MU + (size_t)o * NU;
   const float* Uprev = w.ring + (size_t)((total + 2) % 3) * MU + (size_t)o * NU;
@@ -641,18 +670,34 @@ __global__ __launch_bounds__(PT) void gagm_large_project_kernel(ttdg_graphs_t gr
   GL_LOAD_V_OPERANDS(0)
   // S = sum of the tile shares: one element per thread, 16 independent loads in flight per round (the plain
   // accumulate-as-you-go loop pays one L2 round trip per tile)
-  for (int e = tid; e < NU * NU; e += PT) {
-    float acc[16];
+  {
+    // [r4] every element's tile shares are requested 16 at a time for BOTH elements of a thread (unconditional loads: a clamped
+    // index, the select after the wait), i.e. four L2 round trips for the 64 tiles of cfg-3 instead of eight; the order of the
+    // additions is unchanged (share t goes to accumulator t mod 16, the accumulators meet in the same tree)
+    constexpr int EPT = (NU * NU) / PT;              // 2 (512 threads) or 1
+    float acc[EPT][16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+    for (int x = 0; x < EPT; ++x)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc[x][k] = 0.f;
     for (int t0 = 0; t0 < w.ntiles; t0 += 16) {
+      float sv[EPT][16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) acc[k] += (t0 + k < w.ntiles) ? w.Sp[(size_t)(t0 + k) * (NU * NU) + e] : 0.f;
+      for (int x = 0; x < EPT; ++x)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sv[x][k] = w.Sp[(size_t)min(t0 + k, w.ntiles - 1) * (NU * NU) + tid + x * PT];
+#pragma unroll
+      for (int x = 0; x < EPT; ++x)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[x][k] += (t0 + k < w.ntiles) ? sv[x][k] : 0.f;
     }
-    s_S[e] = (((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]))) +
-             (((acc[8] + acc[9]) + (acc[10] + acc[11])) + ((acc[12] + acc[13]) + (acc[14] + acc[15])));
+#pragma unroll
+    for (int x = 0; x < EPT; ++x)
+      s_S[tid + x * PT] = (((acc[x][0] + acc[x][1]) + (acc[x][2] + acc[x][3])) + ((acc[x][4] + acc[x][5]) + (acc[x][6] + acc[x][7]))) +
+                          (((acc[x][8] + acc[x][9]) + (acc[x][10] + acc[x][11])) + ((acc[x][12] + acc[x][13]) + (acc[x][14] + acc[x][15])));
   }
   __syncthreads();
+  GL_PHASE(0)
   // V_g = (2q B_g S + W U) / G: B rows broadcast from LDS, S column in registers.  V_g goes to the workspace (trace /
   // next launch) AND to an LDS tile with row stride 33 that both projectors read (no global round trip in between)
   float* vl = gl_smem + GL_VL_OFF;
@@ -689,6 +734,7 @@ __global__ __launch_bounds__(PT) void gagm_large_project_kernel(ttdg_graphs_t gr
   }
 #undef GL_LOAD_V_OPERANDS
   __syncthreads();
+  GL_PHASE(1)
   const float* Vg = w.V + (size_t)o * NU;
 
   if (!hung) {
@@ -720,8 +766,24 @@ __global__ __launch_bounds__(PT) void gagm_large_project_kernel(ttdg_graphs_t gr
     const bool tr = n > NU;
     const int nr = tr ? NU : n, nc = tr ? n : NU;
     for (int e = tid; e < n * NU; e += PT) Unew[e] = 0.f;       // (V_g is already in the LDS tile)
+    void* lscr = vl + ((n * 33 + 3) & ~3);                      // behind the V_g tile
+    bool certified = false;
+    if (tr && n <= 512 && !(cfg.variant & TTDG_GAGM_SCIPY_ORDER_LAP)) {
+      // lap_certified.h: warm-started workgroup LAP + uniqueness certificate; the scipy-order solver below only without one
+      const LapCertScratch cs = lap_cert_carve(lscr, n);
+      const double* warm = (s_c.it > 0 && w.lapok[g]) ? w.lapv + o : nullptr;
+      int* stat = cfg.profile ? w.lapstat : nullptr;
+      certified = n <= 64 ? lap_certified_solve<PT, 1>(n, vl, cs, warm, stat) : n <= 128 ? lap_certified_solve<PT, 2>(n, vl, cs, warm, stat)
+                : n <= 256 ? lap_certified_solve<PT, 4>(n, vl, cs, warm, stat) : lap_certified_solve<PT, 8>(n, vl, cs, warm, stat);
+      if (certified) {
+        if (tid < NU) Unew[cs.col4row[tid] * NU + tid] = 1.f;
+        for (int j = tid; j < n; j += PT) w.lapv[o + j] = cs.v[j];
+      }
+      if (tid == 0) { w.lapok[g] = certified ? 1 : 0; atomicAdd(&w.lapstat[certified ? 0 : 1], 1); }
+      GL_PHASE(3)
+    }
     __syncthreads();                                                     // zeros land before wavefront 0 writes the ones
-    if (wave == 0) {
+    if (!certified && wave == 0) {
       if (nc <= 64) {
         const int b = lap_wave_solve_reg<0, true>(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1);
         wave_sync();
@@ -731,7 +793,7 @@ __global__ __launch_bounds__(PT) void gagm_large_project_kernel(ttdg_graphs_t gr
         wave_sync();
         if (lane < nr) { if (tr) Unew[b * NU + lane] = 1.f; else Unew[lane * NU + b] = 1.f; }
       } else {
-        LapScratch sc = lap_carve(vl + ((n * 33 + 3) & ~3), nr, nc);      // behind the V_g tile
+        LapScratch sc = lap_carve(lscr, nr, nc);
         lap_wave_solve(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1, sc);
         wave_sync();
         for (int a = lane; a < nr; a += 64) {
@@ -743,7 +805,21 @@ __global__ __launch_bounds__(PT) void gagm_large_project_kernel(ttdg_graphs_t gr
     __threadfence_block();
   }
   __syncthreads();
+  GL_PHASE(hung ? 4 : 2)
   gl_finish_projection<PT>(gr, cfg, w, s_c, g, Unew, Ucur, Uprev, hung);
+  __syncthreads();
+  GL_PHASE(5)
+#undef GL_PHASE
+}
+
+template <int PT>
+__global__ __launch_bounds__(PT) void gagm_large_project_kernel(ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg, GlWs w, int t) {
+  extern __shared__ __attribute__((aligned(16))) float gl_smem[];
+  __shared__ GlCtl s_c;
+  if (threadIdx.x == 0) s_c = w.ctl[(t + 1) & 1];
+  __syncthreads();
+  if (s_c.done) return;
+  gl_project_graph<PT>(gr, cfg, w, s_c, blockIdx.x, gl_smem);
 }
 
 // control word after `t` enqueued iterations -> w.res (what the host polls)
@@ -755,22 +831,123 @@ __global__ __launch_bounds__(256) void gagm_large_peek_kernel(ttdg_graphs_t gr, 
   }
 }
 
-__global__ __launch_bounds__(256) void gagm_large_finish_kernel(GlWs w, float* __restrict__ Uout, int32_t* __restrict__ info) {
-  const GlCtl* c = (const GlCtl*)w.res;
+// U and info[] from the final control word (grid-stride over `nthreads` threads, `gtid` = this thread's index among them)
+__device__ __forceinline__ void gl_write_result(const GlWs& w, const GlCtl* c, float* __restrict__ Uout, int32_t* __restrict__ info,
+                                                int profile, size_t gtid, size_t nthreads) {
   const size_t MU = (size_t)w.M * NU;
   if (c->jump > 0) {   // cycle shortcut: the final state is a remembered one
     const unsigned char* code = w.hist + (size_t)(c->jump - 1) * w.M;
-    for (size_t e = blockIdx.x * 256 + threadIdx.x; e < MU; e += (size_t)gridDim.x * 256) Uout[e] = (code[e >> 5] == (e & 31)) ? 1.f : 0.f;
+    for (size_t e = gtid; e < MU; e += nthreads) Uout[e] = (code[e >> 5] == (e & 31)) ? 1.f : 0.f;
   } else {
     const float* U = w.ring + (size_t)(c->total % 3) * MU;
-    for (size_t e = blockIdx.x * 256 + threadIdx.x; e < MU; e += (size_t)gridDim.x * 256) Uout[e] = U[e];
+    for (size_t e = gtid; e < MU; e += nthreads) Uout[e] = U[e];
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (gtid == 0) {
     for (int k = 0; k < 6; ++k) info[k] = c->iters[k];
     info[6] = c->total; info[7] = c->stage;
-    for (int k = 8; k < 14; ++k) info[k] = 0;
     info[14] = c->cyc_p; info[15] = c->cyc_i;
+    info[12] = w.lapstat[0]; info[13] = w.lapstat[1];      // Hungarian stage: certified workgroup LAPs / scipy-order fallbacks
+    // cfg.profile: cycles / 1024 summed over graphs and iterations: [8] operands + S, [9] V, [10] projector (Sinkhorn + both LAPs), [11] norms / hash
+    // (cfg.profile == 2: the projector split - [8] Sinkhorn, [9] certified LAP, [10] scipy-order LAP, [11] norms / hash;
+    //  cfg.profile == 3: [8] pricing rounds, [9] rows augmented, [10] Dijkstra steps, [11] / [14] longest certified / scipy-order LAP)
+    if (profile == 3) { info[8] = w.lapstat[2]; info[9] = w.lapstat[3]; info[10] = w.lapstat[4]; info[11] = (int32_t)(w.prof[6] >> 10); info[14] = (int32_t)(w.prof[7] >> 10); return; }
+    if (profile == 2) { info[8] = (int32_t)(w.prof[2] >> 10); info[9] = (int32_t)(w.prof[3] >> 10); info[10] = (int32_t)(w.prof[4] >> 10); }
+    else { info[8] = (int32_t)(w.prof[0] >> 10); info[9] = (int32_t)(w.prof[1] >> 10); info[10] = (int32_t)((w.prof[2] + w.prof[3] + w.prof[4]) >> 10); }
+    info[11] = (int32_t)(w.prof[5] >> 10);
   }
+}
+
+__global__ __launch_bounds__(256) void gagm_large_finish_kernel(GlWs w, float* __restrict__ Uout, int32_t* __restrict__ info, int profile) {
+  gl_write_result(w, (const GlCtl*)w.res, Uout, info, profile, (size_t)blockIdx.x * 256 + threadIdx.x, (size_t)gridDim.x * 256);
+}
+
+// ---- [r4] the whole solve in ONE cooperative launch ------------------------------------------------------------------
+// The two-launch form pays, per iteration, two kernel boundaries (launch gaps + an L2 flush / invalidate each: 55-65 us per
+// iteration at cfg-3 for ~45 us of kernel time) and the host enqueues iterations in chunks with one stream synchronisation per
+// chunk.  Here the iteration loop runs on the device: every workgroup evaluates the stage machine (gl_control), takes its share of
+// the (row tile, K slice) items of the mul phase - a workgroup of PT threads is PT / 256 sub-groups, each working exactly like a
+// workgroup of gagm_large_mul_kernel - meets the others in a grid barrier, workgroups 0..G-1 project their graph
+// (gl_project_graph, the body of gagm_large_project_kernel), second barrier.  Same arithmetic in the same order: the result is
+// bit-identical to the two-launch form (tests compare the two).  The barrier is a monotonic arrival counter in the workspace
+// (agent-scope release before, acquire after; a workgroup that waits longer than ~2^26 cycles raises bar[1] and everybody leaves:
+// the host then reports an error instead of hanging).  Launched with hipLaunchCooperativeKernel: co-residency is checked by the
+// runtime; if the launch is refused the two-launch form runs.
+// MEASURED (MI355X, 8 x 256 nodes, tools/bench_cfg3_solver.py, profiles/r04_cfg3_solver_one_launch.json): 80 us per Sinkhorn-stage
+// iteration and 76 us per Hungarian-stage iteration against 62 and 55 us for the two-launch form.  A grid barrier across 256
+// workgroups on 8 XCDs costs what a kernel boundary costs: the agent-scope acquire behind it invalidates the XCD's whole L2, so W
+// (16 MB, read-only) is fetched from the memory side again in every iteration exactly as after a launch, the barrier itself is an
+// atomic round trip to memory plus a polling loop, and the 576 items of the mul phase take two rounds on 512 sub-groups.  The
+// single launch therefore stays an OPTION (cfg.variant = TTDG_GAGM_ONE_LAUNCH: no host synchronisation at all - the two-launch
+// form reads one flag per chunk of iterations); the default is the faster two-launch form.
+// `naps` = s_sleep(16) periods (~0.45 us each) between two looks at the counter.  Every look is an agent-scope load that travels to
+// the memory side; 248 idle workgroups looking every 128 cycles (the first build) saturated the counter's channel and slowed the
+// eight projecting workgroups' own loads fivefold (operands + S: 40 us instead of 8).
+// `wrote` / `reads`: this workgroup stored data other workgroups will load / will load data other workgroups stored.  The
+// agent-scope release (an L2 write-back) and acquire (an L2 + L1 invalidate) are issued by ONE wavefront per workgroup, and only
+// where they are needed: with every wavefront of all 256 workgroups fencing on both sides (the first build: ~4000 write-backs and
+// ~4000 invalidates per barrier) the L2s were busy with cache maintenance while the eight projecting workgroups tried to load.
+__device__ __forceinline__ bool gl_grid_barrier(unsigned* bar, unsigned target, int naps, bool wrote, bool reads) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        // this wavefront's stores have been acknowledged by the L2
+  __syncthreads();
+  __shared__ int s_bad;
+  if (threadIdx.x == 0) {
+    if (wrote) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int bad = 0;
+    const long long t0 = (long long)__builtin_readcyclecounter();
+    while (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      for (int k = 0; k < naps; ++k) __builtin_amdgcn_s_sleep(16);
+      if (__hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { bad = 1; break; }
+      if ((long long)__builtin_readcyclecounter() - t0 > (1ll << 26)) { __hip_atomic_store(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); bad = 1; break; }
+    }
+    if (reads) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    s_bad = bad;
+  }
+  __syncthreads();
+  return s_bad == 0;
+}
+
+template <int PT>
+__global__ __launch_bounds__(PT) void gagm_large_persistent_kernel(const float* __restrict__ Apack, const float* __restrict__ W,
+                                                                   ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg, GlWs w, float* __restrict__ Uout,
+                                                                   int32_t* __restrict__ info, int cap) {
+  extern __shared__ __attribute__((aligned(16))) float gl_smem[];
+  __shared__ GlCtl s_c;
+  constexpr int NSUB = PT / 256;
+  const int tid = threadIdx.x, sub = tid >> 8, stid = tid & 255;
+  const int nitems = w.ntiles * (w.ks + 1);
+  const unsigned nb = gridDim.x;
+  unsigned arrivals = 0;
+  bool good = true;
+  for (int t = 0; t < cap; ++t) {
+    {
+      const GlCtl ctl = gl_control(w, gr.G, cfg, t, blockIdx.x == 0);
+      __syncthreads();                                  // (gl_control's LDS words are free again)
+      if (tid == 0) s_c = ctl;                          // the word lives in LDS from here on, not in 16 registers per lane
+      __syncthreads();
+    }
+    if (s_c.done) break;
+    for (int base = blockIdx.x * NSUB; base < nitems; base += (int)nb * NSUB) {
+      const int item = base + sub;
+      const bool active = item < nitems;
+      gl_mul_item(Apack, W, gr, w, s_c, active ? item % w.ntiles : 0, active ? item / w.ntiles : 0, active, stid, gl_smem + sub * GL_MUL_LDS);
+      __syncthreads();
+    }
+    arrivals += nb;
+    const bool projects = (int)blockIdx.x < gr.G;
+    if (!gl_grid_barrier(w.bar, arrivals, 1, true, projects)) { good = false; break; }          // everybody arrives within a few us
+    if (projects) gl_project_graph<PT>(gr, cfg, w, s_c, blockIdx.x, gl_smem);
+    arrivals += nb;
+    if (!gl_grid_barrier(w.bar, arrivals, projects ? 1 : 4, projects, true)) { good = false; break; }      // the idle majority looks every ~2 us
+  }
+  __syncthreads();
+  if (!good || !s_c.done) {      // a barrier timed out (1) or the stage machine did not stop within `cap` iterations (2): NaN out, loudly
+    const size_t MU = (size_t)w.M * NU;
+    for (size_t e = (size_t)blockIdx.x * PT + tid; e < MU; e += (size_t)nb * PT) Uout[e] = __int_as_float(0x7fc00000);
+    if (blockIdx.x == 0 && tid == 0) info[8] = good ? 2 : 1;
+    return;
+  }
+  gl_write_result(w, &s_c, Uout, info, (int)cfg.profile, (size_t)blockIdx.x * PT + tid, (size_t)nb * PT);
 }
 
 // entry point used by ttdg_gagm_solve (gagm.hip) when a graph has more than 128 nodes
@@ -791,8 +968,32 @@ int ttdg_gagm_large_solve(const float* Apack, const float* W, const float* U0, t
   const int M = gr.off[gr.G];
   const int cblocks = (M * NU + 255) / 256 < 256 ? (M * NU + 255) / 256 : 256;
   hipLaunchKernelGGL(gagm_large_init_kernel, dim3(cblocks), dim3(256), 0, st, U0, cfg, w);
-  int t = 0, chunk = 4;
   const long long cap = 8LL * cfg.max_iter + 8;
+  if (cfg.variant & TTDG_GAGM_ONE_LAUNCH) {
+    // the whole solve in one cooperative launch (gagm_large_persistent_kernel) - opt-in: measured SLOWER than the two-launch form on
+    // MI355X (header of the kernel); refused launches fall through to the two-launch form
+    const int pt = cmax <= 512 ? 512 : 1024, nsub = pt / 256;
+    const size_t mul_bytes = (size_t)nsub * GL_MUL_LDS * sizeof(float);
+    const size_t pbytes = bytes > mul_bytes ? bytes : mul_bytes;
+    const void* fn = pt == 512 ? (const void*)gagm_large_persistent_kernel<512> : (const void*)gagm_large_persistent_kernel<1024>;
+    if (pt == 512) TTDG_ALLOW_LDS(gagm_large_persistent_kernel<512>, pbytes); else TTDG_ALLOW_LDS(gagm_large_persistent_kernel<1024>, pbytes);
+    int dev = 0, ncu = 0, per_cu = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, pt, pbytes) == hipSuccess && ncu > 0 && per_cu > 0) {
+      const int nitems = w.ntiles * (w.ks + 1);
+      int nb = (nitems + nsub - 1) / nsub;
+      if (nb < gr.G) nb = gr.G;
+      if (nb > ncu) nb = ncu;              // one workgroup per CU; a longer item list is taken in rounds
+      if (nb >= gr.G) {
+        int cap_i = (int)cap;
+        const float* a0 = Apack; const float* a1 = W;
+        void* args[] = {(void*)&a0, (void*)&a1, (void*)&gr, (void*)&cfg, (void*)&w, (void*)&U, (void*)&info, (void*)&cap_i};
+        if (hipLaunchCooperativeKernel(fn, dim3(nb), dim3(pt), args, pbytes, st) == hipSuccess) return ttdg_launch_status("gagm_large_persistent");
+        (void)hipGetLastError();           // refused (co-residency, LDS): clear and fall through
+      }
+    }
+  }
+  int t = 0, chunk = 4;
   int32_t h[16];
   for (;;) {
     for (int k = 0; k < chunk; ++k, ++t) {
@@ -808,6 +1009,6 @@ int ttdg_gagm_large_solve(const float* Apack, const float* W, const float* U0, t
     TTDG_REQUIRE(t < cap, "gagm: the stage machine did not terminate");
     chunk = chunk < 32 ? chunk * 2 : 32;
   }
-  hipLaunchKernelGGL(gagm_large_finish_kernel, dim3(cblocks), dim3(256), 0, st, w, U, info);
+  hipLaunchKernelGGL(gagm_large_finish_kernel, dim3(cblocks), dim3(256), 0, st, w, U, info, (int)cfg.profile);
   return ttdg_launch_status("gagm_large_finish");
 }

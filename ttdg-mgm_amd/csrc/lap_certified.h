@@ -1,0 +1,293 @@
+// Whole-workgroup rectangular LAP (maximise; 32 rows = universe slots, nc = nodes of one graph as columns) for the Hungarian stage
+// of the multi-workgroup GA-MGM solver, with a CERTIFICATE that makes it exchangeable with the scipy-order solver of lap_device.h.
+//
+// The reference projects with scipy.optimize.linear_sum_assignment (utils/hungarian.py:34-63): a successive-shortest-path
+// solver that starts from nothing on every call - 32 augmentations x a Dijkstra scan over the node columns, one data-dependent
+// step at a time (lap_wave_solve_regw: ~90 us for 32 x 256 on one wavefront; 16 of the 24 iterations of BASELINE cfg-3 are spent
+// there).  Consecutive Hungarian-stage iterations solve nearly the same problem, so here:
+//   1. the column duals v of the previous iteration (kept per graph in the workspace) are the starting point; every wavefront
+//      takes rows: u_i = min_j (c_ij - v_j) and the arg-min column; rows that claim a column alone keep it.  Columns that carry
+//      a negative dual but were claimed by nobody return to v = 0 and the rows are re-priced (complementary slackness of the
+//      rectangular problem: an unmatched column has v = 0), until nothing changes;
+//   2. wavefront 0 augments the rows that lost their claim: the same register-resident Dijkstra as lap_wave_solve_regw, fp64
+//      duals, from the partial matching (typically 0-3 rows instead of 32);
+//   3. the WHOLE workgroup certifies the result from (m, v) alone.  With u_i := c_{i,m(i)} - v_{m(i)} and S = max|c| + max|v|:
+//        (i)   m is injective, every v_j <= 0, v_j = 0 on unmatched columns;
+//        (ii)  every reduced cost rc_ij = c_ij - u_i - v_j >= -1e-12 S  (dual feasibility up to fp64 rounding);
+//        (iii) call an entry TIGHT when rc_ij < 1e-9 S, and build the directed graph on the 32 rows plus one node F:
+//              i -> i' when (i, m(i')) is tight, i -> F when i has a tight entry in an unmatched column, F -> i when
+//              v_{m(i)} > -1e-9 S.  The graph must be ACYCLIC (33 nodes: bit masks, sinks peeled by ballot).
+//      Any other assignment m' costs  cost(m) + sum_{m'} rc + sum_{cols(m) \ cols(m')} |v_j|.  If m' uses a non-tight entry the
+//      first sum is >= 1e-9 S - 31e-12 S > 0; if it drops a column with |v_j| >= 1e-9 S likewise; otherwise m' differs from m
+//      along tight alternating cycles, or tight paths from an unmatched column to a dropped column with |v| < 1e-9 S - both are
+//      directed cycles of the graph.  So an acyclic graph proves that m is the UNIQUE optimum with a gap of ~1e-9 S, seven
+//      orders of magnitude above the fp64 rounding of scipy's own duals - and the unique optimum is what scipy returns, whatever
+//      its scan order and tie rules.  (The plain test "every non-matched reduced cost > 0" is not usable: the duals a shortest-
+//      path solver ends with make every edge of its search trees tight.)  The certificate depends on (m, v) only, not on how they
+//      were found: a mistake in steps 1-2 can cost time, never the answer.
+//   4. no certificate (exact ties - e.g. duplicated nodes - or a non-finite entry): the caller runs the scipy-order solver and
+//      counts the fallback (info[13] of ttdg_gagm_solve; certified solves in info[12]).
+#pragma once
+#include "lap_device.h"
+
+struct LapCertScratch {
+  double* v;      // [nc] column duals (<= 0)
+  double* u;      // [32] row duals
+  int* row4col;   // [nc]
+  int* col4row;   // [32]
+  int* arg;       // [32]
+  int* flag;      // [0] a dual was reset this round, [1] certificate holds, [2] max |c| (float bits), [3] max |v| (float bits)
+  unsigned* adj;  // [33][2]: tight-entry graph of the certificate (bit i' of word 0: row i', bit 0 of word 1: the node F)
+};
+
+__host__ __device__ inline size_t lap_cert_scratch_bytes(int nc) { return (size_t)(nc + 32) * 8 + (size_t)(nc + 32 + 32 + 4 + 68) * 4; }
+
+__device__ inline LapCertScratch lap_cert_carve(void* base, int nc) {   // base 8-byte aligned
+  LapCertScratch s;
+  double* d = (double*)base;
+  s.v = d; s.u = d + nc;
+  int* i = (int*)(s.u + 32);
+  s.row4col = i; s.col4row = i + nc; s.arg = s.col4row + 32; s.flag = s.arg + 32; s.adj = (unsigned*)(s.flag + 4);
+  return s;
+}
+
+// wavefront 0: augment every unmatched row from the partial matching (register-resident columns: lane l owns l, l + 64, ...)
+template <int CW>
+__device__ __forceinline__ void lap_cert_augment(int nc, const float* vl, const LapCertScratch& s, int* stat) {
+  const int lane = threadIdx.x & 63;
+  double u = lane < 32 ? s.u[lane] : 0.0;
+  int col4row = lane < 32 ? s.col4row[lane] : 0;
+  double v[CW], spc[CW];
+  int row4col[CW], path[CW];
+  bool is_col[CW];
+#pragma unroll
+  for (int w = 0; w < CW; ++w) {
+    const int j = lane + 64 * w;
+    is_col[w] = j < nc;
+    v[w] = is_col[w] ? s.v[j] : 0.0;
+    row4col[w] = is_col[w] ? s.row4col[j] : -1;
+    path[w] = -1;
+    spc[w] = INFINITY;
+  }
+  unsigned long long fr = __ballot(lane < 32 && col4row == -1);
+  int nsteps = 0;
+  if (stat && lane == 0) atomicAdd(&stat[3], __builtin_popcountll(fr));
+  while (fr) {
+    const int cur = __builtin_ctzll(fr);
+    fr &= fr - 1;
+    double minVal = 0.0;
+    int i = cur, sink = -1;
+    bool active[CW], SC[CW], SR = false;
+#pragma unroll
+    for (int w = 0; w < CW; ++w) { active[w] = is_col[w]; SC[w] = false; spc[w] = INFINITY; }
+    while (sink == -1) {
+      ++nsteps;
+      if (lane == i) SR = true;
+      const double ui = readlane_f64(u, i);
+      double lmin = INFINITY;
+#pragma unroll
+      for (int w = 0; w < CW; ++w)
+        if (active[w]) {
+          const double r = minVal + ((-(double)vl[(lane + 64 * w) * 33 + i] - ui) - v[w]);
+          if (r < spc[w]) { path[w] = i; spc[w] = r; }
+          lmin = fmin(lmin, spc[w]);
+        }
+      const double gmin = wave_min_f64_dpp(lmin);
+      if (!(gmin < INFINITY)) { sink = -2; break; }       // non-finite costs: leave the row unmatched, the certificate refuses
+      int wsel = -1, lsel = 0;
+#pragma unroll
+      for (int w = 0; w < CW; ++w) {
+        const unsigned long long mm = __ballot(active[w] && spc[w] == gmin);
+        if (mm != 0ull && wsel < 0) { wsel = w; lsel = __builtin_ctzll(mm); }
+      }
+      int owner = -1;
+#pragma unroll
+      for (int w = 0; w < CW; ++w)
+        if (w == wsel) owner = __builtin_amdgcn_readlane(row4col[w], lsel);
+      minVal = gmin;
+#pragma unroll
+      for (int w = 0; w < CW; ++w)
+        if (w == wsel && lane == lsel) { SC[w] = true; active[w] = false; }
+      if (owner == -1) sink = lsel + 64 * wsel; else i = owner;
+    }
+    if (sink < 0) break;
+    // dual updates (rows on the alternating tree, scanned columns), then the augmentation along the stored path
+    const int c4r = (col4row >= 0) ? col4row : 0;
+    double spc_of_my_col = 0.0;
+#pragma unroll
+    for (int w = 0; w < CW; ++w) {
+      const double x = __shfl(spc[w], c4r & 63, 64);
+      if ((c4r >> 6) == w) spc_of_my_col = x;
+    }
+    if (lane == cur) u += minVal;
+    else if (SR) u += minVal - spc_of_my_col;
+#pragma unroll
+    for (int w = 0; w < CW; ++w) if (SC[w]) v[w] -= minVal - spc[w];
+    int j = sink;
+    for (int guard = 0; guard < 34; ++guard) {
+      const int wj = j >> 6, lj = j & 63;
+      int r = 0;
+#pragma unroll
+      for (int w = 0; w < CW; ++w) if (w == wj) r = __builtin_amdgcn_readlane(path[w], lj);
+      const int t = __builtin_amdgcn_readlane(col4row, r);
+#pragma unroll
+      for (int w = 0; w < CW; ++w) if (w == wj && lane == lj) row4col[w] = r;
+      if (lane == r) col4row = j;
+      j = t;
+      if (r == cur) break;
+    }
+  }
+  if (lane < 32) s.col4row[lane] = col4row;
+#pragma unroll
+  for (int w = 0; w < CW; ++w) if (is_col[w]) s.v[lane + 64 * w] = v[w];
+  if (stat && lane == 0) atomicAdd(&stat[4], nsteps);
+}
+
+// vl: the graph's V tile in LDS, vl[node * 33 + slot]; warm: the previous iteration's column duals (global, nc doubles) or null.
+// Returns true (workgroup-uniform) when the certificate holds: s.col4row[slot] is then the node of every universe slot and s.v the
+// duals to keep for the next iteration.  PT = threads of the workgroup (every thread must call).
+template <int PT, int CW>
+__device__ __forceinline__ bool lap_certified_solve(int nc, const float* vl, const LapCertScratch& s, const double* warm, int* stat = nullptr) {
+  constexpr int PW = PT / 64;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int j = tid; j < nc; j += PT) {
+    const double x = warm ? warm[j] : 0.0;
+    s.v[j] = (x <= 0.0) ? x : 0.0;         // (also turns a NaN of a stale buffer into 0)
+  }
+  if (tid == 0) s.flag[1] = 1;
+  __syncthreads();
+  // ---- 1. prices and claims
+  for (int round = 0; round < 34; ++round) {
+    for (int j = tid; j < nc; j += PT) s.row4col[j] = -1;
+    if (tid == 0) s.flag[0] = 0;
+    for (int i = wave; i < 32; i += PW) {
+      double best = INFINITY;
+      int bj = 0;
+      for (int j = lane; j < nc; j += 64) {
+        const double x = -(double)vl[j * 33 + i] - s.v[j];
+        if (x < best) { best = x; bj = j; }
+      }
+      const double g = wave_min_f64_dpp(best);
+      const unsigned long long m = __ballot(best == g);
+      const int src = m ? __builtin_ctzll(m) : 0;
+      const int jj = __builtin_amdgcn_readlane(bj, src);
+      if (lane == 0) { s.u[i] = g; s.arg[i] = jj; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const int a = lane < 32 ? s.arg[lane] : -1 - lane;
+      bool lose = false;
+      for (int k = 0; k < 31; ++k) {
+        const int ak = __builtin_amdgcn_readlane(a, k);
+        if (lane > k && a == ak) lose = true;
+      }
+      if (lane < 32) {
+        s.col4row[lane] = lose ? -1 : a;
+        if (!lose) s.row4col[a] = lane;
+      }
+    }
+    __syncthreads();
+    bool ch = false;
+    for (int j = tid; j < nc; j += PT)
+      if (s.v[j] < 0.0 && s.row4col[j] == -1) { s.v[j] = 0.0; ch = true; }
+    if (ch) s.flag[0] = 1;
+    __syncthreads();
+    const int changed = s.flag[0];
+    __syncthreads();
+    if (stat && tid == 0) atomicAdd(&stat[2], 1);
+    if (!changed) break;
+  }
+  // ---- 2. augment the rows that lost their claim.  More than a quarter of the rows without a column means the prices carried
+  // nothing over (the first Hungarian iteration behind a collapsed Sinkhorn stage: every slot wants the same nodes, and the block
+  // is ties all over): the shortest-path work would equal the scipy-order solver's and the certificate would refuse anyway
+  {
+    int losers = 0;
+    if (tid < 32) losers = s.col4row[tid] == -1;
+    const int nl = __builtin_popcountll(__ballot(losers != 0));       // (rows live in wavefront 0)
+    if (tid == 0) s.flag[0] = nl;
+    __syncthreads();
+    const int nfree = s.flag[0];
+    __syncthreads();
+    if (nfree > 8) return false;
+  }
+  if (wave == 0) lap_cert_augment<CW>(nc, vl, s, stat);
+  __syncthreads();
+  // ---- 3. certificate on (m, v)
+  for (int j = tid; j < nc; j += PT) s.row4col[j] = -1;
+  if (tid < 66) s.adj[tid] = 0u;
+  if (tid == 0) { s.flag[2] = 0; s.flag[3] = 0; }
+  __syncthreads();
+  {
+    float mc = 0.f, mv = 0.f;
+    for (int j = tid; j < nc; j += PT) {
+      mv = fmaxf(mv, (float)fabs(s.v[j]) * 1.000001f);
+#pragma unroll 8
+      for (int i = 0; i < 32; ++i) mc = fmaxf(mc, fabsf(vl[j * 33 + i]));
+    }
+    mc = wave_max_f32_dpp(mc); mv = wave_max_f32_dpp(mv);
+    if (lane == 0) { atomicMax(&s.flag[2], __float_as_int(mc)); atomicMax(&s.flag[3], __float_as_int(mv)); }     // non-negative floats order as ints
+  }
+  if (tid < 32) {
+    const int j = s.col4row[tid];
+    bool good = j >= 0 && j < nc;
+    if (good) {
+      if (atomicExch(&s.row4col[j], tid) != -1) good = false;          // two rows on one column
+      s.u[tid] = -(double)vl[j * 33 + tid] - s.v[j];
+    } else {
+      s.u[tid] = 0.0;
+    }
+    if (!good) s.flag[1] = 0;
+  }
+  __syncthreads();
+  const double S = (double)__int_as_float(s.flag[2]) + (double)__int_as_float(s.flag[3]);
+  const double t_lo = 1e-12 * S, t_hi = 1e-9 * S;
+  bool ok = S > 0.0 && S < 1e300;                  // (an all-zero block is all ties; a non-finite entry certifies nothing)
+  // nc <= PT on every caller: a thread owns at most ONE column.  The tight entries of a row are OR-ed over the wavefront first
+  // (DPP) and reach LDS as one atomic per row and wavefront: with one atomic per tight ENTRY a degenerate block (the first
+  // Hungarian iteration behind a collapsed Sinkhorn stage: thousands of ties) spent a million cycles serialised on 33 words.
+  {
+    const int j = tid;
+    const bool have = j < nc;
+    const double vj = have ? s.v[j] : 0.0;
+    const int rj = have ? s.row4col[j] : -1;
+    if (have) {
+      if (!(vj <= 0.0)) ok = false;
+      if (rj < 0 && vj != 0.0) ok = false;
+      if (rj >= 0 && vj > -t_hi) atomicOr(&s.adj[2 * 32], 1u << rj);                    // F -> rj (at most 32 of these)
+    }
+    const unsigned mybit = rj >= 0 ? (1u << rj) : 0u;
+    for (int i = 0; i < 32; ++i) {
+      bool tight = false;
+      if (have && i != rj) {
+        const double rc = (-(double)vl[j * 33 + i] - s.u[i]) - vj;
+        if (!(rc >= -t_lo)) ok = false;
+        else tight = rc < t_hi;
+      }
+      const unsigned long long tf = __ballot(tight && rj < 0);                          // i -> F
+      int m = (tight && rj >= 0) ? (int)mybit : 0;                                      // i -> rj
+#define OP(C, R) m |= dpp_mov<C, R>(m);
+      TTDG_DPP_REDUCE(OP)
+#undef OP
+      m = __builtin_amdgcn_readlane(m, 63);
+      if (lane == 0) {
+        if (m != 0) atomicOr(&s.adj[2 * i], (unsigned)m);
+        if (tf != 0ull) atomicOr(&s.adj[2 * i + 1], 1u);
+      }
+    }
+  }
+  if (!ok) s.flag[1] = 0;
+  __syncthreads();
+  if (wave == 0) {      // acyclic <=> peeling sinks empties the graph
+    unsigned long long my = lane < 33 ? ((unsigned long long)s.adj[2 * lane] | ((unsigned long long)(s.adj[2 * lane + 1] & 1u) << 32)) : 0ull;
+    unsigned long long alive = (1ull << 33) - 1ull;
+    for (int round = 0; round < 34; ++round) {
+      const bool sink = lane < 33 && ((alive >> lane) & 1ull) && (my & alive) == 0ull;
+      const unsigned long long m = __ballot(sink);
+      if (m == 0ull) break;
+      alive &= ~m;
+    }
+    if (lane == 0 && alive != 0ull) s.flag[1] = 0;
+  }
+  __syncthreads();
+  return s.flag[1] != 0;
+}

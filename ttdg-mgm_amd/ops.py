@@ -312,7 +312,7 @@ def gagm_cfg(tau0=0.1, gamma=0.5, min_tau=1e-2, tol=1e-3, quad_weight=0.5, max_i
     c = _lib.GagmCfg()
     c.tau0, c.gamma, c.min_tau, c.tol, c.quad_weight = tau0, gamma, min_tau, tol, quad_weight
     c.max_iter, c.sk_iter = int(max_iter), int(sk_iter)
-    c.max_stages, c.start_hungarian, c.profile = int(max_stages), int(bool(start_hungarian)), int(bool(profile))
+    c.max_stages, c.start_hungarian, c.profile = int(max_stages), int(bool(start_hungarian)), int(profile)
     c.no_cycle_skip = int(bool(no_cycle_skip))
     c.variant = int(variant) | GAGM_VARIANT       # per-call A/B selector (_lib.GAGM_*); GAGM_VARIANT = what bench.py's A/B flags set
     return c
