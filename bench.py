@@ -78,7 +78,6 @@ def parse(argv=None):
                                                                   "1 = direct kernel, XCD-sliced, 0 = direct, flat (round 1)")
     ap.add_argument("--roi-xcd-chunks", action="store_true", help="A/B: channels-last ROIPooler with one contiguous eighth of the ROI list per XCD instead of ROI r on workgroup r")
     ap.add_argument("--roi-chunk", type=int, default=0, help="A/B: bins the channels-last ROIPooler stages per output flush: 49 (round 2), 25 (default) or 13")
-    ap.add_argument("--flat-bias-act", action="store_true", help="A/B: the round-2 flat bias_act kernel instead of the per-plane one")
     ap.add_argument("--no-miopen-db", action="store_true", help="A/B: ignore the tuned MIOpen find-db shipped in ttdg-mgm_amd/miopen_db (MIOpen's heuristic picks the solvers)")
     ap.add_argument("--miopen-search", action="store_true", help="tuning run: torch.backends.cudnn.benchmark = True, i.e. MIOpen times its solvers for every "
                     "convolution shape it meets (minutes) and records the winners in its user find-db (MIOPEN_USER_DB_PATH)")
@@ -249,7 +248,7 @@ def _pairs(sizes):
     return [(sizes[a], sizes[b]) for a in range(len(sizes)) for b in range(a + 1)]
 
 
-BIAS_ACT_KERNEL = "bias_act_nhwc_kernel" if os.environ.get("TTDG_CHANNELS_LAST", "1") != "0" else "bias_act_plane_kernel"      # the epilogue kernel of the active layout
+BIAS_ACT_KERNEL = "bias_act_nhwc_kernel"      # the epilogue kernel of the channels-last backbone
 
 
 def kernel_rooflines(run):
@@ -547,12 +546,9 @@ def gpu_main(args, rank, world, local):
             _ops.GAGM_VARIANT |= _lib.GAGM_256_THREADS
         _ops.ROI_ALIGN_NHWC = args.roi_align_mode == 3
         _lib.load().ttdg_debug_set_roi_align_sliced(min(args.roi_align_mode, 2))
-    if args.roi_xcd_chunks or args.flat_bias_act or args.roi_chunk:
+    if args.roi_xcd_chunks or args.roi_chunk:
         from ttdg_mgm_amd import _lib
-        if args.roi_xcd_chunks or args.roi_chunk:
-            _lib.load().ttdg_debug_set_roi_align_sliced(2 | (16 if args.roi_xcd_chunks else 0) | {0: 0, 25: 0, 49: 32, 13: 64}[args.roi_chunk])
-        if args.flat_bias_act:
-            _lib.load().ttdg_debug_set_bias_act_mode(0)
+        _lib.load().ttdg_debug_set_roi_align_sliced(2 | (16 if args.roi_xcd_chunks else 0) | {0: 0, 25: 0, 49: 32, 13: 64}[args.roi_chunk])
     if args.images:
         # strong scaling: the FIXED stream is sharded; warm-up batches come from another stream so that the timed work is
         # exactly args.images images whatever the rank count

@@ -12,7 +12,12 @@
  *  - every pointer is a DEVICE pointer to fp32 / int32 unless stated; row-major;
  *  - the caller (PyTorch caching allocator) owns every buffer incl. workspaces,
  *    the library allocates nothing and keeps no state but a thread-local
- *    error string;
+ *    error string.  Two exceptions, both outside the product path (no caller in
+ *    ttdg-mgm_amd/, used by tests/ and tools/ only) and both process-global:
+ *    ttdg_debug_set_lap_variant (which of two arg-min lowerings ttdg_lap_batched
+ *    uses) and ttdg_debug_set_roi_align_sliced (which of the ROIPooler kernels
+ *    serves a call).  Every other A/B choice travels per call
+ *    (ttdg_gagm_cfg_t.variant);
  *  - all work is enqueued on `stream` (a hipStream_t); no implicit device sync;
  *  - return value 0 = ok, otherwise a negative TTDG_E* code or a positive
  *    hipError_t; ttdg_last_error() describes the last failure on this thread.
@@ -356,11 +361,6 @@ size_t ttdg_resize_u8_workspace_bytes(int planes, int H, int W, int OH, int OW);
 int ttdg_resize_bilinear_u8(const unsigned char* src, unsigned char* dst, int planes, int H, int W, int OH, int OW, void* ws,
                             ttdg_stream_t stream);
 
-/* A/B: 1 = per-plane bias_act kernel (default), 0 = the flat round-2 kernel */
-void ttdg_debug_set_bias_act_mode(int mode);
-/* diagnostics: device buffer of 4 x npairs uint64 shader clocks (begin, affinity done, sweeps done, end) per workgroup of
- * ttdg_pair_stage_fwd, or NULL to switch the in-kernel clock off */
-int ttdg_debug_set_pair_stage_profile(void* device_buffer);
 
 /* DiceEvaluator reductions (reference evaluation/dice_metric.py:25-92 with enhanced_align :110-143 and
  * Structure_measure :147-240): for `npairs` (predicted mask, same-class ground-truth mask) pairs of H x W byte maps (0/1,

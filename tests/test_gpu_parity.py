@@ -727,7 +727,7 @@ def test_perm_loss_kernel_vs_golden(dev, golden, ci):
     ref = og.permutation_loss(sr.unsqueeze(0), (Ua @ Ub.t()).unsqueeze(0))
     ref.backward()
     loss, dW, flag = ops.perm_loss_fwd_bwd(Wds.to(dev), torch.cat([Ua, Ub]).to(dev), ops.graphs([na, nb]), 2)
-    assert abs(float(loss) - float(ref)) <= 1e-6
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-6
     assert maxerr(dW[:na, na:], sr.grad) <= 1e-6 and int(flag.item()) == 0
     assert float(dW[na:, :].abs().max()) == 0 and float(dW[:na, :na].abs().max()) == 0
     bad = Wds.clone(); bad[0, na] = 1.5
@@ -748,7 +748,7 @@ def _run_mgm3(dev, name, forced=None):
 
 
 def _check_against_gold(gold, name, m, dn, loss):
-    assert abs(float(loss) - float(gold[f"{name}_loss"])) <= TOL
+    assert abs(float(loss.detach()) - float(gold[f"{name}_loss"])) <= TOL
     for gi, x in enumerate(dn):
         assert maxerr(x.grad, gold[f"{name}_dnode{gi}"]) <= TOL, gi
     for k, p in m.named_parameters():
@@ -763,7 +763,7 @@ def test_mgm3_end_to_end_planted_golden(dev, golden, name):
     """Free-running: node features -> loss, gradients and the permutation matrices, all against the reference."""
     gold = planted_gold(golden, name)
     m, dn, loss, tr = _run_mgm3(dev, name)
-    print(name, "gagm iterations", tr["info"].cpu().tolist()[:7], "loss", float(loss), "ref", float(gold[f"{name}_loss"]))
+    print(name, "gagm iterations", tr["info"].cpu().tolist()[:7], "loss", float(loss.detach()), "ref", float(gold[f"{name}_loss"]))
     assert np.array_equal(tr["Ub"].cpu().numpy(), gold[f"{name}_U"]), "permutation matrices differ from the reference"
     LEDGER["planted_e2e.identical_permutations_asserted"] += 1
     _check_against_gold(gold, name, m, dn, loss)
@@ -1250,12 +1250,12 @@ def test_cfg3_full_size_forward_backward_against_the_oracle(dev):
         V0 = (torch.linalg.multi_dot([A, U0 @ U0.t(), A, U0]) + Wds @ U0) / G
     print("cfg-3 full size: |Wds| %.2e  |A| %.2e  |U0| rel %.2e  |V0| rel %.2e  loss %.6f vs %.6f" % (
         maxerr(tr["Wds"], Wds), maxerr(tr["apack"], _pack(A, sizes)), maxerr(tr["U0"], U0) / max(1.0, float(U0.abs().max())),
-        maxerr(tr["V0"], V0) / max(1.0, float(V0.abs().max())), float(loss), ref_loss))
+        maxerr(tr["V0"], V0) / max(1.0, float(V0.abs().max())), float(loss.detach()), ref_loss))
     assert maxerr(tr["Wds"], Wds) <= TOL
     assert maxerr(tr["apack"], _pack(A, sizes)) <= 1e-5
     assert maxerr(tr["U0"], U0) <= TOL * max(1.0, float(U0.abs().max()))
     assert maxerr(tr["V0"], V0) <= TOL * max(1.0, float(V0.abs().max()))
-    assert abs(float(loss) - ref_loss) <= TOL
+    assert abs(float(loss.detach()) - ref_loss) <= TOL
     for a, b in zip(dn, rn):
         assert maxerr(a.grad, b.grad) <= TOL * max(1.0, float(b.grad.abs().max()))
     for k, q in m.named_parameters():

@@ -489,7 +489,7 @@ def test_cfg5_bf16_backbone_vs_fp32_on_trained_checkpoint(trained):
         m.multi_matching_unsup.keep_trace = True
         with torch.no_grad():
             loss, _, _, _ = m(batch, branch="TTT")
-        out[name] = (float(loss), m.multi_matching_unsup.last)
+        out[name] = (float(loss.detach()), m.multi_matching_unsup.last)
     (l32, t32), (l16, t16) = out["f32"], out["bf16"]
     assert t16["X"].dtype == torch.float32 and t16["Wds"].dtype == torch.float32
     assert t16["sizes"] == t32["sizes"]

@@ -26,10 +26,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 info = tr["info"].cpu().tolist()
 print("sizes", sizes, "gagm iters", info[:7], "loss", float(loss))
-if any(info[9:14]):
-    tot = sum(info[9:14]) or 1
-    print("gagm phase share  B %.1f%%  S %.1f%%  V %.1f%%  proj %.1f%%  conv %.1f%%   (ticks/64: %s)" % tuple(
-        [100.0 * x / tot for x in info[9:14]] + [info[9:14]]))
+if max(sizes) > 128 and any(info[12:14]):
+    print("multi-workgroup solver, Hungarian stage: %d LAPs with a uniqueness certificate, %d by the scipy-order solver" % (info[12], info[13]))
 t0 = time.perf_counter()
 for _ in range(reps):
     loss = m(dn, dl, Ud); loss.backward()

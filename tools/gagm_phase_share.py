@@ -1,7 +1,8 @@
 import sys, os
-os.environ["TTDG_GAGM_PROFILE"] = "1"
 sys.path.insert(0, ".")
 import torch
+from ttdg_mgm_amd.GModule import multi_graph_matching as _mgm
+_mgm.GAGM_PROFILE = 1          # in-kernel phase clocks of every solve (info[8..13])
 from ttdg_mgm_amd import data
 from ttdg_mgm_amd.config import get_cfg
 from ttdg_mgm_amd.engine import BaselineTrainer

@@ -5,11 +5,12 @@ saves the solver's inputs (A blocks, Wds, U0, sizes) of every step so that the s
 import os
 import sys
 
-os.environ["TTDG_GAGM_PROFILE"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch  # noqa: E402
+from ttdg_mgm_amd.GModule import multi_graph_matching as _mgm
+_mgm.GAGM_PROFILE = 1          # in-kernel phase clocks of every solve (info[8..13])
 
 import synth_checkpoint as sc  # noqa: E402
 

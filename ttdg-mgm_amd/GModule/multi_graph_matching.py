@@ -16,6 +16,9 @@ from .utils.losses import PermutationLoss
 from .utils.sinkhorn import Sinkhorn
 
 
+
+GAGM_PROFILE = 0        # tools only (tools/bench_core.py): ttdg_gagm_cfg_t.profile of every solve, in-kernel phase clocks into info[8..13]
+
 class GA_GM(nn.Module):
     """Graduated-assignment multi-graph matching (reference :191-389), num_clusters == 1 only
     (the only mode MGM3_unsup uses, :533 -> :243-244)."""
@@ -33,7 +36,7 @@ class GA_GM(nn.Module):
             raise NameError('Unknown projecter name: {}'.format(self.projector0[0]))
         return ops.gagm_cfg(tau0=self.sk_tau0[0], gamma=self.sk_gamma, min_tau=self.min_tau[0], tol=self.converge_tol,
                             quad_weight=quad_weight, max_iter=self.mgm_iter[0], sk_iter=self.sk_iter,
-                            profile=bool(os.environ.get("TTDG_GAGM_PROFILE")))
+                            profile=GAGM_PROFILE)
 
     def solve_packed(self, apack, W, U0, sizes, quad_weight=1.):
         U, info, V0 = ops.gagm_solve(apack, W.detach().contiguous(), U0.detach().contiguous(), ops.graphs(sizes), sizes,

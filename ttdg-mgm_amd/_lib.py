@@ -117,8 +117,6 @@ SIGNATURES = {
     "ttdg_debug_set_roi_align_sliced": (C.c_int, [_I]),
     "ttdg_resize_u8_workspace_bytes": (C.c_size_t, [_I, _I, _I, _I, _I]),
     "ttdg_resize_bilinear_u8": (C.c_int, [_P, _P, _I, _I, _I, _I, _I, _P, _S]),
-    "ttdg_debug_set_bias_act_mode": (None, [_I]),
-    "ttdg_debug_set_pair_stage_profile": (C.c_int, [_P]),
     "ttdg_nchw_to_nhwc": (C.c_int, [_P, _P, _I, _I, _I, _I, _S]),
     "ttdg_roi_align_multilevel_nhwc": (C.c_int, [Fpn, Levels, _P, _I, _I, _F, _I, _I, _P, _S]),
     "ttdg_bias_act": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _S]),

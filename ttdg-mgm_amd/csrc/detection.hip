@@ -768,15 +768,12 @@ extern "C" int ttdg_bias_act_nhwc(float* y, const float* bias, const float* resi
   return ttdg_launch_status("bias_act_nhwc");
 }
 
-static int g_bias_act_mode = 1;     // 1 = plane kernel where it applies (default), 0 = the flat round-2 kernel (A/B)
-extern "C" void ttdg_debug_set_bias_act_mode(int mode) { g_bias_act_mode = mode; }
-
 extern "C" int ttdg_bias_act(float* y, const float* bias, const float* residual, const float* bias2, int N, int C, int HW,
                              int relu, ttdg_stream_t stream) {
   TTDG_REQUIRE(y && N >= 0 && C > 0 && HW > 0, "bias_act: bad arguments");
   const size_t total = (size_t)N * C * HW;
   if (total == 0) return 0;
-  if (g_bias_act_mode == 1 && (HW & 3) == 0 && (size_t)N * C <= 65535 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)residual & 15) == 0) {
+  if ((HW & 3) == 0 && (size_t)N * C <= 65535 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)residual & 15) == 0) {
     const int HW4 = HW >> 2;
     hipLaunchKernelGGL(bias_act_plane_kernel, dim3((HW4 + 1023) / 1024, N * C), dim3(256), 0, (hipStream_t)stream, y, bias, residual, bias2,
                        C, HW4, relu);

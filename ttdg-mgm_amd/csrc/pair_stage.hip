@@ -194,9 +194,7 @@ __device__ __forceinline__ void ps_row_sweep(const float (&L)[PS_RW], float (&f)
 __global__ __launch_bounds__(256) void pair_stage_fwd_kernel(const float* __restrict__ P, const float* __restrict__ Q,
                                                              const float* __restrict__ w2, const float* __restrict__ b2, int H,
                                                              ttdg_graphs_t gr, float tau, int iters, float* __restrict__ aff,
-                                                             float* __restrict__ Wds, float* __restrict__ pot, int cmax,
-                                                             unsigned long long* __restrict__ prof) {
-  const unsigned long long t_begin = prof ? __builtin_amdgcn_s_memtime() : 0ull;
+                                                             float* __restrict__ Wds, float* __restrict__ pot, int cmax) {
   __shared__ __attribute__((aligned(16))) float Ps[2][PS_T][PS_LDK];
   __shared__ __attribute__((aligned(16))) float Qs[2][PS_T][PS_LDK];
   __shared__ __attribute__((aligned(16))) float Ws[2][PS_BK];
@@ -287,7 +285,6 @@ __global__ __launch_bounds__(256) void pair_stage_fwd_kernel(const float* __rest
   __syncthreads();
 
   // ---- phase 2: 20 sweeps in registers ----
-  const unsigned long long t_aff = prof ? __builtin_amdgcn_s_memtime() : 0ull;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int potld = PS_T + 1;
   float L[PS_RW], f[PS_RW];
@@ -331,7 +328,6 @@ __global__ __launch_bounds__(256) void pair_stage_fwd_kernel(const float* __rest
     }
   }
   // ---- result: Wds[a,b] and its mirror; the potential log ----
-  const unsigned long long t_sk = prof ? __builtin_amdgcn_s_memtime() : 0ull;
   float* wab = Wds + (size_t)i0 * M + j0;      // element (i in a, j in b)
   float* wba = Wds + (size_t)j0 * M + i0;      // element (j in b, i in a)
 #pragma unroll
@@ -353,14 +349,7 @@ __global__ __launch_bounds__(256) void pair_stage_fwd_kernel(const float* __rest
       if (x < n) pt[e] = plog[it * potld + x];
     }
   }
-  if (prof && tid == 0) {      // in-kernel phase clock (ttdg_debug_set_pair_stage_profile): begin, affinity done, sweeps done, end
-    prof[blockIdx.x * 4 + 0] = t_begin; prof[blockIdx.x * 4 + 1] = t_aff; prof[blockIdx.x * 4 + 2] = t_sk;
-    prof[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
-  }
 }
-
-static unsigned long long* g_ps_prof = nullptr;     // device buffer of 4 x npairs clocks, or null (diagnostics only)
-extern "C" int ttdg_debug_set_pair_stage_profile(void* device_buffer) { g_ps_prof = (unsigned long long*)device_buffer; return 0; }
 
 extern "C" int ttdg_pair_stage_fwd(const float* P, const float* Q, const float* w2, const float* b2, int H, ttdg_graphs_t gr,
                                    float tau, int iters, float* aff, float* Wds, float* pot, ttdg_stream_t stream) {
@@ -372,7 +361,7 @@ extern "C" int ttdg_pair_stage_fwd(const float* P, const float* Q, const float* 
   for (int g = 0; g < gr.G; ++g) cmax = gr.off[g + 1] - gr.off[g] > cmax ? gr.off[g + 1] - gr.off[g] : cmax;
   TTDG_REQUIRE(cmax <= PS_T, "pair_stage_fwd: graphs of more than 64 nodes take ttdg_affinity_pairwise_fwd + ttdg_sinkhorn_pairs_fwd");
   hipLaunchKernelGGL(pair_stage_fwd_kernel, dim3(gr.G * (gr.G + 1) / 2), dim3(256), 0, (hipStream_t)stream, P, Q, w2, b2, H, gr, tau,
-                     iters, aff, Wds, pot, cmax, g_ps_prof);
+                     iters, aff, Wds, pot, cmax);
   return ttdg_launch_status("pair_stage_fwd");
 }
 

@@ -88,6 +88,9 @@ def map_for_test(d, min_size=800, max_size=1333, resize=True):
     return out
 
 
+STAGE_IN_THREAD = False      # disk streams: stage on a helper thread instead of the consumer's own (A/B switch, measured in DESIGN.md section 8)
+
+
 class TestLoader:
     """Iterable over lists of mapped dicts; rank r sees the contiguous shard detectron2's InferenceSampler gives it.
 
@@ -111,8 +114,8 @@ class TestLoader:
         self.device_resize = (cuda and not resident) if device_resize is None else bool(device_resize and cuda)
         self._disk = None
         # disk streams: stage (DMA from the ring + resize launch) from the consumer's own thread one batch ahead (default), or on a helper
-        # thread (TTDG_STAGE_THREAD=1).  Measured back to back on the final build: 0.932 / 0.950 x the resident rate against 0.902 / 0.940
-        self.stage_in_thread = os.environ.get("TTDG_STAGE_THREAD", "0") != "0"
+        # thread (data.STAGE_IN_THREAD = True).  Measured back to back on the final build: 0.932 / 0.950 x the resident rate against 0.902 / 0.940
+        self.stage_in_thread = STAGE_IN_THREAD
         if not resident and _REGISTRY[name]["kind"] == "disk":
             from . import disk
             spec = _REGISTRY[name]

@@ -8,9 +8,9 @@ import numpy as np
 import torch
 
 # the float64 closed forms of Dice / E / S run in ONE small HIP kernel after the count kernel (ops.mask_pair_measures);
-# TTDG_DEVICE_MEASURES=0 evaluates them with torch tensor operations instead (measures_from_counts: ~150 tiny launches per batch;
+# DEVICE_MEASURES = False evaluates them with torch tensor operations instead (measures_from_counts: ~150 tiny launches per batch;
 # the statement the kernel is tested against)
-DEVICE_MEASURES = os.environ.get("TTDG_DEVICE_MEASURES", "1") != "0"
+DEVICE_MEASURES = True
 
 
 # All three measures are written without host synchronisation (no .item(), no Python branch on a device value):

@@ -8,22 +8,22 @@ import torch.nn.functional as F
 from .. import ops
 
 
-import os
-
-# module switch (calibrate_frozen_bn turns it off: its statistics hooks sit on ConvNorm.forward); TTDG_FUSED_EPILOGUE=0 for A/B runs
-FUSED_EPILOGUE = os.environ.get("TTDG_FUSED_EPILOGUE", "1") != "0"
+# The four switches below are module attributes, not configuration: nothing reads the environment.  The product runs with all of
+# them True; the parity tests flip one at a time to compare a fused kernel with the plain torch formulation of the same arithmetic
+# (tests/test_gpu_parity.py), tools/ab_backbone.py measures them, and calibrate_frozen_bn turns FUSED_EPILOGUE off while its
+# statistics hooks sit on ConvNorm.forward.
+FUSED_EPILOGUE = True
 # the FrozenBN scale is folded into all filters of a ResNet stage by ONE launch (ops.row_scale_multi) instead of one elementwise
-# kernel per filter per pass; TTDG_MULTI_FOLD=0 for A/B runs
-MULTI_FOLD = os.environ.get("TTDG_MULTI_FOLD", "1") != "0"
-# bias (+ top-down sum) of the FPN convolutions, the RPN head inside the TTA step and the mask head through the in-place epilogue
-# kernel; TTDG_FUSED_HEADS=0 for A/B runs
-FUSED_HEADS = os.environ.get("TTDG_FUSED_HEADS", "1") != "0"
+# kernel per filter per pass
+MULTI_FOLD = True
+# bias (+ top-down sum) of the FPN convolutions, the RPN head inside the TTA step and the mask head through the in-place epilogue kernel
+FUSED_HEADS = True
 # The backbone runs in CHANNELS-LAST memory on the GPU (fp32, outside autocast): MIOpen's fastest fp32 kernels on gfx950 are its
 # NHWC implicit GEMMs, which it wraps in transposes when handed NCHW tensors (6 % of an adapted batch); measured with MIOpen
 # choosing per shape in both layouts: 21.6 vs 24.2 ms per train step, 8.5 vs 9.5 ms per no-grad forward (plain epilogues).
 # FPN.forward moves its filters to channels-last storage at the first GPU forward and converts the image batch; every kernel behind ops.* takes either
-# layout.  TTDG_CHANNELS_LAST=0 keeps NCHW (A/B).
-CHANNELS_LAST = os.environ.get("TTDG_CHANNELS_LAST", "1") != "0"
+# layout.  (False keeps NCHW: the layout parity test.)
+CHANNELS_LAST = True
 
 
 def _publish(t):

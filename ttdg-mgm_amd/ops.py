@@ -89,7 +89,7 @@ def gemm_grouped(descs):
         call("ttdg_gemm_f32_grouped", arr, len(chunk), stream())
 
 
-GROUPED_GEMM = os.environ.get("TTDG_GROUPED_GEMM", "1") != "0"      # False = one launch per product (A/B)
+GROUPED_GEMM = True      # False = one launch per product (parity tests compare the two)
 GROUPED_GEMM_MAX_ROWS = 512      # stacked nodes up to which the 32 x 32-tile grouped kernel is used: it is built for M ~ 120 (launch-bound
                                  # products); at cfg-3 (M = 2048) the 64 x 64-tile kernel is twice as fast per product (84 vs 2 x 22 us)
 
@@ -229,7 +229,7 @@ def sinkhorn_pairs_fwd(part, b2, gr, sizes, tau, iters, want_pot=True):
     return Wds, pot
 
 
-FUSED_PAIR_STAGE = os.environ.get("TTDG_FUSED_PAIR", "1") != "0"     # graphs of <= 64 nodes: affinity + pair Sinkhorn in one launch (csrc/pair_stage.hip); False = the two-launch form (A/B)
+FUSED_PAIR_STAGE = True     # graphs of <= 64 nodes: affinity + pair Sinkhorn in one launch (csrc/pair_stage.hip); False = the two-launch form larger graphs take (parity tests)
 PAIR_STAGE_MAX = 64
 
 
@@ -840,7 +840,7 @@ def rpn_decode(deltas, anchors, idx, score, sizes_t, boxes, scores, col0):
          B, k, A4 // 4, H, W, boxes.shape[1], int(col0), ptr(boxes), ptr(scores), stream())
 
 
-RPN_SELECT = os.environ.get("TTDG_RPN_SELECT", "1") != "0"      # False = per level permute + torch.topk + rpn_decode (A/B)
+RPN_SELECT = True      # False = per level permute + torch.topk + rpn_decode: the path beyond the selection kernel's limits (parity test)
 
 
 def rpn_select(logits, deltas, anchors, ks, sizes_t, boxes, scores):
