@@ -61,6 +61,57 @@ def test_two_rank_sharding_and_score_gather():
     assert t0 == t1 == 2.0
 
 
+def _worker_cfg4(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ttdg_mgm_amd import data
+        from ttdg_mgm_amd.config import get_cfg
+        from ttdg_mgm_amd.evaluation import DiceEvaluator
+        cfg = get_cfg()
+        cfg.TEST.BATCH = 4
+        cfg.INPUT.MIN_SIZE_TEST, cfg.INPUT.MAX_SIZE_TEST = 32, 64          # (the plumbing, not 2048 resizes to 800 x 800 on the CPU)
+        data.register_synthetic("cfg4_ds", 2048, size=32, cfg_id=4)
+        loader = data.build_detection_test_loader(cfg, "cfg4_ds", rank, world)
+        nb, ids = 0, []
+        for b in loader:
+            nb += 1
+            ids += [d["image_id"] for d in b]
+        ev = DiceEvaluator("cfg4_ds", 0.9)
+        ev.dice_scores = [float(i) for i in ids if i % (rank + 2) == 0]       # a DIFFERENT number of kept masks on every rank
+        ev.ea_scores, ev.sm_scores = list(ev.dice_scores), list(ev.dice_scores)
+        ev.gather_scores()
+        t = torch.tensor([10.0 - rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        q.put((rank, ids[0], ids[-1], len(ids), nb, len(ev.dice_scores), float(sum(ev.dice_scores)), float(t)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_sharding_of_the_2048_image_stream():
+    """BASELINE cfg-4 plumbing (no 8-GPU node is available to the builder): 2048 images over 8 ranks, TEST.BATCH = 4 - every rank
+    owns the contiguous shard [256 r, 256 (r + 1)) (detectron2 InferenceSampler [3P], data/build.py:139), takes 64 steps, and the
+    variable-length score lists are all-gathered so that every rank reports the same 2048-image means (SURVEY.md 8e Mode R); the
+    bench's max-over-ranks timing reduction.  gloo on CPU; the same code path runs over RCCL on the GPUs."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_cfg4, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect_kept = sum(1 for r in range(world) for i in range(256 * r, 256 * (r + 1)) if i % (r + 2) == 0)
+    expect_sum = float(sum(i for r in range(world) for i in range(256 * r, 256 * (r + 1)) if i % (r + 2) == 0))
+    for r, first, last, n, nb, kept, total, t in res:
+        assert (first, last, n, nb) == (256 * r, 256 * r + 255, 256, 64), (r, first, last, n, nb)
+        assert kept == expect_kept and total == expect_sum          # every rank holds every rank's scores
+        assert t == 10.0
+
+
 def test_single_process_loader_matches_reference_sampler():
     from ttdg_mgm_amd import data
     from ttdg_mgm_amd.config import get_cfg

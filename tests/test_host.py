@@ -481,3 +481,23 @@ def test_layout_helpers():
             out = ops.like_layout(src, ref)
             assert torch.equal(out, b) and out.stride() == ref.stride()
     assert ops.like_layout(b, a) is b and ops.like_layout(b.contiguous(memory_format=CL), a.contiguous(memory_format=CL)).is_contiguous(memory_format=CL)
+
+
+def test_mode_s_flattens_gradients_in_the_parameters_storage_order():
+    """engine/sync_universe.py: a channels-last filter gradient enters the all-reduce buffer as a VIEW in storage order (round 3
+    went through reshape(-1): a transposing copy in, an NCHW-strided gradient out, a second copy inside the SGD step) and comes
+    back with the parameter's own strides; plain tensors are untouched; the order depends on the parameter only."""
+    import torch
+    from ttdg_mgm_amd.engine import sync_universe as su
+    p = torch.randn(6, 4, 3, 3).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(6, 4, 3, 3).contiguous(memory_format=torch.channels_last)
+    f = su.storage_flat(g, p)
+    assert f.data_ptr() == g.data_ptr() and f.is_contiguous() and f.numel() == g.numel()          # a view, no copy
+    back = su.storage_unflat(f.clone(), p)
+    assert back.stride() == p.stride() and torch.equal(back, g)
+    # an NCHW-contiguous gradient of a channels-last parameter lands in the SAME order (every rank composes the same buffer)
+    assert torch.equal(su.storage_flat(g.contiguous(), p), f)
+    q = torch.randn(5, 7)
+    assert su.storage_flat(q, q).data_ptr() == q.data_ptr() and torch.equal(su.storage_unflat(q.reshape(-1), q), q)
+    one = torch.randn(8, 1, 1, 1)              # both layouts at once: stays the plain path
+    assert su.storage_flat(one, one).data_ptr() == one.data_ptr()

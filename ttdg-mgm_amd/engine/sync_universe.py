@@ -135,6 +135,27 @@ def _have_mask(params):
     return [bool(h) for h in have.tolist()]
 
 
+def _is_cl(p):
+    """A dense channels-last 4-D tensor (the detector's filters on the GPU, modeling/backbone.py) that is not ALSO NCHW-contiguous."""
+    return p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last)
+
+
+def storage_flat(g, like):
+    """``g`` as a flat vector in the STORAGE order of the parameter ``like`` - a view when g has that layout (the usual case: no
+    transposing copy of a channels-last gradient through reshape(-1)); the order depends on the parameter only, so every rank
+    composes the same flat buffer."""
+    return g.permute(0, 2, 3, 1).reshape(-1) if _is_cl(like) else g.reshape(-1)
+
+
+def storage_unflat(flat, like):
+    """Inverse of storage_flat: a tensor of ``like``'s shape AND strides over ``flat``'s memory (the fused SGD step then finds the
+    gradient in the parameter's own layout and copies nothing)."""
+    if _is_cl(like):
+        n, c, h, w = like.shape
+        return flat.view(n, h, w, c).permute(0, 3, 1, 2)
+    return flat.view_as(like)
+
+
 def _launch_bucket(params, idx, have, nsum, world):
     """Flatten the gradients of one bucket (zeros where this rank has none, replicated ones pre-divided) and start its
     SUM all-reduce.  -> (work handle, flat buffer, [(param, numel)]) or None for a bucket without any live gradient."""
@@ -147,7 +168,7 @@ def _launch_bucket(params, idx, have, nsum, world):
         items.append((p, g / world if i >= nsum else g))
     if not items:
         return None
-    flat = torch.cat([g.reshape(-1) for _, g in items])
+    flat = torch.cat([storage_flat(g, p) for p, g in items])
     return _all_reduce_async(flat, dist.ReduceOp.SUM), flat, [(p, g.numel()) for p, g in items]
 
 
@@ -156,7 +177,7 @@ def _finish(work):
         w.wait()
         off = 0
         for p, n in items:
-            p.grad = flat[off:off + n].view_as(p)
+            p.grad = storage_unflat(flat[off:off + n], p)
             off += n
 
 
