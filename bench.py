@@ -78,6 +78,7 @@ def parse(argv=None):
                                                                   "1 = direct kernel, XCD-sliced, 0 = direct, flat (round 1)")
     ap.add_argument("--roi-xcd-chunks", action="store_true", help="A/B: channels-last ROIPooler with one contiguous eighth of the ROI list per XCD instead of ROI r on workgroup r")
     ap.add_argument("--roi-chunk", type=int, default=0, help="A/B: bins the channels-last ROIPooler stages per output flush: 49 (round 2), 25 (default) or 13")
+    ap.add_argument("--no-graphs", action="store_true", help="A/B: the backbone eagerly, kernel by kernel (default: hipGraph replay of its forward / backward, modeling/graphed.py)")
     ap.add_argument("--no-miopen-db", action="store_true", help="A/B: ignore the tuned MIOpen find-db shipped in ttdg-mgm_amd/miopen_db (MIOpen's heuristic picks the solvers)")
     ap.add_argument("--miopen-search", action="store_true", help="tuning run: torch.backends.cudnn.benchmark = True, i.e. MIOpen times its solvers for every "
                     "convolution shape it meets (minutes) and records the winners in its user find-db (MIOPEN_USER_DB_PATH)")
@@ -538,6 +539,8 @@ def gpu_main(args, rank, world, local):
     cfg = base_cfg(args, device)
     from ttdg_mgm_amd import ops as _ops
     from ttdg_mgm_amd.modeling import detector as _det
+    from ttdg_mgm_amd.modeling import graphed as _graphed
+    _graphed.ENABLED = not args.no_graphs
     assert _det._backend is _ops, "the GPU legs must run on the HIP operators (detector._backend was re-pointed)"
     if args.gagm_threads or args.roi_align_mode != 3:
         from ttdg_mgm_amd import _lib
@@ -568,6 +571,17 @@ def gpu_main(args, rank, world, local):
     init_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
     tf = bool(args.teacher_forced)
     main = timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, world, device, tf)
+    eager_probe = None
+    if _graphed.ENABLED and model.__dict__.get("_graphed") is not None and model.__dict__["_graphed"].stats["train_replays"] > 0:
+        # Inside a graph replay no HIP event can be placed around a single kernel from here.  The per-kernel durations of the
+        # rooflines therefore come from a SECOND timed pass over the same K batches with the backbone launched eagerly (live HIP
+        # events on the launch stream, as before); its images/s is the graphs-off A/B figure of the line.
+        _graphed.ENABLED = False
+        try:
+            eager_probe = timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, world, device, tf)
+        finally:
+            _graphed.ENABLED = True
+        main["stamps"] = eager_probe["stamps"]
     note("headline pass done: %.1f images/s" % (world * K * B / main["elapsed"]))
     if args.sync_debug and world == 1:
         import collections
@@ -730,6 +744,10 @@ def gpu_main(args, rank, world, local):
         "inputs": "pre-staged in HBM (uint8, already resized to 800x800 by the test mapper); loader-inclusive rate under ab.loader_inclusive",
         "tta_only_images_per_s": images / main["tta"], "dice": main["dice"], "kept_masks": main["kept_masks"],
         "tta_steps_taken": main["steps_taken"],
+        "eager_pass": (None if eager_probe is None else {"value": images / eager_probe["elapsed"], "unit": "images/s", "dice": eager_probe["dice"],
+                                                          "note": "same K batches, backbone launched kernel by kernel (graphs off): the pass the per-kernel HIP-event durations of `roofline` come from"}),
+        "backbone_launches": ("hipGraph replay of the backbone's forward (Dice pass) and forward + backward (TTA step): %s (A/B: --no-graphs)" % (model.__dict__["_graphed"].stats,)
+                              if model.__dict__.get("_graphed") is not None else "eager, kernel by kernel (--no-graphs)"),
         "vendor_convolutions": ("MIOpen immediate mode, solvers from the find-db shipped in ttdg-mgm_amd/miopen_db (tools/tune_miopen.sh; A/B: --no-miopen-db)"
                                 if os.path.basename(os.environ.get("MIOPEN_USER_DB_PATH", "").rstrip("/")).startswith(("miopen_db", "ttdg_miopen_db")) and not args.miopen_search else
                                 "MIOpen timing its solvers in this process (--miopen-search)" if args.miopen_search else "MIOpen immediate mode, heuristic solver choice"),

@@ -586,3 +586,66 @@ def test_cfg5_own_checkpoint_bf16_backbone_vs_fp32(trained):
 CFG5_DICE_TOL = 3e-2        # every box fits its own polyp checkpoint (the fit is not bit-reproducible), so the figure has a spread: relative Dice
                             # difference 5.1e-4 / 6.7e-3 (16 images, ~20 kept masks), then < 1e-2 on three boxes and 1.7e-2 on one (48 images,
                             # 68 kept masks: one or two masks crossing the 0.9 score threshold move the mean by a point); E and S stay < 1e-2
+
+
+def test_graphed_backbone_equals_the_eager_backbone(trained):
+    """[r4] modeling/graphed.py: fixed-shape fp32 batches replay the backbone from hipGraphs (one for the no-grad forward of the
+    Dice pass, a forward + backward pair for the TTA step).  Same kernels in the same order: (1) eval-mode features of a replay
+    equal the eager forward bit for bit, on the capture batch AND on another batch, BEFORE and AFTER an adaptation step moved the
+    weights (the folds of the adapted filters are inside the graph); (2) a TTA step through the graphs gives the eager step's loss
+    and gradients (the vendor's weight-gradient kernels are not bit-reproducible run to run: gradients within 1e-4 of the largest
+    entry per tensor, the loss within 1e-5 relative); (3) both graphs were actually captured and replayed."""
+    import copy
+    from ttdg_mgm_amd.engine import BaselineTrainer
+    from ttdg_mgm_amd.modeling import graphed
+    cfg, cpu, gpu, batches = trained
+    assert graphed.ENABLED
+    mg, me = copy.deepcopy(gpu), copy.deepcopy(gpu)
+    for m in (mg, me):
+        m.teacher_forced = True
+        m.multi_matching_unsup.eval()
+
+    def feats(m, batch, use_graph):
+        graphed.ENABLED = use_graph
+        try:
+            m.eval()
+            with torch.no_grad():
+                f = m._backbone(m.preprocess_image(batch).tensor)
+            return {k: v.clone() for k, v in f.items()}
+        finally:
+            graphed.ENABLED = True
+
+    def step(m, batch, use_graph, opt):
+        graphed.ENABLED = use_graph
+        try:
+            m.train()
+            loss, _, _, _ = m(batch, branch="TTT")
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            g = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+            opt.step()
+            return float(loss.detach()), g
+        finally:
+            graphed.ENABLED = True
+
+    for b in (batches[0], batches[1]):                                   # (1) before any step
+        fg, fe = feats(mg, b, True), feats(me, b, False)
+        for k in fe:
+            assert torch.equal(fg[k], fe[k]), k
+    og_, oe = BaselineTrainer.build_optimizer(cfg, mg), BaselineTrainer.build_optimizer(cfg, me)
+    for b in (batches[2], batches[3]):                                   # (2) two adaptation steps
+        lg, gg = step(mg, b, True, og_)
+        le, ge = step(me, b, False, oe)
+        assert abs(lg - le) <= 1e-5 * max(1.0, abs(le)), (lg, le)
+        assert set(gg) == set(ge)
+        for n in ge:
+            assert float((gg[n] - ge[n]).abs().max()) <= 1e-4 * max(float(ge[n].abs().max()), 1e-12) + 1e-9, n
+    # (1) again: the graphs re-fold from the LIVE parameters.  Same weights on both sides for an exact statement.
+    me.load_state_dict(mg.state_dict())
+    for b in (batches[0], batches[4]):
+        fg, fe = feats(mg, b, True), feats(me, b, False)
+        for k in fe:
+            assert torch.equal(fg[k], fe[k]), k
+    st = mg.__dict__["_graphed"].stats
+    print("graphed backbone:", st)
+    assert st["disabled"] is None and st["eval_captures"] == 1 and st["train_captures"] == 1 and st["eval_replays"] >= 4 and st["train_replays"] >= 2, st

@@ -782,8 +782,14 @@ __device__ __forceinline__ void gl_project_graph(const ttdg_graphs_t& gr, const 
       if (tid == 0) { w.lapok[g] = certified ? 1 : 0; atomicAdd(&w.lapstat[certified ? 0 : 1], 1); }
       GL_PHASE(3)
     }
-    __syncthreads();                                                     // zeros land before wavefront 0 writes the ones
-    if (!certified && wave == 0) {
+    __syncthreads();                                                     // zeros land before the ones are written
+    if (!certified && tr && n <= PT && !(cfg.variant & TTDG_GAGM_SCIPY_ORDER_LAP)) {
+      // scipy-order LAP over all wavefronts of the workgroup (lap_certified.h: lap_block_solve_exact), one column per thread
+      const LapBlockScratch bs = lap_block_carve(lscr, n);
+      lap_block_solve_exact<PT>(n, vl, bs);
+      __syncthreads();
+      if (tid < NU) Unew[bs.col4row[tid] * NU + tid] = 1.f;
+    } else if (!certified && wave == 0) {
       if (nc <= 64) {
         const int b = lap_wave_solve_reg<0, true>(nr, nc, vl, tr ? 1 : 33, tr ? 33 : 1);
         wave_sync();

@@ -291,3 +291,115 @@ __device__ __forceinline__ bool lap_certified_solve(int nc, const float* vl, con
   __syncthreads();
   return s.flag[1] != 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Scipy-order LAP on the WHOLE workgroup (32 rows = universe slots, nc <= PT node columns, one column per thread): step for step
+// the algorithm of lap_wave_solve_regw - the same shortest-path scan, the same fp64 evaluation order ((minVal + c) - u_i) - v_j,
+// the same tie rule on scipy's `remaining` positions (some minimal column unassigned -> the LAST such position, else the FIRST
+// minimal position; the last position moves into the hole) - with the arg-min of a step taken over all wavefronts: a DPP minimum
+// per wavefront, three LDS meetings per step (minima; tie summary; the selected column).  One wavefront owning four columns per
+// lane spends ~2400 cycles per step in one dependent fp64 chain (measured: 1.25 M cycles for the 32 x 256 block of all-tied costs
+// that follows a collapsed Sinkhorn stage - 23 % of the cfg-3 solve); here a step is ~800.
+struct LapBlockScratch {
+  double* u;        // [32]
+  double* spc;      // [nc]   (published for the dual update)
+  double* wmin;     // [16]
+  int* path;        // [nc]
+  int* row4col;     // [nc]
+  int* col4row;     // [32]
+  int* SR;          // [32]
+  int* tie;         // [16][4]: count of minima, largest position of an unassigned minimum (-1: none), smallest position of a minimum
+  int* sel;         // [4]: selected column, its owner row, its position
+};
+__host__ __device__ inline size_t lap_block_scratch_bytes(int nc) { return (size_t)(32 + nc + 16) * 8 + (size_t)(2 * nc + 32 + 32 + 64 + 4) * 4; }
+__device__ inline LapBlockScratch lap_block_carve(void* base, int nc) {     // base 8-byte aligned
+  LapBlockScratch s;
+  double* d = (double*)base;
+  s.u = d; s.spc = d + 32; s.wmin = s.spc + nc;
+  int* i = (int*)(s.wmin + 16);
+  s.path = i; s.row4col = i + nc; s.col4row = s.row4col + nc; s.SR = s.col4row + 32; s.tie = s.SR + 32; s.sel = s.tie + 64;
+  return s;
+}
+
+// every thread of the workgroup calls; on return s.col4row[slot] = node of every universe slot
+template <int PT>
+__device__ __forceinline__ void lap_block_solve_exact(int nc, const float* vl, const LapBlockScratch& s) {
+  constexpr int NW = PT / 64;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int j = tid;
+  const bool is_col = j < nc;
+  double v = 0.0, spc = INFINITY;
+  int row4col = -1, path = -1;
+  if (tid < 32) { s.u[tid] = 0.0; s.col4row[tid] = -1; }
+  __syncthreads();
+  for (int cur = 0; cur < 32; ++cur) {
+    double minVal = 0.0;
+    int nrem = nc, i = cur, sink = -1;
+    bool active = is_col, SC = false;
+    int pos = nc - 1 - j;
+    spc = INFINITY;
+    if (tid < 32) s.SR[tid] = 0;
+    __syncthreads();
+    while (sink == -1) {
+      if (tid == 0) s.SR[i] = 1;
+      const double ui = s.u[i];
+      if (active) {
+        const double r = minVal + (-(double)vl[j * 33 + i]) - ui - v;
+        if (r < spc) { path = i; spc = r; }
+      }
+      const double wm = wave_min_f64_dpp(active ? spc : INFINITY);
+      if (lane == 0) s.wmin[wave] = wm;
+      __syncthreads();
+      double gmin = s.wmin[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) gmin = fmin(gmin, s.wmin[w]);
+      const bool is_min = active && spc == gmin;
+      const bool un = is_min && row4col == -1;
+      {
+        const unsigned long long mm = __ballot(is_min);
+        int mx = -1, mn = 0x7fffffff;
+        if (mm != 0ull) {          // wavefront-uniform
+          mx = wave_max_i32_dpp(un ? pos : -1);
+          mn = wave_min_i32_dpp(is_min ? pos : 0x7fffffff);
+        }
+        if (lane == 0) { s.tie[4 * wave] = __builtin_popcountll(mm); s.tie[4 * wave + 1] = mx; s.tie[4 * wave + 2] = mn; }
+      }
+      __syncthreads();
+      int mxu = -1, mnp = 0x7fffffff;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { mxu = max(mxu, s.tie[4 * w + 1]); mnp = min(mnp, s.tie[4 * w + 2]); }
+      const int selpos = mxu >= 0 ? mxu : mnp;          // (finite costs: at least one minimum exists)
+      if (active && pos == selpos) { s.sel[0] = j; s.sel[1] = row4col; }
+      __syncthreads();
+      const int jsel = s.sel[0], owner = s.sel[1];
+      if (j == jsel) { SC = true; active = false; }
+      else if (active && pos == nrem - 1) pos = selpos;
+      --nrem;
+      minVal = gmin;
+      if (owner == -1) sink = jsel; else i = owner;
+      if (nrem < 0) { sink = jsel; break; }             // (cannot happen with finite costs; never spin)
+    }
+    // dual updates (rows on the alternating tree, scanned columns), then the augmentation along the stored path
+    if (is_col) { s.spc[j] = spc; s.path[j] = path; s.row4col[j] = row4col; }
+    __syncthreads();
+    if (tid < 32) {
+      if (tid == cur) s.u[tid] += minVal;
+      else if (s.SR[tid]) s.u[tid] += minVal - s.spc[s.col4row[tid]];
+    }
+    if (SC) v -= minVal - spc;
+    __syncthreads();
+    if (tid == 0) {
+      int jj = sink;
+      for (int guard = 0; guard < 34; ++guard) {
+        const int r = s.path[jj];
+        const int t = s.col4row[r];
+        s.row4col[jj] = r;
+        s.col4row[r] = jj;
+        jj = t;
+        if (r == cur) break;
+      }
+    }
+    __syncthreads();
+    if (is_col) row4col = s.row4col[j];
+  }
+}

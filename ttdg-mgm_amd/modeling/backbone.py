@@ -26,10 +26,13 @@ FUSED_HEADS = True
 CHANNELS_LAST = True
 
 
+_CAPTURING = False      # set by modeling/graphed.py while a hipGraph capture records the forward: no host synchronisation then
+
+
 def _publish(t):
     """A lazily built constant is about to be cached and may be consumed from ANOTHER HIP stream (the Dice pass runs
     inference on several streams): make sure the kernels that produce it have finished before it becomes visible."""
-    if t.is_cuda:
+    if t.is_cuda and not _CAPTURING:
         torch.cuda.current_stream(t.device).synchronize()
     return t
 
@@ -211,18 +214,33 @@ class ResNet50(nn.Module):
             for p in m.parameters():
                 p.requires_grad_(False)
 
+    # cfg-5 precision islands (rcnn.autocast_backbone = "res2" ... "res5"): the stages up to and including ``autocast_upto`` run
+    # under bf16 autocast, the later ones (and the FPN) in fp32 on the up-cast activations; None = whatever context the caller set
+    autocast_upto = None
+    _ORDER = ("stem", "res2", "res3", "res4", "res5")
+
+    def _run(self, name, mod, x):
+        upto = self.autocast_upto
+        if upto is None:
+            return mod(x)
+        if self._ORDER.index(name) <= self._ORDER.index(upto):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                return mod(x)
+        return mod(x.float())
+
     def forward(self, x):
-        x = self.stem(x)
+        x = self._run("stem", self.stem, x)
         outs = []
         for name in ("res2", "res3", "res4", "res5"):
             stage = getattr(self, name)
-            staged = _fold_stage(stage, x)
+            island = self.autocast_upto is not None and self._ORDER.index(name) <= self._ORDER.index(self.autocast_upto)
+            staged = None if island else _fold_stage(stage, x.float() if self.autocast_upto is not None else x)
             try:
-                x = stage(x)
+                x = self._run(name, stage, x)
             finally:
                 for c in staged or ():
                     c._staged_w = None
-            outs.append(x)
+            outs.append(x.float() if self.autocast_upto is not None else x)
         return tuple(outs)
 
 

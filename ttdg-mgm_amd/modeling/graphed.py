@@ -1,0 +1,129 @@
+"""hipGraph replay of the ResNet-50-FPN stand-in for fixed-shape fp32 GPU batches.
+
+An adapted batch launches ~1300 kernels, ~900 of them inside the backbone's forward / backward, with 4-5 us of idle device time
+between two of them (profiles/r03_trace_gaps.txt: 5.8 % of the step in gaps below 15 us).  The test streams of this path have ONE
+image shape, so the backbone's launch sequence is the same every step: it is captured once per (shape, mode) and replayed.
+
+  eval mode (Dice pass, no gradient)  torch.cuda.CUDAGraph over ``backbone(x)``.  The FrozenBN folds of the ADAPTED filters are
+      captured too (their caches are dropped before the capture, so every replay re-folds from the live parameters: a replay after
+      a TTA step sees the adapted weights); frozen filters (stem, res2) keep their cached folds - constants for the process.
+  TTT mode (gradients)               torch.cuda.make_graphed_callables over a tuple-returning wrapper: one graph for the forward,
+      one for the backward (custom autograd Functions of ops.* launch on the capturing stream like any other kernel).
+
+Same kernels in the same order on the same data: a replay returns what the eager call returns (checked once, right after the
+capture, on the capture batch; a mismatch or any capture error switches the graph off for the process and the eager path runs).
+Outputs are STATIC tensors, overwritten by the next replay: the callers consume the features inside the step (rcnn.forward /
+rcnn.inference do).  Not used under bf16 autocast (cfg-5), on CPU, or in Mode S (gradient hooks fire inside the backward)."""
+import torch
+import torch.nn as nn
+
+ENABLED = True            # module switch (bench.py --no-graphs, parity tests)
+MAX_SHAPES = 2            # graphs kept per mode (each holds its own activation pool)
+_FEATS = ("p2", "p3", "p4", "p5", "p6")
+
+
+class _TupleBackbone(nn.Module):
+    def __init__(self, backbone):
+        super().__init__()
+        self.backbone = backbone
+
+    def forward(self, x):
+        f = self.backbone(x)
+        return tuple(f[k] for k in _FEATS)
+
+
+class GraphedBackbone:
+    """Per-model cache of captured graphs; ``__call__`` returns the feature dict or None when the eager path has to run."""
+
+    def __init__(self, backbone):
+        self.backbone = backbone
+        self.eval_graphs = {}          # shape -> (graph, static input, static outputs)
+        self.train_graphs = {}         # shape -> graphed callable
+        self.broken = False
+        self.stats = dict(eval_captures=0, train_captures=0, eval_replays=0, train_replays=0, disabled=None)
+
+    def __deepcopy__(self, memo):
+        return None                    # graphs are not copied: the copy of the model captures its own (rcnn._backbone)
+
+    def _give_up(self, why):
+        self.broken = True
+        self.stats["disabled"] = why
+        self.eval_graphs.clear()
+        self.train_graphs.clear()
+
+    def usable(self, x):
+        return (ENABLED and not self.broken and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled())
+
+    def __call__(self, x):
+        if not self.usable(x):
+            return None
+        try:
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.backbone.parameters()):
+                return self._train(x)
+            return self._eval(x)
+        except Exception as e:          # capture problems must never take the step down: eager from here on
+            self._give_up("%s: %s" % (type(e).__name__, e))
+            return None
+
+    # ------------------------------------------------------------------------------------------------------------ eval
+    def _eval(self, x):
+        from . import backbone as bb
+        key = tuple(x.shape)
+        ent = self.eval_graphs.get(key)
+        if ent is None:
+            if len(self.eval_graphs) >= MAX_SHAPES:
+                return None
+            with torch.no_grad():
+                ref = self.backbone(x)                                   # eager: builds every lazily cached constant
+                static_in = x.clone()
+                adapted = [m for m in self.backbone.modules() if isinstance(m, bb.ConvNorm) and m.norm is not None and m.weight.requires_grad]
+                side = torch.cuda.Stream(device=x.device)
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):                                   # warm-up on the capture stream (allocator, MIOpen handles)
+                        self.backbone(static_in)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize(x.device)
+                for m in adapted:
+                    m._wfold = None                                      # the folds of the adapted filters are captured with the graph
+                g = torch.cuda.CUDAGraph()
+                bb._CAPTURING = True
+                try:
+                    with torch.cuda.graph(g):
+                        out = self.backbone(static_in)
+                finally:
+                    bb._CAPTURING = False
+                g.replay()
+                torch.cuda.synchronize(x.device)
+                for k in _FEATS:
+                    if not float((out[k] - ref[k]).abs().max()) <= 1e-5 * max(1.0, float(ref[k].abs().max())):
+                        self._give_up("eval replay differs from the eager forward on %s" % k)
+                        return None
+            ent = self.eval_graphs[key] = (g, static_in, out)
+            self.stats["eval_captures"] += 1
+        g, static_in, out = ent
+        static_in.copy_(x)
+        g.replay()
+        self.stats["eval_replays"] += 1
+        return out
+
+    # ------------------------------------------------------------------------------------------------------------ TTT
+    def _train(self, x):
+        key = tuple(x.shape)
+        fn = self.train_graphs.get(key)
+        if fn is None:
+            if len(self.train_graphs) >= MAX_SHAPES:
+                return None
+            wrapped = _TupleBackbone(self.backbone)
+            wrapped.train(self.backbone.training)
+            with torch.no_grad():
+                self.backbone(x)                                         # lazily cached constants exist before the capture
+            grads = [p.grad for p in self.backbone.parameters()]         # the warm-up passes of the capture must not leave gradients
+            fn = torch.cuda.make_graphed_callables(wrapped, (x.clone(),), num_warmup_iters=2)
+            for p, g in zip(self.backbone.parameters(), grads):
+                p.grad = g
+            self.train_graphs[key] = fn
+            self.stats["train_captures"] += 1
+        outs = fn(x)
+        self.stats["train_replays"] += 1
+        return dict(zip(_FEATS, outs))

@@ -44,7 +44,7 @@ class DAobjTwoStagePseudoLabGeneralizedRCNN(nn.Module):
         self.multi_matching_unsup = MGM3_unsup(self.roi_heads.num_classes, univ_size)
         self.sync_universe = False      # Mode S (engine/sync_universe.py): all ranks adapt on one gathered multi-graph
         self.teacher_forced = False     # synthetic runs: replace detections by the jittered GT boxes the inputs carry
-        self.autocast_backbone = False  # cfg-5: bf16 autocast for the backbone only
+        self.autocast_backbone = False  # cfg-5: bf16 autocast for the backbone only (True / "all"), or up to a stage ("res2" .. "res5": the rest fp32)
 
     @property
     def device(self):
@@ -61,10 +61,27 @@ class DAobjTwoStagePseudoLabGeneralizedRCNN(nn.Module):
         return ImageList.from_tensors(images, self.backbone.size_divisibility)
 
     def _backbone(self, x):
-        if self.autocast_backbone:
+        mode = self.autocast_backbone
+        if isinstance(mode, str) and mode != "all":
+            # bf16 up to the named ResNet stage, fp32 behind it (a precision island: the FPN and the late stages decide the scores)
+            self.backbone.bottom_up.autocast_upto = mode
+            try:
+                return self.backbone(x)
+            finally:
+                self.backbone.bottom_up.autocast_upto = None
+        if mode:
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 f = self.backbone(x)
             return {k: v.float() for k, v in f.items()}
+        if x.is_cuda and not self.sync_universe:
+            # fixed-shape fp32 batches: the backbone's launch sequence is replayed from a hipGraph (modeling/graphed.py)
+            g = self.__dict__.get("_graphed")
+            if g is None:
+                from .graphed import GraphedBackbone
+                g = self.__dict__["_graphed"] = GraphedBackbone(self.backbone)
+            f = g(x)
+            if f is not None:
+                return f
         return self.backbone(x)
 
     def forward(self, batched_inputs, branch=None, given_proposals=None, val_mode=False):
