@@ -572,7 +572,7 @@ def gpu_main(args, rank, world, local):
     tf = bool(args.teacher_forced)
     main = timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, world, device, tf)
     eager_probe = None
-    if _graphed.ENABLED and model.__dict__.get("_graphed") is not None and model.__dict__["_graphed"].stats["train_replays"] > 0:
+    if _graphed.ENABLED and model.__dict__.get("_graphed") is not None and model.__dict__["_graphed"].stats["eval_replays"] + model.__dict__["_graphed"].stats["train_replays"] > 0:
         # Inside a graph replay no HIP event can be placed around a single kernel from here.  The per-kernel durations of the
         # rooflines therefore come from a SECOND timed pass over the same K batches with the backbone launched eagerly (live HIP
         # events on the launch stream, as before); its images/s is the graphs-off A/B figure of the line.
@@ -746,7 +746,7 @@ def gpu_main(args, rank, world, local):
         "tta_steps_taken": main["steps_taken"],
         "eager_pass": (None if eager_probe is None else {"value": images / eager_probe["elapsed"], "unit": "images/s", "dice": eager_probe["dice"],
                                                           "note": "same K batches, backbone launched kernel by kernel (graphs off): the pass the per-kernel HIP-event durations of `roofline` come from"}),
-        "backbone_launches": ("hipGraph replay of the backbone's forward (Dice pass) and forward + backward (TTA step): %s (A/B: --no-graphs)" % (model.__dict__["_graphed"].stats,)
+        "backbone_launches": ("hipGraph replay of the backbone's no-grad forward (Dice pass); the TTA step's forward + backward eagerly (modeling/graphed.py): %s (A/B: --no-graphs)" % (model.__dict__["_graphed"].stats,)
                               if model.__dict__.get("_graphed") is not None else "eager, kernel by kernel (--no-graphs)"),
         "vendor_convolutions": ("MIOpen immediate mode, solvers from the find-db shipped in ttdg-mgm_amd/miopen_db (tools/tune_miopen.sh; A/B: --no-miopen-db)"
                                 if os.path.basename(os.environ.get("MIOPEN_USER_DB_PATH", "").rstrip("/")).startswith(("miopen_db", "ttdg_miopen_db")) and not args.miopen_search else

@@ -589,63 +589,79 @@ CFG5_DICE_TOL = 3e-2        # every box fits its own polyp checkpoint (the fit i
 
 
 def test_graphed_backbone_equals_the_eager_backbone(trained):
-    """[r4] modeling/graphed.py: fixed-shape fp32 batches replay the backbone from hipGraphs (one for the no-grad forward of the
-    Dice pass, a forward + backward pair for the TTA step).  Same kernels in the same order: (1) eval-mode features of a replay
-    equal the eager forward bit for bit, on the capture batch AND on another batch, BEFORE and AFTER an adaptation step moved the
-    weights (the folds of the adapted filters are inside the graph); (2) a TTA step through the graphs gives the eager step's loss
-    and gradients (the vendor's weight-gradient kernels are not bit-reproducible run to run: gradients within 1e-4 of the largest
-    entry per tensor, the loss within 1e-5 relative); (3) both graphs were actually captured and replayed."""
+    """[r4] modeling/graphed.py: the Dice pass replays the backbone's no-grad forward from a hipGraph (fixed-shape fp32 batches).
+    Same kernels in the same order: the feature maps of a replay against the eager forward - on the capture batch and on others,
+    BEFORE and AFTER optimizer steps moved the weights (the FrozenBN folds of the adapted filters are inside the graph, so a
+    replay must see the live parameters), in eval and in train mode - within 1e-5 of the largest entry (the vendor's kernels
+    carry no bit-reproducibility promise; the count of bit-identical maps is printed).  The TTA step's forward + backward stays
+    eager (graphed.TRAIN_GRAPHS = False, reason in the module): asserted too, since a stale gradient graph is how this went
+    wrong during development."""
     import copy
     from ttdg_mgm_amd.engine import BaselineTrainer
     from ttdg_mgm_amd.modeling import graphed
     cfg, cpu, gpu, batches = trained
-    assert graphed.ENABLED
+    assert graphed.ENABLED and not graphed.TRAIN_GRAPHS
     mg, me = copy.deepcopy(gpu), copy.deepcopy(gpu)
-    for m in (mg, me):
-        m.teacher_forced = True
-        m.multi_matching_unsup.eval()
+    identical = []
 
-    def feats(m, batch, use_graph):
+    def same(fg, fe, tol=1e-5):
+        for k in fe:
+            identical.append(bool(torch.equal(fg[k], fe[k])))
+            assert float((fg[k] - fe[k]).abs().max()) <= tol * max(1.0, float(fe[k].abs().max())), (k, float((fg[k] - fe[k]).abs().max()))
+
+    def feats(m, batch, use_graph, train=False):
         graphed.ENABLED = use_graph
         try:
-            m.eval()
+            m.train(train)
             with torch.no_grad():
                 f = m._backbone(m.preprocess_image(batch).tensor)
             return {k: v.clone() for k, v in f.items()}
         finally:
             graphed.ENABLED = True
 
-    def step(m, batch, use_graph, opt):
-        graphed.ENABLED = use_graph
-        try:
-            m.train()
-            loss, _, _, _ = m(batch, branch="TTT")
-            opt.zero_grad(set_to_none=True)
-            loss.backward()
-            g = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
-            opt.step()
-            return float(loss.detach()), g
-        finally:
-            graphed.ENABLED = True
-
-    for b in (batches[0], batches[1]):                                   # (1) before any step
-        fg, fe = feats(mg, b, True), feats(me, b, False)
-        for k in fe:
-            assert torch.equal(fg[k], fe[k]), k
-    og_, oe = BaselineTrainer.build_optimizer(cfg, mg), BaselineTrainer.build_optimizer(cfg, me)
-    for b in (batches[2], batches[3]):                                   # (2) two adaptation steps
-        lg, gg = step(mg, b, True, og_)
-        le, ge = step(me, b, False, oe)
-        assert abs(lg - le) <= 1e-5 * max(1.0, abs(le)), (lg, le)
-        assert set(gg) == set(ge)
-        for n in ge:
-            assert float((gg[n] - ge[n]).abs().max()) <= 1e-4 * max(float(ge[n].abs().max()), 1e-12) + 1e-9, n
-    # (1) again: the graphs re-fold from the LIVE parameters.  Same weights on both sides for an exact statement.
-    me.load_state_dict(mg.state_dict())
+    for b in (batches[0], batches[1]):
+        same(feats(mg, b, True), feats(me, b, False))
+    mg.teacher_forced = me.teacher_forced = True
+    og_ = BaselineTrainer.build_optimizer(cfg, mg)
+    mg.train()
+    for b in (batches[2], batches[3]):                                   # two real TTA steps on the graphed model (eager forward + backward)
+        loss = BaselineTrainer.tta_step(mg, og_, b)
+        assert loss is not None and torch.isfinite(loss)
+    me.load_state_dict(mg.state_dict())                                  # same (moved) weights on both sides
     for b in (batches[0], batches[4]):
-        fg, fe = feats(mg, b, True), feats(me, b, False)
-        for k in fe:
-            assert torch.equal(fg[k], fe[k]), k
+        same(feats(mg, b, True), feats(me, b, False))
+        same(feats(mg, b, True, train=True), feats(me, b, False, train=True))
     st = mg.__dict__["_graphed"].stats
-    print("graphed backbone:", st)
-    assert st["disabled"] is None and st["eval_captures"] == 1 and st["train_captures"] == 1 and st["eval_replays"] >= 4 and st["train_replays"] >= 2, st
+    print("graphed backbone:", st, "| feature maps bit-identical to the eager forward: %d of %d" % (sum(identical), len(identical)))
+    assert st["disabled"] is None and st["eval_captures"] == 1 and st["train_captures"] == 0 and st["eval_replays"] >= 6, st
+
+
+def test_free_running_drift_stays_inside_the_cpu_ports_own_spread(trained):
+    """the Dice after K continual FREE-RUNNING adaptation steps (own detections, own solve, weights and momentum
+    carried over) against the CPU port of the reference formulation - with a denominator.  The last Sinkhorn stage of the solver
+    is rounding-chaotic in this regime, so neither implementation defines the trajectory to 1e-3: the CPU port itself,
+    run with 32 / 64 threads and under two 1e-7-relative perturbations of the weights, spreads 0.36-0.38 Dice points after 8 steps
+    and 1.25 after 32 (profiles/r04_drift_denominator_*.json, three streams) - and every device run of those studies lies INSIDE
+    the CPU port's min-max.  This test is the short form that fits the suite (tools/drift_denominator.py is the long one):
+    K = 2 steps on one stream, the CPU port with 32 and with 64 threads, three device runs (plain, plain again, 1e-7-perturbed).
+    At this horizon the trajectories have not separated yet, so BASELINE.json's own bar applies: every device Dice / E / S within
+    1e-3 relative of every CPU-port value."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import drift_denominator as dd
+    import synth_checkpoint as sc
+    cfg, cpu, gpu, batches = trained
+    dev = torch.device("cuda:0")
+    path, _ = sc.get_or_make(cfg, dev, log=lambda m: None)
+    rows = dd.study(2, 1, cfg, dev, path, variants=dd.VARIANTS[:2], device_variants=[None, None, (1e-7, 21)])
+    r = rows[0]
+    print("drift, 2 free-running steps: cpu port", {k: {n: round(v[k], 4) for n, v in r["cpu_port"].items()} for k in dd.KEYS[:1]},
+          "device", [round(d[dd.KEYS[0]], 4) for d in r["device"]])
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "drift_2steps.json"), "w") as f:
+        json.dump(r, f, indent=1, default=str)
+    for d in r["device"]:
+        assert d["kept"] >= 4
+        for c in r["cpu_port"].values():
+            for k in dd.KEYS:
+                assert abs(d[k] - c[k]) <= 1e-3 * abs(c[k]), (k, d[k], c[k])

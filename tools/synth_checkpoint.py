@@ -531,7 +531,12 @@ def make(cfg, device, steps=600, tta_steps=16, n_images=64, size=512, lr=0.01, s
                         roi_grad=roi_grad, u0_weight=u0_weight, u0_temp=u0_temp, feat_reg=feat_reg, ttt_weight=ttt_weight, ttt_from=ttt_from)
     if u0_ridge > 0:
         fit_universe_readout(model, batches, device, u0_ridge, log=log)
-    stats = warm_tta(model, cfg, batches, tta_steps, log=log) if tta_steps else []
+    from ttdg_mgm_amd.modeling import graphed as _graphed
+    keep, _graphed.ENABLED = _graphed.ENABLED, False          # the fit is infrastructure: every step eager (and no graph pool left behind)
+    try:
+        stats = warm_tta(model, cfg, batches, tta_steps, log=log) if tta_steps else []
+    finally:
+        _graphed.ENABLED = keep
     torch.cuda.synchronize()
     report = dict(stage1_steps=steps, stage2_tta_steps=tta_steps, source_images=n_images, seconds=time.perf_counter() - t0,
                   stage1_last=hist[-1] if hist else None, stage2_last=stats[-1] if stats else None)

@@ -18,6 +18,11 @@ import torch
 import torch.nn as nn
 
 ENABLED = True            # module switch (bench.py --no-graphs, parity tests)
+TRAIN_GRAPHS = False      # the forward + backward pair of the TTA step: OFF.  Captured with torch.cuda.make_graphed_callables it is exact
+                          # on the stand-alone FPN at 2 x 3 x 256 x 256 (every gradient equal to the eager one), but at the bench's
+                          # 4 x 3 x 800 x 800 the replayed backward returned FPN bias gradients that did not depend on the cotangent
+                          # (stale values of the capture pass, 6e19 in one of them) and res4 / res5 filter gradients 1-3 % off: some
+                          # vendor kernel of the large shapes is not replayed.  Not understood, therefore not used (round 4).
 MAX_SHAPES = 2            # graphs kept per mode (each holds its own activation pool)
 _FEATS = ("p2", "p3", "p4", "p5", "p6")
 
@@ -59,7 +64,7 @@ class GraphedBackbone:
             return None
         try:
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.backbone.parameters()):
-                return self._train(x)
+                return self._train(x) if TRAIN_GRAPHS else None
             return self._eval(x)
         except Exception as e:          # capture problems must never take the step down: eager from here on
             self._give_up("%s: %s" % (type(e).__name__, e))
