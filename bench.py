@@ -78,7 +78,7 @@ def parse(argv=None):
                                                                   "1 = direct kernel, XCD-sliced, 0 = direct, flat (round 1)")
     ap.add_argument("--roi-xcd-chunks", action="store_true", help="A/B: channels-last ROIPooler with one contiguous eighth of the ROI list per XCD instead of ROI r on workgroup r")
     ap.add_argument("--roi-chunk", type=int, default=0, help="A/B: bins the channels-last ROIPooler stages per output flush: 49 (round 2), 25 (default) or 13")
-    ap.add_argument("--no-graphs", action="store_true", help="A/B: the backbone eagerly, kernel by kernel (default: hipGraph replay of its forward / backward, modeling/graphed.py)")
+    ap.add_argument("--graphs", action="store_true", help="A/B: hipGraph replay of the backbone's no-grad forward in the Dice pass (modeling/graphed.py; default: eager - measured equal)")
     ap.add_argument("--no-miopen-db", action="store_true", help="A/B: ignore the tuned MIOpen find-db shipped in ttdg-mgm_amd/miopen_db (MIOpen's heuristic picks the solvers)")
     ap.add_argument("--miopen-search", action="store_true", help="tuning run: torch.backends.cudnn.benchmark = True, i.e. MIOpen times its solvers for every "
                     "convolution shape it meets (minutes) and records the winners in its user find-db (MIOPEN_USER_DB_PATH)")
@@ -540,7 +540,7 @@ def gpu_main(args, rank, world, local):
     from ttdg_mgm_amd import ops as _ops
     from ttdg_mgm_amd.modeling import detector as _det
     from ttdg_mgm_amd.modeling import graphed as _graphed
-    _graphed.ENABLED = not args.no_graphs
+    _graphed.ENABLED = bool(args.graphs)
     assert _det._backend is _ops, "the GPU legs must run on the HIP operators (detector._backend was re-pointed)"
     if args.gagm_threads or args.roi_align_mode != 3:
         from ttdg_mgm_amd import _lib
@@ -746,8 +746,8 @@ def gpu_main(args, rank, world, local):
         "tta_steps_taken": main["steps_taken"],
         "eager_pass": (None if eager_probe is None else {"value": images / eager_probe["elapsed"], "unit": "images/s", "dice": eager_probe["dice"],
                                                           "note": "same K batches, backbone launched kernel by kernel (graphs off): the pass the per-kernel HIP-event durations of `roofline` come from"}),
-        "backbone_launches": ("hipGraph replay of the backbone's no-grad forward (Dice pass); the TTA step's forward + backward eagerly (modeling/graphed.py): %s (A/B: --no-graphs)" % (model.__dict__["_graphed"].stats,)
-                              if model.__dict__.get("_graphed") is not None else "eager, kernel by kernel (--no-graphs)"),
+        "backbone_launches": ("hipGraph replay of the backbone's no-grad forward (Dice pass); the TTA step's forward + backward eagerly (modeling/graphed.py): %s (A/B: --graphs)" % (model.__dict__["_graphed"].stats,)
+                              if model.__dict__.get("_graphed") is not None else "eager, kernel by kernel (A/B: --graphs replays the Dice pass's backbone forward from a hipGraph)"),
         "vendor_convolutions": ("MIOpen immediate mode, solvers from the find-db shipped in ttdg-mgm_amd/miopen_db (tools/tune_miopen.sh; A/B: --no-miopen-db)"
                                 if os.path.basename(os.environ.get("MIOPEN_USER_DB_PATH", "").rstrip("/")).startswith(("miopen_db", "ttdg_miopen_db")) and not args.miopen_search else
                                 "MIOpen timing its solvers in this process (--miopen-search)" if args.miopen_search else "MIOpen immediate mode, heuristic solver choice"),
