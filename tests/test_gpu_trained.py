@@ -583,9 +583,15 @@ def test_cfg5_own_checkpoint_bf16_backbone_vs_fp32(trained):
         json.dump(dict(checkpoint=rep, f32=out["f32"], bf16=out["bf16"], relative_difference=rel, tolerance=CFG5_DICE_TOL), f, indent=1, default=str)
 
 
-CFG5_DICE_TOL = 3e-2        # every box fits its own polyp checkpoint (the fit is not bit-reproducible), so the figure has a spread: relative Dice
-                            # difference 5.1e-4 / 6.7e-3 (16 images, ~20 kept masks), then < 1e-2 on three boxes and 1.7e-2 on one (48 images,
-                            # 68 kept masks: one or two masks crossing the 0.9 score threshold move the mean by a point); E and S stay < 1e-2
+CFG5_DICE_TOL = 2e-2        # every box fits its own polyp checkpoint (the fit is not bit-reproducible), so the figure has a spread.  Twelve fits
+                            # over rounds 3 and 4: relative Dice difference of the bf16-backbone run 1.6e-4 ... 1.7e-2 (48 images, 70-80 kept masks).
+                            # Round 4 looked for an fp32 island that brings it under 1e-3 (tools/cfg5_island.py, profiles/r04_cfg5_islands*.json,
+                            # six fits): bf16 up to res5 / res4 / res3 / res2 with everything behind in fp32 gives 2.1e-5 ... 1.2e-2 - no smaller
+                            # than whole-backbone bf16 (1.6e-4 ... 1.0e-2), and not ordered by island size - while the fp32 path itself is exact
+                            # under 1e-7 weight perturbations (0 ... 7e-7).  The difference is not accumulated precision loss: the kept sets
+                            # differ (71 vs 74-76 masks: detections crossing the 0.9 score threshold), and one mask of 75 moves the mean by up
+                            # to 1.3 points.  BASELINE.json's 1e-3 is therefore NOT met by any bf16 placement on this stream; the gate is the
+                            # measured envelope, E and S stay < 1e-2
 
 
 def test_graphed_backbone_equals_the_eager_backbone(trained):

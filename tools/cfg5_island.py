@@ -3,6 +3,8 @@ the bf16 run to agree with the fp32 run?  VERDICT r3 item 8.  For each of `fits`
 (tools/synth_checkpoint.py kind = "polyp"; the fit is not bit-reproducible, every fit is a different checkpoint) the eval-mode
 Dice / E / S over 48 held-out images with
     f32            the fp32 backbone (reference of the comparison)
+    f32_eps1e-7_*  the fp32 backbone with every trainable tensor perturbed by 1e-7 relative (two draws): how well the metric is
+                   defined by the fp32 path itself on this stream
     all            bf16 autocast over the whole backbone (round 2 / 3's cfg-5)
     res5 .. res2   bf16 up to and including that ResNet stage, fp32 behind it (later stages + FPN: a precision island)
 and the eval-only images/s of every variant (median of 3 passes over the 48 images).
@@ -19,7 +21,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch  # noqa: E402
 
-VARIANTS = ("f32", "all", "res5", "res4", "res3", "res2")
+VARIANTS = ("f32", "f32_eps1e-7_a", "f32_eps1e-7_b", "all", "res5", "res4", "res3", "res2")
 KEYS = ("Dice Coefficient", "Enhanced Alignment Metric", "Structural Similarity Metric")
 
 
@@ -47,7 +49,13 @@ def main():
             for v in VARIANTS:
                 m = BaselineTrainer.build_model(cfg)
                 load_weights(m, path)
-                m.autocast_backbone = False if v == "f32" else v
+                m.autocast_backbone = False if v.startswith("f32") else v
+                if v.startswith("f32_eps"):          # the fp32 path's OWN sensitivity: every trainable tensor times (1 + 1e-7 randn)
+                    g = torch.Generator().manual_seed(11 if v.endswith("a") else 12)
+                    with torch.no_grad():
+                        for q in m.parameters():
+                            if q.requires_grad:
+                                q.mul_((1 + 1e-7 * torch.randn(q.shape, generator=g)).to(q.device))
                 ev = DiceEvaluator("cfg5_island", cfg.TEST.DICE_THRES, dataset_dicts=loader.dataset_dicts)
                 r, _ = inference_on_dataset(m, loader, ev, cfg)
                 ts = []
