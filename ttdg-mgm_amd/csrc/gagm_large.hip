@@ -183,19 +183,30 @@ __global__ __launch_bounds__(256) void gagm_large_init_kernel(const float* __res
   }
 }
 
+// [r4] every load is UNCONDITIONAL (clamped address, the zero selected after the wait): a load under a condition is waited for at
+// the join, which serialised the 32 loads of a chunk; out-of-range rows / columns read a valid neighbour and are zeroed
 __device__ __forceinline__ void gl_load_chunk(const float* __restrict__ Asrc, int lda, int nrows, const float* __restrict__ Ub,
                                               int k0, int kend, int li, int kh, float (&ra)[16], float (&rb)[16]) {
-  const int k = k0 + li;
+  const int kl = max(kend - 1, 0), k = k0 + li, kc = min(k, kl);
+  const int rmax = max(nrows - 1, 0);
 #pragma unroll
   for (int j = 0; j < 16; ++j) {        // 32 x 32 tile of A, coalesced 128-byte rows
     const int row = kh + 2 * j;
-    ra[j] = (row < nrows && k < kend) ? Asrc[(size_t)row * lda + k] : 0.f;
+    ra[j] = Asrc[(size_t)min(row, rmax) * lda + kc];
   }
 #pragma unroll
   for (int s = 0; s < 16; ++s) {        // MFMA B operand: U[k][col], two k per step
     const int kk = k0 + 2 * s + kh;
-    rb[s] = (kk < kend) ? Ub[(size_t)kk * NU + li] : 0.f;
+    rb[s] = Ub[(size_t)min(kk, kl) * NU + li];
   }
+}
+// the zeros of a chunk, applied where its registers are consumed (not behind the loads: that would wait for them at once)
+__device__ __forceinline__ void gl_mask_chunk(int nrows, int k0, int kend, int li, int kh, float (&ra)[16], float (&rb)[16]) {
+  const int k = k0 + li;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) ra[j] = (kh + 2 * j < nrows && k < kend) ? ra[j] : 0.f;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) rb[s] = (k0 + 2 * s + kh < kend) ? rb[s] : 0.f;
 }
 
 // One (row tile, K slice) item of the mul phase on a sub-group of 256 threads (4 wavefronts).  `sub` = index of the sub-group
@@ -235,14 +246,15 @@ __device__ __forceinline__ void gl_mul_item(const float* __restrict__ Apack, con
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   float ra[16], rb[16], cb[16];
   int k0 = kbeg + wave * 32;
-  if (k0 < kend) gl_load_chunk(Asrc, lda, nrows, Ub, k0, kend, li, kh, ra, rb);
+  gl_load_chunk(Asrc, lda, nrows, Ub, k0, kend, li, kh, ra, rb);
   for (; k0 < kend; k0 += 128) {
+    gl_mask_chunk(nrows, k0, kend, li, kh, ra, rb);
 #pragma unroll
     for (int j = 0; j < 16; ++j) sa[(kh + 2 * j) * 33 + li] = ra[j];
 #pragma unroll
     for (int s = 0; s < 16; ++s) cb[s] = rb[s];
     wave_sync();
-    if (k0 + 128 < kend) gl_load_chunk(Asrc, lda, nrows, Ub, k0 + 128, kend, li, kh, ra, rb);   // in flight under the MFMAs
+    gl_load_chunk(Asrc, lda, nrows, Ub, k0 + 128, kend, li, kh, ra, rb);   // in flight under the MFMAs (past the end: clamped, unused)
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[li * 33 + 2 * s + kh], cb[s], acc, 0, 0, 0);
     wave_sync();
@@ -251,6 +263,12 @@ __device__ __forceinline__ void gl_mul_item(const float* __restrict__ Apack, con
 #pragma unroll
   for (int r = 0; r < 16; ++r) s_a[wave * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * kh) * NU + li] = acc[r];
   __syncthreads();
+  float ut[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {            // (A slice) the tile's rows of U for its share of S: four loads in flight, not four round trips
+    const int e = tid + 256 * j, row = e >> 5, col = e & 31;
+    ut[j] = U[(size_t)min(row0 + row, M - 1) * NU + col];
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int e = tid + 256 * j, row = e >> 5, col = e & 31;
@@ -261,7 +279,7 @@ __device__ __forceinline__ void gl_mul_item(const float* __restrict__ Apack, con
     } else {
       if (ok) w.B[(size_t)(row0 + row) * NU + col] = v;
       s_bt[row * 33 + col] = ok ? v : 0.f;
-      s_ut[row * 33 + col] = ok ? U[(size_t)(row0 + row) * NU + col] : 0.f;
+      s_ut[row * 33 + col] = ok ? ut[j] : 0.f;
     }
   }
   __syncthreads();
@@ -657,14 +675,16 @@ __device__ __forceinline__ void gl_project_graph(const ttdg_graphs_t& gr, const 
   constexpr int CHUNK = 2 * PW * 8;          // rows per pass of the V loop (256): a wavefront takes two rows at a time
   float bv[8], wu[8];
   // operands of the first V chunk: issued before the S reduction so that both sets of L2 round trips overlap
-#define GL_LOAD_V_OPERANDS(base)                                                                        \
+#define GL_LOAD_V_OPERANDS(base)     /* unconditional loads (clamped row / plane), zeros selected afterwards */ \
   _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                       \
     const int i = (base) + j * 2 * PW + wave * 2 + kh;                                            \
     const bool ok = i < n;                                                                               \
     const size_t idx = (size_t)(o + (ok ? i : 0)) * NU + li;                                             \
-    bv[j] = ok ? w.B[idx] : 0.f;                                                                         \
+    const float b0 = w.B[idx];                                                                           \
     float p[GL_MAXKS];                                                                                   \
-    _Pragma("unroll") for (int z = 0; z < GL_MAXKS; ++z) p[z] = (ok && z < w.ks) ? w.WUp[(size_t)z * MU + idx] : 0.f; \
+    _Pragma("unroll") for (int z = 0; z < GL_MAXKS; ++z) p[z] = w.WUp[(size_t)min(z, w.ks - 1) * MU + idx]; \
+    _Pragma("unroll") for (int z = 0; z < GL_MAXKS; ++z) p[z] = (ok && z < w.ks) ? p[z] : 0.f;           \
+    bv[j] = ok ? b0 : 0.f;                                                                               \
     wu[j] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));                           \
   }
   GL_LOAD_V_OPERANDS(0)
@@ -968,7 +988,10 @@ int ttdg_gagm_large_solve(const float* Apack, const float* W, const float* U0, t
   const int r = cmax < NU ? cmax : NU, c = cmax < NU ? NU : cmax;
   // [projector scratch: GL_VL_OFF floats][V_g tile: n x 33][LAP scratch]; the generic Sinkhorn of a < 32-node graph in
   // a large batch (rows = nodes) needs 2*32+1 + 31*33 floats and runs after the tile was consumed (it re-reads V from L2)
-  const size_t bytes = (size_t)(GL_VL_OFF + ((cmax * 33 + 3) & ~3)) * sizeof(float) + lap_scratch_bytes(r, c) + 16;
+  size_t lapb = lap_scratch_bytes(r, c);
+  if (lap_cert_scratch_bytes(c) > lapb) lapb = lap_cert_scratch_bytes(c);
+  if (lap_block_scratch_bytes(c) > lapb) lapb = lap_block_scratch_bytes(c);
+  const size_t bytes = (size_t)(GL_VL_OFF + ((cmax * 33 + 3) & ~3)) * sizeof(float) + lapb + 16;
   TTDG_ALLOW_LDS(gagm_large_project_kernel<512>, bytes);
   TTDG_ALLOW_LDS(gagm_large_project_kernel<1024>, bytes);
   const int M = gr.off[gr.G];

@@ -296,28 +296,29 @@ __device__ __forceinline__ bool lap_certified_solve(int nc, const float* vl, con
 // Scipy-order LAP on the WHOLE workgroup (32 rows = universe slots, nc <= PT node columns, one column per thread): step for step
 // the algorithm of lap_wave_solve_regw - the same shortest-path scan, the same fp64 evaluation order ((minVal + c) - u_i) - v_j,
 // the same tie rule on scipy's `remaining` positions (some minimal column unassigned -> the LAST such position, else the FIRST
-// minimal position; the last position moves into the hole) - with the arg-min of a step taken over all wavefronts: a DPP minimum
-// per wavefront, three LDS meetings per step (minima; tie summary; the selected column).  One wavefront owning four columns per
-// lane spends ~2400 cycles per step in one dependent fp64 chain (measured: 1.25 M cycles for the 32 x 256 block of all-tied costs
-// that follows a collapsed Sinkhorn stage - 23 % of the cfg-3 solve); here a step is ~800.
+// minimal position; the last position moves into the hole) - with the arg-min of a step taken over all wavefronts in ONE LDS
+// meeting: every wavefront reduces its own columns (DPP minimum; among ITS minima the largest position of an unassigned one and
+// the smallest position, with the columns and the owner row behind them) and publishes that record; after the barrier every
+// thread combines the records of the wavefronts that hold the global minimum.  Records are double-buffered, so one barrier per
+// step is all.  One wavefront owning four columns per lane spends ~2400 cycles per step in one dependent fp64 chain (measured:
+// 1.25 M cycles for the 32 x 256 block of all-tied costs that follows a collapsed Sinkhorn stage - a quarter of the cfg-3 solve).
 struct LapBlockScratch {
   double* u;        // [32]
   double* spc;      // [nc]   (published for the dual update)
-  double* wmin;     // [16]
+  double* wmin;     // [2][16] per-wavefront minimum, two slots
   int* path;        // [nc]
   int* row4col;     // [nc]
   int* col4row;     // [32]
   int* SR;          // [32]
-  int* tie;         // [16][4]: count of minima, largest position of an unassigned minimum (-1: none), smallest position of a minimum
-  int* sel;         // [4]: selected column, its owner row, its position
+  int* rec;         // [2][16][8]: largest position of an unassigned minimum (-1: none), its column; smallest position of a minimum, its column, its owner row
 };
-__host__ __device__ inline size_t lap_block_scratch_bytes(int nc) { return (size_t)(32 + nc + 16) * 8 + (size_t)(2 * nc + 32 + 32 + 64 + 4) * 4; }
+__host__ __device__ inline size_t lap_block_scratch_bytes(int nc) { return (size_t)(32 + nc + 32) * 8 + (size_t)(2 * nc + 32 + 32 + 256) * 4; }
 __device__ inline LapBlockScratch lap_block_carve(void* base, int nc) {     // base 8-byte aligned
   LapBlockScratch s;
   double* d = (double*)base;
   s.u = d; s.spc = d + 32; s.wmin = s.spc + nc;
-  int* i = (int*)(s.wmin + 16);
-  s.path = i; s.row4col = i + nc; s.col4row = s.row4col + nc; s.SR = s.col4row + 32; s.tie = s.SR + 32; s.sel = s.tie + 64;
+  int* i = (int*)(s.wmin + 32);
+  s.path = i; s.row4col = i + nc; s.col4row = s.row4col + nc; s.SR = s.col4row + 32; s.rec = s.SR + 32;
   return s;
 }
 
@@ -332,6 +333,7 @@ __device__ __forceinline__ void lap_block_solve_exact(int nc, const float* vl, c
   int row4col = -1, path = -1;
   if (tid < 32) { s.u[tid] = 0.0; s.col4row[tid] = -1; }
   __syncthreads();
+  int slot = 0;
   for (int cur = 0; cur < 32; ++cur) {
     double minVal = 0.0;
     int nrem = nc, i = cur, sink = -1;
@@ -348,30 +350,47 @@ __device__ __forceinline__ void lap_block_solve_exact(int nc, const float* vl, c
         if (r < spc) { path = i; spc = r; }
       }
       const double wm = wave_min_f64_dpp(active ? spc : INFINITY);
-      if (lane == 0) s.wmin[wave] = wm;
-      __syncthreads();
-      double gmin = s.wmin[0];
-#pragma unroll
-      for (int w = 1; w < NW; ++w) gmin = fmin(gmin, s.wmin[w]);
-      const bool is_min = active && spc == gmin;
-      const bool un = is_min && row4col == -1;
       {
-        const unsigned long long mm = __ballot(is_min);
-        int mx = -1, mn = 0x7fffffff;
-        if (mm != 0ull) {          // wavefront-uniform
-          mx = wave_max_i32_dpp(un ? pos : -1);
-          mn = wave_min_i32_dpp(is_min ? pos : 0x7fffffff);
+        const bool lmin = active && spc == wm;
+        const bool lun = lmin && row4col == -1;
+        const unsigned long long mm = __ballot(lmin), mu = __ballot(lun);
+        int mx = -1, jmx = 0, mn = 0x7fffffff, jmn = 0, omn = -1;
+        if (mm != 0ull) {                               // wavefront-uniform
+          if ((mm & (mm - 1)) == 0ull) {                // one minimum in this wavefront: no reductions
+            const int l = __builtin_ctzll(mm);
+            mn = __builtin_amdgcn_readlane(pos, l); jmn = 64 * wave + l; omn = __builtin_amdgcn_readlane(row4col, l);
+            if (mu != 0ull) { mx = mn; jmx = jmn; }
+          } else {
+            mn = wave_min_i32_dpp(lmin ? pos : 0x7fffffff);
+            const int l = __builtin_ctzll(__ballot(lmin && pos == mn));
+            jmn = 64 * wave + l; omn = __builtin_amdgcn_readlane(row4col, l);
+            if (mu != 0ull) {
+              mx = wave_max_i32_dpp(lun ? pos : -1);
+              jmx = 64 * wave + __builtin_ctzll(__ballot(lun && pos == mx));
+            }
+          }
         }
-        if (lane == 0) { s.tie[4 * wave] = __builtin_popcountll(mm); s.tie[4 * wave + 1] = mx; s.tie[4 * wave + 2] = mn; }
+        if (lane == 0) {
+          s.wmin[slot * 16 + wave] = wm;
+          int* r = s.rec + (slot * 16 + wave) * 8;
+          r[0] = mx; r[1] = jmx; r[2] = mn; r[3] = jmn; r[4] = omn;
+        }
       }
       __syncthreads();
-      int mxu = -1, mnp = 0x7fffffff;
+      double gmin = s.wmin[slot * 16];
 #pragma unroll
-      for (int w = 0; w < NW; ++w) { mxu = max(mxu, s.tie[4 * w + 1]); mnp = min(mnp, s.tie[4 * w + 2]); }
+      for (int w = 1; w < NW; ++w) gmin = fmin(gmin, s.wmin[slot * 16 + w]);
+      int mxu = -1, jmxu = 0, mnp = 0x7fffffff, jmnp = 0, omnp = -1;
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+        if (s.wmin[slot * 16 + w] == gmin) {
+          const int* r = s.rec + (slot * 16 + w) * 8;
+          if (r[0] > mxu) { mxu = r[0]; jmxu = r[1]; }
+          if (r[2] < mnp) { mnp = r[2]; jmnp = r[3]; omnp = r[4]; }
+        }
+      slot ^= 1;
       const int selpos = mxu >= 0 ? mxu : mnp;          // (finite costs: at least one minimum exists)
-      if (active && pos == selpos) { s.sel[0] = j; s.sel[1] = row4col; }
-      __syncthreads();
-      const int jsel = s.sel[0], owner = s.sel[1];
+      const int jsel = mxu >= 0 ? jmxu : jmnp, owner = mxu >= 0 ? -1 : omnp;
       if (j == jsel) { SC = true; active = false; }
       else if (active && pos == nrem - 1) pos = selpos;
       --nrem;
