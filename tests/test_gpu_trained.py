@@ -338,15 +338,17 @@ def test_continual_tta_trajectory_matches_cpu_port(trained):
       the gate:   derived ONCE, one formula for every group and step, every term printed:
                       |theta_dev - theta_host|_max(g, k)  <=  TRAJ_FACTOR * E_g * sum_{j<=k} step_move_j(g)  +  (k + 1) * ulp_g
                   E_g         = what ONE float32 host step loses against the SAME step in float64 (same detections, same
-                                pseudo-labels), relative to the step's own movement - measured at step 0.  A layer's gradient
-                                inherits the relative error of its INPUT, i.e. of everything upstream of it in the forward pass
-                                (once the two sides' upstream parameters are e apart, so are the features the layer sees), so
-                                E_g = max(own, E of every group upstream): res3 own; res4 max(own, res3); res5 max(.., res4);
-                                FPN max(own, res3..res5); affinity max(own, FPN).  Round 3 applied this to the affinity layers
-                                only; on one box's checkpoint the FPN's own one-step figure came out at 9e-4 (6e-3 on others)
-                                while res3 - res5 were 2-3 % apart, and the FPN - whose distance grew from 0.09 % of its movement
-                                at step 1 to 0.7 % at step 7 as the stages below it drifted apart - missed a bound of 19 ulp by 2
-                                (profiles/r04_gpu_suite_box1_failed.txt).  The rule is now applied to every group.
+                                pseudo-labels), relative to the step's own movement - measured at step 0 - and the MAXIMUM of
+                                that figure over the five groups is used for every group: the adapted layers are one coupled
+                                system.  A layer's gradient inherits the relative error of its input (features computed by
+                                everything upstream: once the two sides' upstream parameters are e apart, so are the features)
+                                AND of the gradient handed back to it (back-propagated through everything downstream).  Round 3
+                                used each group's own figure (the affinity layers inheriting the FPN's); two fresh-box runs of
+                                round 4 showed what that misses (profiles/r04_gpu_suite_box1_failed.txt, ..box2_failed.txt): the
+                                one-step figure of a single group is a noisy draw (res3: 0.36 % on one box, 2.2 % on another;
+                                FPN 0.09 % / 0.6 %) while the groups' distances converge to a common 2-3.5 % of their movement
+                                within a few steps whichever group started out small - missed by 2 ulp of 19 (FPN, step 7) and
+                                by 3 % of the bound (res3, step 3).
                   step_move_j = the host's largest parameter change in step j.  With momentum a relative gradient error e in
                                 step j moves the parameters by e times what that gradient itself moves them over the following
                                 steps: errors add like the movements do, hence the SUM of per-step movements (not (k + 1) times
@@ -441,10 +443,8 @@ def test_continual_tta_trajectory_matches_cpu_port(trained):
     print("after %d continual steps: device %s (%d masks) host %s (%d masks)" % (K, rg, len(evg.dice_scores), rc, len(evc.dice_scores)))
     # ---- gates (the formula of the docstring; every term is in trajectory.json)
     worst = {}
-    upstream = dict(res3=("res3",), res4=("res3", "res4"), res5=("res3", "res4", "res5"), fpn=("res3", "res4", "res5", "fpn"),
-                    affinity=("res3", "res4", "res5", "fpn", "affinity"))
+    E = max(e_ref[h]["host32"] for h in names)           # one coupled system: the largest one-step figure, for every group
     for g in names:
-        E = max(e_ref[h]["host32"] for h in upstream.get(g, (g,)) if h in e_ref)
         assert e_ref[g]["device"] <= TRAJ_FACTOR * E + 1e-4, ("step 0 vs float64", g, e_ref[g], E)
         for row in rec:
             v = row["groups"][g]
