@@ -348,7 +348,9 @@ def test_continual_tta_trajectory_matches_cpu_port(trained):
                                 one-step figure of a single group is a noisy draw (res3: 0.36 % on one box, 2.2 % on another;
                                 FPN 0.09 % / 0.6 %) while the groups' distances converge to a common 2-3.5 % of their movement
                                 within a few steps whichever group started out small - missed by 2 ulp of 19 (FPN, step 7) and
-                                by 3 % of the bound (res3, step 3).
+                                by 3 % of the bound (res3, step 3).  The figure is the larger of the host's and the device's
+                                distance from the float64 step (|dev - host| <= |dev - truth| + |host - truth|; the device's own
+                                is first held to 4 x the host's).
                   step_move_j = the host's largest parameter change in step j.  With momentum a relative gradient error e in
                                 step j moves the parameters by e times what that gradient itself moves them over the following
                                 steps: errors add like the movements do, hence the SUM of per-step movements (not (k + 1) times
@@ -443,9 +445,13 @@ def test_continual_tta_trajectory_matches_cpu_port(trained):
     print("after %d continual steps: device %s (%d masks) host %s (%d masks)" % (K, rg, len(evg.dice_scores), rc, len(evc.dice_scores)))
     # ---- gates (the formula of the docstring; every term is in trajectory.json)
     worst = {}
-    E = max(e_ref[h]["host32"] for h in names)           # one coupled system: the largest one-step figure, for every group
+    E_host = max(e_ref[h]["host32"] for h in names)      # one coupled system: the largest one-step figure, for every group
+    # |device - host| <= |device - truth| + |host - truth|: both sides' one-step distances from the float64 step are draws of the
+    # same quantity (what fp32 arithmetic loses on this step), the larger one is the better estimate; the device's own figure is
+    # held to the HOST's first (next line), so a wrong device cannot buy itself a wider bound
+    E = max(E_host, max(e_ref[h]["device"] for h in names))
     for g in names:
-        assert e_ref[g]["device"] <= TRAJ_FACTOR * E + 1e-4, ("step 0 vs float64", g, e_ref[g], E)
+        assert e_ref[g]["device"] <= TRAJ_FACTOR * E_host + 1e-4, ("step 0 vs float64", g, e_ref[g], E_host)
         for row in rec:
             v = row["groups"][g]
             bound = TRAJ_FACTOR * E * v["sum_step_moves"] + (row["step"] + 1) * v["param_ulp"]
