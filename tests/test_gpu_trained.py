@@ -270,13 +270,17 @@ def test_trained_regime_solver_census(trained):
     assert sum(ndef[:3]) >= CENSUS_MIN_DEFINED_STATES, ndef
     # ---- where the final answer is not well defined: is the device exchangeable with the reference's own runs?  Rank of the
     # device's objective / loss among the eight reference answers of the same batch, summed over the batches (Wilcoxon-type;
-    # |z| <= 3.5 is a < 5e-4 two-sided event for an exchangeable implementation): a solver whose answers are systematically worse
+    # |z| <= 3.5 would be a < 5e-4 two-sided event for an exchangeable implementation on INDEPENDENT batches; the gate below is 5, see there): a solver whose answers are systematically worse
     # (or whose loss is systematically off) than the reference's fails this, whatever the per-batch spread
     weak = [r for r in rec if not r["strong"]]
     z_obj = admission.rank_sum_z([r["objective_device"] for r in weak], [r["objective_oracle_runs"] for r in weak]) if weak else 0.0
     z_loss = admission.rank_sum_z([r["loss_device"] for r in weak], [r["loss_oracle_runs"] for r in weak]) if weak else 0.0
-    assert z_obj >= -3.5, z_obj                  # one-sided: never systematically below the reference's objective
-    assert abs(z_loss) <= 3.5, z_loss
+    # Gate at 5, not at the 3.5 a single independent sample would get: the 16 batches of one continual run share a weight trajectory
+    # (their ranks are positively correlated, the null variance of z is above 1), and every box fits its own checkpoint - recorded
+    # over six boxes of round 4: z objective -2.03 ... +0.73, z loss -0.53 ... +3.00 (profiles/r04_trained_census.json is the
+    # extreme one).  A solver that is systematically worse - every batch below the reference's worst answer - gives z = -6.2.
+    assert z_obj >= -5.0, z_obj                  # one-sided: never systematically below the reference's objective
+    assert abs(z_loss) <= 5.0, z_loss
     outside = sum(not admission.within_spread(r["objective_device"], r["objective_oracle_runs"]) for r in weak) + \
         sum(not admission.within_spread(r["loss_device"], r["loss_oracle_runs"]) for r in weak)
     summary = dict(steps=len(rec), strong=nstrong, weak=len(rec) - nstrong, first_three_stage_counts_identical=len(rec), first_four_stage_counts_identical=n4, device_equals_oracle32=sum(r["device_equals_oracle32"] for r in rec),
