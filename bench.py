@@ -747,7 +747,7 @@ def gpu_main(args, rank, world, local):
         "eager_pass": (None if eager_probe is None else {"value": images / eager_probe["elapsed"], "unit": "images/s", "dice": eager_probe["dice"],
                                                           "note": "same K batches, backbone launched kernel by kernel (graphs off): the pass the per-kernel HIP-event durations of `roofline` come from"}),
         "backbone_launches": ("hipGraph replay of the backbone's no-grad forward (Dice pass); the TTA step's forward + backward eagerly (modeling/graphed.py): %s (A/B: --graphs)" % (model.__dict__["_graphed"].stats,)
-                              if model.__dict__.get("_graphed") is not None else "eager, kernel by kernel (A/B: --graphs replays the Dice pass's backbone forward from a hipGraph)"),
+                              if model.__dict__.get("_graphed") is not None and model.__dict__["_graphed"].stats["eval_replays"] + model.__dict__["_graphed"].stats["train_replays"] > 0 else "eager, kernel by kernel (A/B: --graphs replays the Dice pass's backbone forward from a hipGraph)"),
         "vendor_convolutions": ("MIOpen immediate mode, solvers from the find-db shipped in ttdg-mgm_amd/miopen_db (tools/tune_miopen.sh; A/B: --no-miopen-db)"
                                 if os.path.basename(os.environ.get("MIOPEN_USER_DB_PATH", "").rstrip("/")).startswith(("miopen_db", "ttdg_miopen_db")) and not args.miopen_search else
                                 "MIOpen timing its solvers in this process (--miopen-search)" if args.miopen_search else "MIOpen immediate mode, heuristic solver choice"),
