@@ -73,12 +73,12 @@ class DAobjTwoStagePseudoLabGeneralizedRCNN(nn.Module):
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 f = self.backbone(x)
             return {k: v.float() for k, v in f.items()}
-        if x.is_cuda and not self.sync_universe:
-            # fixed-shape fp32 batches: the backbone's launch sequence is replayed from a hipGraph (modeling/graphed.py)
+        from . import graphed
+        if graphed.ENABLED and x.is_cuda and not self.sync_universe:
+            # A/B switch (off by default): fixed-shape fp32 batches replay the backbone's no-grad forward from a hipGraph
             g = self.__dict__.get("_graphed")
             if g is None:
-                from .graphed import GraphedBackbone
-                g = self.__dict__["_graphed"] = GraphedBackbone(self.backbone)
+                g = self.__dict__["_graphed"] = graphed.GraphedBackbone(self.backbone)
             f = g(x)
             if f is not None:
                 return f
