@@ -40,3 +40,77 @@ def test_tie_heavy_inputs(shape):
 def test_constant_matrix_is_identity():
     assert np.array_equal(olap.lap(np.ones((9, 9))), np.arange(9))
     assert np.array_equal(scipy_cols(np.ones((9, 9)), False), np.arange(9))
+
+
+# ---- the uniqueness certificate of csrc/lap_certified.h (restated in oracle/lap_certificate.py), checked by brute force ----------
+def _all_assignments(nr, nc):
+    import itertools
+    return itertools.permutations(range(nc), nr)
+
+
+def _brute(c):
+    nr, nc = c.shape
+    costs = sorted((float(sum(c[i, p[i]] for i in range(nr))), p) for p in _all_assignments(nr, nc))
+    return costs
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_lap_certificate_is_sound_by_brute_force(seed):
+    """The claim the multi-workgroup solver's Hungarian stage rests on (lap_certified.h): an ACYCLIC tight-entry graph proves that
+    the assignment is the UNIQUE optimum - then it is what scipy returns, whatever its tie rules.  Small instances (3 x 3 ... 4 x 6),
+    real-valued and tie-laden integer costs, duals from a shortest-path solver AND deliberately damaged duals / assignments:
+    whenever the certificate says yes, enumeration of all assignments must agree (strict gap to the runner-up), and it must agree
+    with scipy; on generic costs the certificate must say yes (otherwise it would be useless), on all-ties costs no."""
+    from oracle import lap_certificate as lc
+    rng = np.random.default_rng(100 + seed)
+    yes = no = yes_generic = 0
+    for trial in range(120):
+        nr = int(rng.integers(3, 5))
+        nc = int(rng.integers(nr, 7))
+        kind = trial % 4
+        if kind == 0:
+            c = rng.normal(size=(nr, nc))                                   # generic
+        elif kind == 1:
+            c = rng.integers(0, 3, size=(nr, nc)).astype(np.float64)        # ties everywhere
+        elif kind == 2:
+            c = np.repeat(rng.normal(size=(1, nc)), nr, axis=0) + 1e-9 * rng.integers(0, 2, size=(nr, nc))   # near-constant rows
+        else:
+            c = rng.normal(size=(nr, nc)).astype(np.float32).astype(np.float64)
+            c[:, -1] = c[:, 0]                                              # a duplicated column (a duplicated node)
+        m, u, v = lc.ssp_duals(c)
+        variants = [(m, v)]
+        v2 = v.copy(); v2[rng.integers(nc)] -= abs(rng.normal())          # a damaged dual
+        variants.append((m, v2))
+        m3 = m.copy(); m3[0], m3[1] = m3[1], m3[0]                          # a (usually) non-optimal assignment with the true duals
+        variants.append((m3, v))
+        ranked = _brute(c)
+        for mm, vv in variants:
+            if lc.certificate(c, mm, vv):
+                yes += 1
+                assert tuple(int(x) for x in mm) == ranked[0][1], "certified an assignment that is not optimal"
+                assert ranked[1][0] - ranked[0][0] > 0.0, "certified an optimum that is not unique"
+                r, cc = scipy.optimize.linear_sum_assignment(c)
+                assert np.array_equal(cc, mm)
+            else:
+                no += 1
+        if kind == 0:
+            assert lc.certificate(c, m, v), "generic costs with the solver's own duals must certify"
+            yes_generic += 1
+        if kind == 1 and ranked[1][0] == ranked[0][0]:
+            assert not lc.certificate(c, m, v)
+    assert yes >= 30 and no >= 60 and yes_generic == 30, (yes, no, yes_generic)
+
+
+def test_lap_certificate_on_solver_sized_blocks():
+    """32 x 64 ... 32 x 256 blocks of generic fp32 values (the shape of one graph's Hungarian-stage projection): the shortest-path
+    duals certify, and the certified assignment is scipy's; a block of identical columns (every node the same) never certifies."""
+    from oracle import lap_certificate as lc
+    rng = np.random.default_rng(7)
+    for nc in (64, 130, 256):
+        c = -rng.normal(size=(32, nc)).astype(np.float32).astype(np.float64)
+        m, u, v = lc.ssp_duals(c)
+        assert lc.certificate(c, m, v)
+        assert np.array_equal(scipy.optimize.linear_sum_assignment(c)[1], m)
+        same = np.repeat(rng.normal(size=(32, 1)), nc, axis=1)
+        m2, _, v2 = lc.ssp_duals(same)
+        assert not lc.certificate(same, m2, v2)
