@@ -811,7 +811,7 @@ def test_mgm3_none_and_train_mode(dev):
     m.load_state_dict(synth.mgm3_params(9), strict=True)
     m.train()                                     # dropout on the attention: stochastic but finite
     l1 = m([x.to(dev) for x in nodes], [l.to(dev) for l in labels], U)
-    assert torch.isfinite(l1) and float(l1) > 0
+    assert torch.isfinite(l1) and float(l1.detach()) > 0
 
 
 # ------------------------------------------------------------------------------------------- A2
