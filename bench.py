@@ -308,7 +308,7 @@ def kernel_rooflines(run):
 
 def pmc_traffic(stamp_name):
     """HBM bytes per launch from the committed PMC passes of this command (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in
-    separate runs -> tools/pmc_summary.py -> profiles/r02_bench_pmc.json).  Counters cannot be read from inside the timed
+    separate runs -> tools/pmc_summary.py -> profiles/rNN_bench_pmc.json, the newest round's record that holds the kernel).  Counters cannot be read from inside the timed
     process, so this is the recorded figure, not a live one; None when absent."""
     names = {"gagm": ("gagm_kernel", False), "sgd": ("sgd_multi_tensor", True), "affinity_fwd": ("affinity_fwd", False),
              "affinity_bwd": ("affinity_bwd_kernel", False), "sinkhorn_pairs_fwd": ("sinkhorn_pairs_fwd", False),
@@ -316,7 +316,8 @@ def pmc_traffic(stamp_name):
              "pair_stage_bwd": ("pair_stage_bwd", False), "bias_act": ("bias_act", True), "relu_bwd": ("relu_bwd", True),
              "roi_align_nhwc": ("roi_align_nhwc", True), "row_scale_multi": ("row_scale_multi", True)}
     kernel, streaming = names[stamp_name]
-    for f in ("r03_bench_pmc.json", "r02_bench_pmc.json", "r01_bench_pmc.json"):
+    import glob
+    for f in sorted((os.path.basename(x) for x in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_pmc.json"))), reverse=True):   # newest round first
         try:
             with open(os.path.join(ROOT, "profiles", f)) as fh:
                 rec = json.load(fh).get(kernel)

@@ -31,6 +31,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: what this header declares is exactly what libttdg_mgm.so exports
+ * (tests/test_abi.py compares the dynamic symbol table with this file). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define TTDG_VERSION 100 /* 0.1.0 */
 #define TTDG_MAX_GRAPHS 64
@@ -377,6 +382,9 @@ int ttdg_mask_pair_counts(const unsigned long long* pred, const unsigned long lo
 int ttdg_mask_measures(const int32_t* counts, const int32_t* cy, const int32_t* cx, const int32_t* owner, int npairs, int H, int W,
                        double alpha, double* best, ttdg_stream_t stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -195,6 +195,77 @@ def gold_mgm3_big(mgm):
     np.savez_compressed(os.path.join(OUT, "mgm3_big.npz"), **out)
 
 
+def gold_mgm3_cfg3(mgm):
+    """BASELINE.json cfg-3 at full size (8 graphs x 256 nodes): the REFERENCE's own free-running
+    MGM3_unsup.forward + backward on the planted case cases.PLANTED_CFG3_CASES, admitted like every planted golden (1 / 8
+    threads, two 1e-7 input perturbations, tests/golden/admission.py with the reference's GA_GM), stored compactly:
+      U            one uint8 universe column per node (255 = unassigned)                       multi_graph_matching.py:300-389
+      iters        iterations per stage of the schedule, read off the reference's own print_helper(i, tau) calls  :374-381
+      V0           first-iteration V exactly as :317-321 computes it
+      U0           x U^T (:531-532);  Wds as a strided sample (cases.CFG3_WSTRIDE) + Frobenius norm (:518-525)
+      loss, node / parameter gradients (strided sample + L2 norm)."""
+    out = {}
+    for name, sizes, seed, _ in PLANTED_CFG3_CASES:
+        params, nodes, labels, U, _ = mgm_inputs(name)
+        runs = []
+        for trial in range(4):
+            torch.set_num_threads(8 if trial == 1 else 1)
+            m = mgm.MGM3_unsup(2, 32)
+            m.load_state_dict(params, strict=True)
+            m.eval()
+            xs = [x.clone() for x in nodes]
+            if trial >= 2:
+                g = synth.gen(77 + trial)
+                xs = [x * (1 + 1e-7 * synth.normal(g, tuple(x.shape))) for x in xs]
+            xs = [x.requires_grad_() for x in xs]
+            cap = {"stages": []}
+            orig = m.ga_mgmc.forward
+
+            def spy(A, W, U0, *a, _o=orig, _c=cap, **k):
+                _c["A"], _c["W"], _c["U0"] = A.detach().clone(), W.detach().clone(), U0.detach().clone()
+                res = _o(A, W, U0, *a, **k)
+                _c["U"] = res[0].detach().clone()
+                return res
+            m.ga_mgmc.forward = spy
+            ph = mgm.print_helper
+            mgm.print_helper = lambda i, tag, _c=cap: _c["stages"].append((int(i) + 1, tag))
+            try:
+                loss = m(xs, labels, U)
+            finally:
+                mgm.print_helper = ph
+            if trial == 0:
+                loss.backward()
+            runs.append((cap, loss.detach(), m, xs))
+            print("cfg3 golden %s trial %d: loss %.6f stages %s" % (name, trial, float(loss), cap["stages"]), flush=True)
+        torch.set_num_threads(1)
+        assert all(torch.equal(runs[0][0]["U"], r[0]["U"]) for r in runs[1:]), "reference not rounding-stable on " + name
+        assert all([c for c, _ in runs[0][0]["stages"]] == [c for c, _ in r[0]["stages"]] for r in runs[1:]), "stage counts move under rounding on " + name
+        cap, loss, m, xs = runs[0]
+        Ub = cap["U"]
+        torch.set_num_threads(8)
+        ok, res = admission.check(params, nodes, labels, U, sizes, solve=lambda *a, **k: ref_solve(mgm, *a, **k), golden=Ub)
+        torch.set_num_threads(1)
+        print("admission %-9s %s" % (name, "ok" if ok else "FAILED: " + ", ".join(k for k, v in res.items() if not v)), flush=True)
+        assert ok, "planted case %s sits on a rounding edge of the reference: %s" % (name, res)
+        A, W, U0 = cap["A"], cap["W"], cap["U0"]
+        V0 = (torch.chain_matmul(A, U0 @ U0.t(), A, U0) * 0.5 * 2 + W @ U0) / len(sizes)
+        out[f"{name}_U"] = perm_to_columns(npy(Ub))
+        out[f"{name}_iters"] = np.array([c for c, _ in cap["stages"]], np.int64)
+        out[f"{name}_V0"] = npy(V0)
+        out[f"{name}_U0"] = npy(U0)
+        out[f"{name}_Wds__sample"] = npy(W.reshape(-1)[::CFG3_WSTRIDE])
+        out[f"{name}_Wds__norm"] = npy(W.double().norm())
+        out[f"{name}_loss"] = npy(loss)
+        for gi, x in enumerate(xs):
+            pgrad(out, f"{name}_dnode{gi}", x.grad)
+        for k, p in m.named_parameters():
+            if p.grad is not None:
+                pgrad(out, f"{name}_d_{k}", p.grad)
+            else:
+                out[f"{name}_nograd_{k}"] = np.zeros(0, np.float32)
+    np.savez_compressed(os.path.join(OUT, "mgm3_cfg3.npz"), **out)
+
+
 def gold_mgm3(mgm):
     out = {}
     for name, sizes, seed in MGM_CASES:
@@ -328,6 +399,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "mgm3_big":
         gold_mgm3_big(mgm)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "mgm3_cfg3":
+        gold_mgm3_cfg3(mgm)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "mgm3":
         gold_mgm3(mgm)
         return
@@ -342,6 +416,7 @@ def main():
     gold_gagm(mgm)
     gold_mgm3(mgm)
     gold_mgm3_big(mgm)
+    gold_mgm3_cfg3(mgm)
     gold_proto(bg)
     gold_usup(mgm)
     gold_sinkhorn_ref()

@@ -30,6 +30,17 @@ def test_every_declared_symbol_is_exported(lib):
         assert hasattr(lib, s), s
 
 
+def test_exported_functions_are_exactly_the_header(lib):
+    """-fvisibility=hidden + the header's visibility pragma: the dynamic symbol table's FUNCTIONS (nm type T) are the header's
+    entry points and nothing else - no kernel launch stubs, no internal helpers (the remaining data symbols are the kernel handle
+    objects the HIP runtime registers)."""
+    import subprocess
+    from ttdg_mgm_amd import _lib
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    funcs = sorted(line.split()[-1] for line in out.splitlines() if len(line.split()) == 3 and line.split()[1] in "Tt")
+    assert funcs == header_symbols(), sorted(set(funcs) ^ set(header_symbols()))
+
+
 def test_ctypes_table_matches_header():
     from ttdg_mgm_amd import _lib
     assert sorted(_lib.SIGNATURES) == header_symbols()

@@ -769,6 +769,58 @@ def test_mgm3_end_to_end_planted_golden(dev, golden, name):
     _check_against_gold(gold, name, m, dn, loss)
 
 
+# ------------------------------------------------------------------------------------------- cfg-3 at full size, planted
+@pytest.mark.parametrize("name", [c[0] for c in cases.PLANTED_CFG3_CASES])
+def test_cfg3_planted_solver_identical_permutations(dev, golden, name):
+    """BASELINE.json cfg-3 at FULL SIZE (8 graphs x 256 nodes) against the REFERENCE's own output (VERDICT r4 item 2;
+    tests/golden/mgm3_cfg3.npz: multi_graph_matching.py:300-389 run on the planted case and admitted by
+    tests/golden/admission.py with the reference's GA_GM).  Solver inputs (A, Wds, U0) from the oracle's front end, then the
+    multi-workgroup solver free-running: first V, the permutation matrices, every Sinkhorn-stage iteration count and the
+    Hungarian-stage count as the reference's print_helper reported them."""
+    from oracle import gmodule as og
+    from ttdg_mgm_amd import ops
+    gold = golden("mgm3_cfg3")
+    params, nodes, labels, U, sizes = cases.mgm_inputs(name)
+    otr = {}
+    og.mgm3_unsup_forward(params, nodes, labels, U, trace=otr)
+    ref_iters = gold[f"{name}_iters"].tolist()
+    assert otr["iters"] == ref_iters, ("the oracle does not walk the reference's trajectory", otr["iters"], ref_iters)
+    assert maxerr(otr["U0"], gold[f"{name}_U0"]) <= 1e-6 * max(1.0, float(np.abs(gold[f"{name}_U0"]).max()))
+    Ug, info, V0 = ops.gagm_solve(_pack(otr["A"], sizes).to(dev), otr["Wds"].to(dev), otr["U0"].to(dev), ops.graphs(sizes), list(sizes))
+    it = info.cpu().tolist()
+    print(name, "iterations per stage: device", it[:6], "reference", ref_iters, "| certified LAPs / fallbacks", it[12], it[13])
+    assert maxerr(V0, gold[f"{name}_V0"]) <= TOL * max(1.0, float(np.abs(gold[f"{name}_V0"]).max()))
+    assert np.array_equal(cases.perm_to_columns(Ug.cpu().numpy()), gold[f"{name}_U"]), "permutation matrices differ from the reference"
+    assert it[:5] == ref_iters[:5] and abs(it[5] - ref_iters[5]) <= 1 and it[7] == 6
+    LEDGER["cfg3_planted.identical_permutations_asserted"] += 1
+    LEDGER["cfg3_planted.hungarian_count_exact"] += int(it[5] == ref_iters[5])
+
+
+@pytest.mark.parametrize("name", [c[0] for c in cases.PLANTED_CFG3_CASES])
+def test_cfg3_planted_end_to_end_golden(dev, golden, name):
+    """The same case end to end and free-running through MGM3_unsup (multi_graph_matching.py:487-569): node features -> Wds
+    (strided sample + norm), U0, the reference's permutation matrices, loss, node gradients and parameter gradients."""
+    gold = golden("mgm3_cfg3")
+    m, dn, loss, tr = _run_mgm3(dev, name)
+    it = tr["info"].cpu().tolist()
+    print(name, "gagm iterations", it[:7], "loss", float(loss.detach()), "ref", float(gold[f"{name}_loss"]))
+    assert np.array_equal(cases.perm_to_columns(tr["Ub"].cpu().numpy()), gold[f"{name}_U"]), "permutation matrices differ from the reference"
+    assert it[:5] == gold[f"{name}_iters"].tolist()[:5]
+    W = tr["Wds"].detach().reshape(-1).cpu()
+    assert maxerr(W[::cases.CFG3_WSTRIDE], gold[f"{name}_Wds__sample"]) <= TOL
+    assert abs(float(W.double().norm()) - float(gold[f"{name}_Wds__norm"])) <= TOL * float(gold[f"{name}_Wds__norm"])
+    assert maxerr(tr["U0"], gold[f"{name}_U0"]) <= TOL * max(1.0, float(np.abs(gold[f"{name}_U0"]).max()))
+    assert abs(float(loss.detach()) - float(gold[f"{name}_loss"])) <= TOL
+    for gi, x in enumerate(dn):
+        check_pgrad(gold, f"{name}_dnode{gi}", x.grad, TOL)
+    for k, p in m.named_parameters():
+        if f"{name}_nograd_{k}" in gold:
+            assert p.grad is None, k
+        else:
+            check_pgrad(gold, f"{name}_d_{k}", p.grad, TOL)
+    LEDGER["cfg3_planted_e2e.identical_permutations_asserted"] += 1
+
+
 @pytest.mark.parametrize("name", [c[0] for c in cases.MGM_CASES])
 def test_mgm3_end_to_end_random_teacher_forced(dev, golden, name):
     """Random-weight cases: the reference's own permutations are rounding noise there (it returns different ones
@@ -2023,6 +2075,9 @@ def test_statement_ledger():
     assert LEDGER["planted_solver.identical_permutations_asserted"] == nplanted
     assert LEDGER["planted_e2e.identical_permutations_asserted"] == nplanted
     assert LEDGER["planted_solver.hungarian_count_exact"] >= nplanted - 2          # +-1 tolerated on at most two
+    # BASELINE.json cfg-3 at full size (8 x 256): the reference's permutation matrices, twice
+    assert LEDGER["cfg3_planted.identical_permutations_asserted"] == len(cases.PLANTED_CFG3_CASES)
+    assert LEDGER["cfg3_planted_e2e.identical_permutations_asserted"] == len(cases.PLANTED_CFG3_CASES)
     # multi-workgroup solver vs its host-driven statement on RANDOM inputs (the rounding-chaotic regime; its reference
     # permutations are pinned by the planted cases pb_n132 / pb_12x30 above): the Sinkhorn-stage counts are compared on
     # every case, and the strong end-state statement must have been made at least `LARGE_MIN_IDENTICAL` times

@@ -210,3 +210,24 @@ def test_gagm_trained_regime_is_reproducible_through_four_stages(golden, j):
     U64 = og.gagm(A.double(), W.double(), U0.double(), sizes, trace=t64, max_stages=4)
     assert t32["iters"] == t64["iters"] and len(t32["iters"]) == 4
     assert float((U32.double() - U64).abs().max()) <= 5e-6
+
+
+@pytest.mark.parametrize("name", [c[0] for c in cases.PLANTED_CFG3_CASES])
+def test_cfg3_size_planted_golden(golden, name):
+    """BASELINE.json cfg-3 at full size (8 x 256 nodes): the oracle against the REFERENCE's own run of the planted case
+    (tests/golden/mgm3_cfg3.npz; multi_graph_matching.py:487-569 + :300-389): Wds (strided sample + norm), U0, first V, the
+    iteration count of every stage as the reference's print_helper reported it, the permutation matrices, and the loss."""
+    gold = golden("mgm3_cfg3")
+    params, nodes, labels, U, sizes = cases.mgm_inputs(name)
+    tr = {}
+    with torch.no_grad():
+        loss = og.mgm3_unsup_forward(params, nodes, labels, U, trace=tr)
+    W = tr["Wds"].reshape(-1)
+    close(W[::cases.CFG3_WSTRIDE], gold[f"{name}_Wds__sample"], 1e-6)
+    assert abs(float(W.double().norm()) - float(gold[f"{name}_Wds__norm"])) <= 1e-5 * float(gold[f"{name}_Wds__norm"])
+    close(tr["U0"], gold[f"{name}_U0"], 1e-6)
+    close(tr["V0"], gold[f"{name}_V0"], 1e-5)
+    assert tr["iters"] == gold[f"{name}_iters"].tolist()
+    assert np.array_equal(cases.perm_to_columns(tr["Ub"].numpy()), gold[f"{name}_U"])
+    assert np.array_equal(cases.columns_to_perm(gold[f"{name}_U"]), tr["Ub"].numpy())
+    close(loss, gold[f"{name}_loss"], 1e-6)

@@ -1,0 +1,232 @@
+"""Continual-TTA trajectory against the float64 statement of the SAME trajectory.
+
+K adaptation steps with weights and momentum carried over (reference engine/trainer.py:452,469-482) are taken three times from one
+checkpoint:
+    host32   the CPU port in float32, free-running (its own detections, its own solve)                    - the reference side
+    host64   the CPU port in float64, fed host32's detections and pseudo-labels at every step             - the truth
+    device   the product, fed the same detections and pseudo-labels                                       - the side under test
+so that all three differentiate the same loss on the same node selection and what separates them is arithmetic only.  Per step k
+and tensor group g (res3, res4, res5, FPN, affinity) the record holds, in max-norm over the group's parameters,
+    h(g,k) = |theta_host32 - theta_host64|      what the REFERENCE's float32 arithmetic has lost after k + 1 steps
+    d(g,k) = |theta_device - theta_host64|      what the device's has
+    step_move, sum_step_moves, moved            the host's own movement (per step, summed, net), param_ulp = float32 spacing at the
+                                                group's largest parameter.
+h is a property of the reference side alone; the gate of tests/test_gpu_trained.py::test_continual_tta_trajectory_matches_cpu_port
+is built from it (per group, per step), never from the device's own figure.  The coupling between groups (a layer's gradient
+inherits the error of the features it is fed and of the gradient handed back to it) is IN h, because host32 walks the same coupled
+system - no model of error propagation is needed.
+
+usage (GPU box):  python tools/trajectory_study.py [K=8] [checkpoints=3] [out.json]
+    fits `checkpoints` fresh trained-regime checkpoints (each fit draws different weights: the vendor's weight-gradient kernels use
+    atomics) and records the full table for each - the pre-registration sample the gate constants were fixed on."""
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tools")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+GROUPS = {"res3": "backbone.bottom_up.res3", "res4": "backbone.bottom_up.res4", "res5": "backbone.bottom_up.res5", "fpn": "backbone.fpn_",
+          "affinity": "multi_matching_unsup.node_affinity"}
+
+
+def adapted(model):
+    return {n: p for n, p in model.named_parameters() if p.requires_grad}
+
+
+class host_backend:
+    """Point the detector's operator provider at the oracle's CPU operators for the duration of a ``with`` block."""
+
+    def __enter__(self):
+        from oracle import tta_cpu
+        from ttdg_mgm_amd.modeling import detector
+        self.saved = detector._backend
+        detector._backend = tta_cpu._CpuBackend
+
+    def __exit__(self, *a):
+        from ttdg_mgm_amd.modeling import detector
+        detector._backend = self.saved
+
+
+def host_tta_step(cpu, batch, bufs, cfg, og, dets=None, forced_U=None, dtype=torch.float32):
+    """One adaptation step of the CPU port (oracle/tta_cpu.tta_step), returning what the other two sides need to be teacher-forced:
+    the host's detections and pseudo-labels.  ``dets`` / ``forced_U`` given: skip the detector / the solver (float64 run)."""
+    images = cpu.preprocess_image(batch)
+    features = cpu.backbone(images.tensor.to(dtype))
+    if dets is None:
+        props, _ = cpu.proposal_generator(images, features, None, compute_loss=False)
+        dets, _ = cpu.roi_heads(images, features, props, None, compute_loss=False, branch="TTT")
+    feats = [features[k] for k in ("p2", "p3", "p4", "p5", "p6")]
+    nodes, labels = og.prototype_computation(feats, [d.pred_boxes.tensor for d in dets], [d.pred_classes for d in dets])
+    p = dict(cpu.multi_matching_unsup.named_parameters())
+    tr = {}
+    loss = og.mgm3_unsup_forward(p, nodes, labels, cpu.multi_matching_sup.U, trace=tr, forced_U=forced_U)
+    params = [q for q in cpu.parameters() if q.requires_grad]
+    for q in params:
+        q.grad = None
+    loss.backward()
+    with torch.no_grad():
+        og.sgd_step(params, [q.grad for q in params], bufs, cfg.SOLVER.BASE_LR, cfg.SOLVER.MOMENTUM, cfg.SOLVER.WEIGHT_DECAY)
+    return loss.detach(), dets, tr, [len(x) for x in nodes]
+
+
+def run(cfg, cpu0, gpu0, batches, K, f64_steps=None, log=print):
+    """-> (record dict, adapted cpu model, adapted gpu model).  ``f64_steps`` = how many steps the float64 host walks along
+    (default: all K)."""
+    from oracle import gmodule as og
+    from ttdg_mgm_amd.engine import BaselineTrainer
+    f64_steps = K if f64_steps is None else min(K, f64_steps)
+    cpu, gpu = copy.deepcopy(cpu0), copy.deepcopy(gpu0)
+    cpu.train(), gpu.train()
+    cpu.multi_matching_unsup.eval(), gpu.multi_matching_unsup.eval()        # attention dropout off on every side
+    gpu.teacher_forced = True
+    theta0 = {n: p.detach().clone() for n, p in adapted(cpu).items()}
+    names = {g: [n for n in theta0 if pre in n] for g, pre in GROUPS.items()}
+    assert all(names.values()), {g: len(v) for g, v in names.items()}
+    nparams = len([q for q in cpu.parameters() if q.requires_grad])
+    bufs, bufs64 = [None] * nparams, [None] * nparams
+    c64 = copy.deepcopy(cpu).double()
+    opt = BaselineTrainer.build_optimizer(cfg, gpu)
+    rec = []
+    prev_h, cum = {n: p.clone() for n, p in theta0.items()}, {g: 0.0 for g in GROUPS}
+    seconds = dict(host32=0.0, host64=0.0, device=0.0)
+    for k in range(K):
+        batch = batches[k]
+        t0 = time.time()
+        with host_backend():
+            loss_h, dets, otr, hsizes = host_tta_step(cpu, batch, bufs, cfg, og)
+        t1 = time.time()
+        loss64 = None
+        if k < f64_steps:
+            with host_backend():
+                loss64, _, _, s64 = host_tta_step(c64, batch, bufs64, cfg, og, dets=dets, forced_U=otr["Ub"], dtype=torch.float64)
+            assert s64 == hsizes
+        t2 = time.time()
+        fb = [dict(it, tf_boxes=d.pred_boxes.tensor.detach(), tf_classes=d.pred_classes) for it, d in zip(batch, dets)]
+        gpu.multi_matching_unsup.keep_trace = True
+        gpu.multi_matching_unsup.forced_U = otr["Ub"].to("cuda:0")
+        loss_d = BaselineTrainer.tta_step(gpu, opt, fb)
+        assert loss_d is not None and list(gpu.multi_matching_unsup.last["sizes"]) == hsizes, "node selection differs"
+        th_d = {n: p.detach().cpu() for n, p in adapted(gpu).items()}
+        t3 = time.time()
+        seconds["host32"] += t1 - t0
+        seconds["host64"] += t2 - t1
+        seconds["device"] += t3 - t2
+        th_h = adapted(cpu)
+        t64 = {n: p.detach() for n, p in adapted(c64).items()} if k < f64_steps else None
+        row = dict(step=k, sizes=hsizes, loss_host=float(loss_h), loss_device=float(loss_d.detach()), loss_host64=None if loss64 is None else float(loss64),
+                   solver_iters_host=otr["iters"], groups={})
+        for g, ns in names.items():
+            move = max(float((th_h[n].detach() - theta0[n]).abs().max()) for n in ns)
+            smove = max(float((th_h[n].detach() - prev_h[n]).abs().max()) for n in ns)
+            cum[g] += smove
+            diff = max(float((th_d[n] - th_h[n].detach()).abs().max()) for n in ns)
+            pmax = max(float(th_h[n].detach().abs().max()) for n in ns)
+            v = dict(moved=move, step_move=smove, sum_step_moves=cum[g], device_minus_host=diff, rel=diff / max(move, 1e-30),
+                     param_ulp=float(np.spacing(np.float32(pmax))))
+            if t64 is not None:
+                v["host32_minus_host64"] = max(float((th_h[n].detach().double() - t64[n]).abs().max()) for n in ns)
+                v["device_minus_host64"] = max(float((th_d[n].double() - t64[n]).abs().max()) for n in ns)
+            row["groups"][g] = v
+        prev_h = {n: p.detach().clone() for n, p in th_h.items()}
+        rec.append(row)
+        log("step %d: loss host %.6f device %.6f%s | per group |host32-host64|, |device-host64|, |device-host32| (units of 1e-9): %s" %
+            (k, row["loss_host"], row["loss_device"], "" if loss64 is None else " float64 %.6f" % float(loss64),
+             {g: tuple(round(v.get(x, float("nan")) * 1e9, 1) for x in ("host32_minus_host64", "device_minus_host64", "device_minus_host")) for g, v in row["groups"].items()}))
+    gpu.multi_matching_unsup.forced_U = None
+    gpu.multi_matching_unsup.keep_trace = False
+    return dict(steps=K, float64_steps=f64_steps, records=rec, seconds=seconds), cpu, gpu
+
+
+TRAJ_FACTOR = 4.0
+
+
+def gate_table(rec, factor=TRAJ_FACTOR):
+    """The gate of the trajectory test, evaluated on a record of run(): for every group g and step k with a float64 statement
+        d(g,k)  <=  factor * max_{j<=k} h(g,j)  +  (k + 1) * ulp_g.
+    h is a max-norm over 1e5 ... 1e7 parameters of accumulated rounding differences; the running maximum over the steps so far makes the
+    bound monotone (a step on which the reference's own error happens to dip does not tighten it).  ulp_g: p - lr * buf is rounded to
+    p's float32 grid once per step on each side whatever the size of the update.  factor = 4: h and d are two draws of the same
+    quantity - what float32 arithmetic loses on this trajectory; on the pre-registration sample (profiles/r05_trajectory_study.json)
+    their ratio d / h lies in the range recorded there.  -> ({group: worst d / bound}, rows)."""
+    worst, rows = {}, []
+    hmax = {}
+    for row in rec:
+        for g, v in row["groups"].items():
+            if "host32_minus_host64" not in v:
+                continue
+            hmax[g] = max(hmax.get(g, 0.0), v["host32_minus_host64"])
+            bound = factor * hmax[g] + (row["step"] + 1) * v["param_ulp"]
+            frac = v["device_minus_host64"] / bound
+            v["bound"], v["fraction_of_bound"] = bound, frac
+            worst[g] = max(worst.get(g, 0.0), frac)
+            rows.append((row["step"], g, v["device_minus_host64"], bound))
+    return worst, rows
+
+
+def additive_table(rec, factor=TRAJ_FACTOR, draws=3):
+    """RECORDED, not asserted (keep the tight formula visible): VERDICT r4's per-group additive form
+        |device - host32|(g,k)  <=  factor * E_g * sum_{j<=k} step_move_j(g)  +  (k + 1) * ulp_g,
+        E_g = max over the first `draws` steps of h(g,k) / sum_step_moves(g,k)   (host figures only)."""
+    E = {}
+    for row in rec[:draws]:
+        for g, v in row["groups"].items():
+            if "host32_minus_host64" in v:
+                E[g] = max(E.get(g, 0.0), v["host32_minus_host64"] / max(v["sum_step_moves"], 1e-30))
+    worst = {}
+    for row in rec:
+        for g, v in row["groups"].items():
+            if g in E:
+                bound = factor * E[g] * v["sum_step_moves"] + (row["step"] + 1) * v["param_ulp"]
+                worst[g] = max(worst.get(g, 0.0), v["device_minus_host"] / bound)
+    return E, worst
+
+
+def main():
+    K = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    nck = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", "trajectory_study.json")
+    import synth_checkpoint as sc
+    from ttdg_mgm_amd import data
+    from ttdg_mgm_amd.config import get_cfg
+    from ttdg_mgm_amd.engine import BaselineTrainer
+    from ttdg_mgm_amd.engine.checkpoint import load_weights
+    cfg = get_cfg()
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "test_segment.yaml"))
+    dev = torch.device("cuda:0")
+    cfg.MODEL.DEVICE = str(dev)
+    ccfg = cfg.clone()
+    ccfg.MODEL.DEVICE = "cpu"
+    data.register_synthetic("traj_ds", 4 * K, size=512, cfg_id=2)
+    batches = list(data.build_detection_test_loader(ccfg, "traj_ds"))
+    out = dict(K=K, factor=TRAJ_FACTOR, checkpoints=[])
+    for c in range(nck):
+        path, rep = sc.get_or_make(cfg, dev, cache_dir="/tmp/ttdg_traj_ckpt_%d" % c, log=lambda m: None)
+        gpu = BaselineTrainer.build_model(cfg)
+        load_weights(gpu, path)
+        cpu = BaselineTrainer.build_model(ccfg)
+        load_weights(cpu, path)
+        t0 = time.time()
+        rec, _, _ = run(cfg, cpu, gpu, batches, K)
+        worst, _ = gate_table(rec["records"])
+        E, worst_add = additive_table(rec["records"])
+        ratios = {g: [row["groups"][g]["device_minus_host64"] / max(row["groups"][g]["host32_minus_host64"], 1e-30) for row in rec["records"]] for g in GROUPS}
+        rec.update(worst_fraction_of_bound=worst, additive_E=E, additive_worst_fraction=worst_add, d_over_h=ratios, wall_s=time.time() - t0,
+                   checkpoint=str(rep.get("content_sha16", "")) or os.path.basename(path))
+        out["checkpoints"].append(rec)
+        print("checkpoint %d: worst d / bound per group %s | additive form %s | seconds %s" %
+              (c, {g: round(w, 3) for g, w in worst.items()}, {g: round(w, 3) for g, w in worst_add.items()}, {k: round(v, 1) for k, v in rec["seconds"].items()}), flush=True)
+        os.makedirs(os.path.dirname(out_path), exist_ok=True)
+        with open(out_path, "w") as f:
+            json.dump(out, f, indent=1)
+        del gpu, cpu
+
+
+if __name__ == "__main__":
+    main()
