@@ -160,9 +160,12 @@ int ttdg_mha_adjacency(const float* q, const float* k, int d, ttdg_graphs_t gr, 
  * (multi_graph_matching.py:223-244, 300-389 with num_clusters == 1; utils/hungarian.py:8-66 ->
  * scipy.optimize.linear_sum_assignment [3P] re-implemented on device, one wavefront per LAP.)
  * Apack as above, W = Wds (M x M), U0 (M x 32).  U (M x 32) receives the 0/1 matching.
- * info (int32[16], device): [0..5] iterations per stage, [6] total, [7] stages run, [8] status (0 = ok; the cooperative
- * multi-workgroup kernel: 1 = a grid barrier timed out, 2 = the stage machine did not stop - U is then NaN); multi-workgroup solver:
- * [12] Hungarian-stage LAPs solved with a uniqueness certificate, [13] LAPs that fell back to the scipy-order solver.
+ * info (int32[24], device, zero-initialised by the caller): [0..5] iterations per stage, [6] total, [7] stages run,
+ * [8] STATUS and nothing else (0 = ok; the cooperative multi-workgroup kernel: 1 = a grid barrier timed out, 2 = the stage
+ * machine did not stop - U is then NaN); [12] Hungarian-stage LAPs solved with a uniqueness certificate, [13] LAPs that fell back to
+ * the scipy-order solver (multi-workgroup solver); [14], [15] period and detection iteration of a Hungarian-stage cycle;
+ * cfg.profile != 0: single-workgroup kernel [9..13] = cycle-counter ticks / 64 spent in B, S, V, projection, convergence;
+ * multi-workgroup solver [16..20] = cycles / 1024 per phase (csrc/gagm_large.hip: gl_write_result).
  * ws: workspace of ttdg_gagm_workspace_bytes(M) bytes; its first 2*M*32 floats receive the
  * first-iteration V and the first projected U (parity tests). */
 typedef struct {
@@ -171,7 +174,7 @@ typedef struct {
   int32_t max_stages;        /* 0 = run the full schedule; k > 0 stops after k stages (parity tests) */
   int32_t start_hungarian;   /* non-zero: the first stage already uses the Hungarian projector (parity tests) */
   int32_t no_cycle_skip;     /* non-zero: disable the exact Hungarian-stage cycle shortcut (parity tests) */
-  int32_t profile;           /* non-zero: info[9..13] receive cycle-counter ticks/64 spent in B, S, V, projection, convergence */
+  int32_t profile;           /* non-zero: phase clocks in info[9..13] (single-workgroup kernel) / info[16..20] (multi-workgroup solver) */
   int32_t variant;           /* 0 = the product path.  A/B and parity-test selectors, per call (the library keeps no switches):
                               *   TTDG_GAGM_LDS_PROJECTORS    round 1's LDS-exchange Sinkhorn projectors for graphs of <= 64 nodes
                               *   TTDG_GAGM_FORCE_LARGE       the multi-workgroup solver even where one workgroup would do

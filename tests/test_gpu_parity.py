@@ -413,6 +413,59 @@ def test_pair_sinkhorn_forward_backward(dev, sizes, ks):
     derived_gate("pair sinkhorn bwd %s" % (sizes,), torch.where(low > 0, dM.cpu(), torch.zeros(())), Mr.grad * low, M64.grad * low)     # (dM is unspecified outside the a > b blocks: select, do not multiply)
 
 
+@pytest.mark.parametrize("sizes,spike", [((256, 256), None), ((140, 200, 256), None), ((200, 31, 200), None), ((256, 256), -10.0), ((200, 150), -12.0),
+                                         ((256, 190), 9.0)])
+def test_pair_sinkhorn_scaling_form_log_domain_and_range_fallback(dev, sizes, spike):
+    """[r5] The pair stage for graphs of 129-256 nodes runs in the SCALING form (csrc/sinkhorn.hip: K = the row-normalised matrix after
+    sweep 0, then s_p = sum_q K v, c_q = sum_p K u - one exponential per entry in all; utils/sinkhorn.py:58-87 / SURVEY Appendix B in
+    exact arithmetic).  Checked in the LOG domain - y = L - f - g rebuilt from the potentials the kernel logs for its backward, against
+    log of the float64 oracle - on every block, at the gate of test_sinkhorn_vs_reference_tree_log_sinkhorn (1e-4 + 40 ulp of max |s / tau|).
+    ``spike``: one column (and one row) of every block is shifted by that much: at tau = 0.05 a shift of -10 is 2^-288 against the
+    rest of its rows - the scaling form's column sum underflows, the workgroup must detect it and take the log-domain sweeps instead
+    (the oracle has no such limit); +9 overflows the other way round only if the row maximum were not removed first."""
+    from oracle import gmodule as og
+    from ttdg_mgm_amd import ops
+    G, M = len(sizes), sum(sizes)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    g = synth.gen(sum(sizes) * 17 + (0 if spike is None else 1))
+    Mraw = synth.normal(g, (M, M), 0.1)
+    if spike is not None:
+        for a in range(G):
+            Mraw[:, off[a] + 3] += spike
+            Mraw[off[a] + 5, :] += spike
+    b2 = torch.tensor([0.03])
+    tau, iters = 0.05, 20
+    gr = ops.graphs(sizes)
+    Wd, pot = ops.sinkhorn_pairs_fwd(Mraw.unsqueeze(0).to(dev).contiguous(), b2.to(dev), gr, list(sizes), tau, iters)
+    Wd, pot = Wd.cpu(), pot.cpu()
+    assert torch.isfinite(Wd).all()
+    pair, worst_p, worst_l = 0, 0.0, 0.0
+    for a in range(G):
+        for b in range(a + 1):
+            blk = (Mraw[off[a]:off[a + 1], off[b]:off[b + 1]] + b2)
+            flip = sizes[b] < sizes[a]                        # rows <= cols (multi_graph_matching.py:518-522)
+            x = blk.t() if flip else blk
+            r, c = x.shape
+            ref32 = og.sinkhorn_pair(x)
+            ref64 = og.sinkhorn_pair(x.double())
+            out = Wd[off[a]:off[a + 1], off[b]:off[b + 1]]
+            out = out.t() if flip else out
+            worst_p = max(worst_p, float((out - ref32).abs().max()))
+            assert float((out - ref32).abs().max()) <= TOL, (a, b)
+            if a != b:
+                assert torch.equal(Wd[off[b]:off[b + 1], off[a]:off[a + 1]], Wd[off[a]:off[a + 1], off[b]:off[b + 1]].t())
+            L2 = x.double() * (1.4426950408889634 / tau)
+            f, gq = pot[pair, iters - 2, :r].double(), pot[pair, iters - 1, :c].double()
+            y2 = L2 - f[:, None] - gq[None, :]
+            live = ref64 > 1e-300
+            d = float((y2[live] - ref64[live].log2()).abs().max())
+            ulp = float(np.spacing(np.float32(float(L2.abs().max()))))
+            worst_l = max(worst_l, d)
+            assert d <= (1e-4 + 40 * ulp) * 1.4426950408889634, (a, b, d, ulp)
+            pair += 1
+    print("pair sinkhorn %s spike %s: max |Wds - oracle| %.2e, log2 domain %.2e" % (sizes, spike, worst_p, worst_l))
+
+
 @pytest.mark.parametrize("sizes", [(9, 14), (22, 22, 22), (22, 35, 28, 40), (5, 3), (64, 64), (1, 1), (64, 1, 33), (40,),
                                    (30, 27, 33, 25, 38, 21)])
 def test_fused_pair_stage_forward_backward(dev, sizes):

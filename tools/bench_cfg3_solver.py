@@ -63,7 +63,7 @@ for name, var in (("certified", 0), ("scipy_order", _lib.GAGM_SCIPY_ORDER_LAP), 
 for name, kw in (("full", {}), ("hungarian_24", dict(start_hungarian=True, max_stages=1, no_cycle_skip=True, max_iter=24))):
     for mode in (1, 2):
         _, it = timed(ops.gagm_cfg(profile=mode, **kw))
-        out.setdefault("project_kernel_kcycles_" + name, {})["operands+S, V, projector, norms" if mode == 1 else "Sinkhorn, certified LAP, scipy-order LAP, norms"] = it[8:12] + [dict(certified=it[12], fallbacks=it[13], iterations=it[6])]
+        out.setdefault("project_kernel_kcycles_" + name, {})["operands+S, V, projector, norms" if mode == 1 else "Sinkhorn, certified LAP, scipy-order LAP, norms"] = it[16:20] + [dict(certified=it[12], fallbacks=it[13], iterations=it[6])]
     _, it = timed(ops.gagm_cfg(profile=3, **kw))
-    out["project_kernel_kcycles_" + name]["pricing rounds, rows to augment, Dijkstra steps, max certified-LAP kcycles, max scipy-order kcycles"] = it[8:12] + [it[14]]
+    out["project_kernel_kcycles_" + name]["pricing rounds, rows to augment, Dijkstra steps, max certified-LAP kcycles, max scipy-order kcycles"] = it[16:20] + [it[20]]
 print(json.dumps(out, indent=1))

@@ -96,17 +96,44 @@ def run(cfg, cpu0, gpu0, batches, K, f64_steps=None, log=print):
     rec = []
     prev_h, cum = {n: p.clone() for n, p in theta0.items()}, {g: 0.0 for g in GROUPS}
     seconds = dict(host32=0.0, host64=0.0, device=0.0)
+    t_start = time.time()
+    # The float64 walker needs only the float32 host's detections and pseudo-labels of the same step, and (with both given) calls neither
+    # the detector's operator provider nor the solver: it runs one step BEHIND in a worker thread, next to the float32 host's next step
+    # (separate model copies, separate autograd graphs; torch releases the interpreter lock inside its kernels).
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=1)
+
+    def step64(batch, dets, Ub):
+        t = time.time()
+        loss64, _, _, s64 = host_tta_step(c64, batch, bufs64, cfg, og, dets=dets, forced_U=Ub, dtype=torch.float64)
+        return float(loss64), s64, {n: p.detach().clone() for n, p in adapted(c64).items()}, time.time() - t
+
+    pending = None       # (row, th_h snapshot, th_d snapshot, future)
+
+    def finish(pend):
+        row, th_h, th_d, fut = pend
+        loss64, s64, t64, dt = fut.result()
+        assert s64 == row["sizes"]
+        seconds["host64"] += dt
+        row["loss_host64"] = loss64
+        for g, ns in names.items():
+            v = row["groups"][g]
+            v["host32_minus_host64"] = max(float((th_h[n].double() - t64[n]).abs().max()) for n in ns)
+            v["device_minus_host64"] = max(float((th_d[n].double() - t64[n]).abs().max()) for n in ns)
+        log("step %d: loss host %.6f device %.6f float64 %.6f | per group |host32-host64|, |device-host64|, |device-host32| (units of 1e-9): %s" %
+            (row["step"], row["loss_host"], row["loss_device"], loss64,
+             {g: tuple(round(v.get(x, float("nan")) * 1e9, 1) for x in ("host32_minus_host64", "device_minus_host64", "device_minus_host")) for g, v in row["groups"].items()}))
+
     for k in range(K):
         batch = batches[k]
         t0 = time.time()
         with host_backend():
             loss_h, dets, otr, hsizes = host_tta_step(cpu, batch, bufs, cfg, og)
         t1 = time.time()
-        loss64 = None
-        if k < f64_steps:
-            with host_backend():
-                loss64, _, _, s64 = host_tta_step(c64, batch, bufs64, cfg, og, dets=dets, forced_U=otr["Ub"], dtype=torch.float64)
-            assert s64 == hsizes
+        if pending is not None:
+            finish(pending)
+            pending = None
+        fut = pool.submit(step64, batch, dets, otr["Ub"]) if k < f64_steps else None
         t2 = time.time()
         fb = [dict(it, tf_boxes=d.pred_boxes.tensor.detach(), tf_classes=d.pred_classes) for it, d in zip(batch, dets)]
         gpu.multi_matching_unsup.keep_trace = True
@@ -116,29 +143,28 @@ def run(cfg, cpu0, gpu0, batches, K, f64_steps=None, log=print):
         th_d = {n: p.detach().cpu() for n, p in adapted(gpu).items()}
         t3 = time.time()
         seconds["host32"] += t1 - t0
-        seconds["host64"] += t2 - t1
         seconds["device"] += t3 - t2
-        th_h = adapted(cpu)
-        t64 = {n: p.detach() for n, p in adapted(c64).items()} if k < f64_steps else None
-        row = dict(step=k, sizes=hsizes, loss_host=float(loss_h), loss_device=float(loss_d.detach()), loss_host64=None if loss64 is None else float(loss64),
+        th_h = {n: p.detach().clone() for n, p in adapted(cpu).items()}
+        row = dict(step=k, sizes=hsizes, loss_host=float(loss_h), loss_device=float(loss_d.detach()), loss_host64=None,
                    solver_iters_host=otr["iters"], groups={})
         for g, ns in names.items():
-            move = max(float((th_h[n].detach() - theta0[n]).abs().max()) for n in ns)
-            smove = max(float((th_h[n].detach() - prev_h[n]).abs().max()) for n in ns)
+            move = max(float((th_h[n] - theta0[n]).abs().max()) for n in ns)
+            smove = max(float((th_h[n] - prev_h[n]).abs().max()) for n in ns)
             cum[g] += smove
-            diff = max(float((th_d[n] - th_h[n].detach()).abs().max()) for n in ns)
-            pmax = max(float(th_h[n].detach().abs().max()) for n in ns)
-            v = dict(moved=move, step_move=smove, sum_step_moves=cum[g], device_minus_host=diff, rel=diff / max(move, 1e-30),
-                     param_ulp=float(np.spacing(np.float32(pmax))))
-            if t64 is not None:
-                v["host32_minus_host64"] = max(float((th_h[n].detach().double() - t64[n]).abs().max()) for n in ns)
-                v["device_minus_host64"] = max(float((th_d[n].double() - t64[n]).abs().max()) for n in ns)
-            row["groups"][g] = v
-        prev_h = {n: p.detach().clone() for n, p in th_h.items()}
+            diff = max(float((th_d[n] - th_h[n]).abs().max()) for n in ns)
+            pmax = max(float(th_h[n].abs().max()) for n in ns)
+            row["groups"][g] = dict(moved=move, step_move=smove, sum_step_moves=cum[g], device_minus_host=diff, rel=diff / max(move, 1e-30),
+                                    param_ulp=float(np.spacing(np.float32(pmax))))
+        prev_h = th_h
         rec.append(row)
-        log("step %d: loss host %.6f device %.6f%s | per group |host32-host64|, |device-host64|, |device-host32| (units of 1e-9): %s" %
-            (k, row["loss_host"], row["loss_device"], "" if loss64 is None else " float64 %.6f" % float(loss64),
-             {g: tuple(round(v.get(x, float("nan")) * 1e9, 1) for x in ("host32_minus_host64", "device_minus_host64", "device_minus_host")) for g, v in row["groups"].items()}))
+        if fut is not None:
+            pending = (row, th_h, th_d, fut)
+        else:
+            log("step %d: loss host %.6f device %.6f" % (k, row["loss_host"], row["loss_device"]))
+    if pending is not None:
+        finish(pending)
+    pool.shutdown()
+    seconds["wall"] = time.time() - t_start
     gpu.multi_matching_unsup.forced_U = None
     gpu.multi_matching_unsup.keep_trace = False
     return dict(steps=K, float64_steps=f64_steps, records=rec, seconds=seconds), cpu, gpu

@@ -929,7 +929,7 @@ extern "C" int ttdg_gagm_solve(const float* Apack, const float* W, const float* 
   // 512 threads (8 wavefronts).  With the 256-VGPR cap the kernel spills ~100 VGPRs, all at phase boundaries (none inside
   // the Sinkhorn / LAP loops); the spill-free 256-thread build (one wavefront per SIMD, 440 VGPRs) was measured SLOWER on
   // the bench (30.2 vs 27.1 us per iteration, 67.9 vs 72.0 images/s): B = A U and the convergence sweep want the eight
-  // wavefronts.  It stays selectable for A/B runs (ttdg_debug_set_gagm_threads).
+  // wavefronts.  It stays selectable for A/B runs (cfg.variant & TTDG_GAGM_256_THREADS).
   const int threads = (cmax <= 64 && (cfg.variant & TTDG_GAGM_256_THREADS)) ? 256 : 512;
   const int waves = threads / 64;
   const int cw = cmax <= 64 ? 1 : 2;

@@ -873,13 +873,14 @@ __device__ __forceinline__ void gl_write_result(const GlWs& w, const GlCtl* c, f
     info[6] = c->total; info[7] = c->stage;
     info[14] = c->cyc_p; info[15] = c->cyc_i;
     info[12] = w.lapstat[0]; info[13] = w.lapstat[1];      // Hungarian stage: certified workgroup LAPs / scipy-order fallbacks
-    // cfg.profile: cycles / 1024 summed over graphs and iterations: [8] operands + S, [9] V, [10] projector (Sinkhorn + both LAPs), [11] norms / hash
-    // (cfg.profile == 2: the projector split - [8] Sinkhorn, [9] certified LAP, [10] scipy-order LAP, [11] norms / hash;
-    //  cfg.profile == 3: [8] pricing rounds, [9] rows augmented, [10] Dijkstra steps, [11] / [14] longest certified / scipy-order LAP)
-    if (profile == 3) { info[8] = w.lapstat[2]; info[9] = w.lapstat[3]; info[10] = w.lapstat[4]; info[11] = (int32_t)(w.prof[6] >> 10); info[14] = (int32_t)(w.prof[7] >> 10); return; }
-    if (profile == 2) { info[8] = (int32_t)(w.prof[2] >> 10); info[9] = (int32_t)(w.prof[3] >> 10); info[10] = (int32_t)(w.prof[4] >> 10); }
-    else { info[8] = (int32_t)(w.prof[0] >> 10); info[9] = (int32_t)(w.prof[1] >> 10); info[10] = (int32_t)((w.prof[2] + w.prof[3] + w.prof[4]) >> 10); }
-    info[11] = (int32_t)(w.prof[5] >> 10);
+    // info[8] is the STATUS word and nothing else (written by the cooperative kernel on a barrier failure, 0 otherwise - the caller
+    // zero-initialises info).  cfg.profile != 0: info[16..20], cycles / 1024 summed over graphs and iterations:
+    //   profile 1: [16] operands + S, [17] V, [18] projector (Sinkhorn + both LAPs), [19] norms / hash
+    //   profile 2: the projector split - [16] Sinkhorn, [17] certified LAP, [18] scipy-order LAP, [19] norms / hash
+    //   profile 3: [16] pricing rounds, [17] rows augmented, [18] Dijkstra steps, [19] / [20] longest certified / scipy-order LAP
+    if (profile == 3) { info[16] = w.lapstat[2]; info[17] = w.lapstat[3]; info[18] = w.lapstat[4]; info[19] = (int32_t)(w.prof[6] >> 10); info[20] = (int32_t)(w.prof[7] >> 10); return; }
+    if (profile == 2) { info[16] = (int32_t)(w.prof[2] >> 10); info[17] = (int32_t)(w.prof[3] >> 10); info[18] = (int32_t)(w.prof[4] >> 10); info[19] = (int32_t)(w.prof[5] >> 10); }
+    else if (profile) { info[16] = (int32_t)(w.prof[0] >> 10); info[17] = (int32_t)(w.prof[1] >> 10); info[18] = (int32_t)((w.prof[2] + w.prof[3] + w.prof[4]) >> 10); info[19] = (int32_t)(w.prof[5] >> 10); }
   }
 }
 

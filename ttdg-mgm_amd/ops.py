@@ -398,20 +398,21 @@ def gagm_solve_hostloop(apack, W, U0, sizes, cfg, states=None):
             tau *= float(cfg.gamma)
         else:
             hung = True
-    info = torch.zeros(16, dtype=torch.int32)
+    info = torch.zeros(24, dtype=torch.int32)
     info[:len(iters)] = torch.tensor(iters, dtype=torch.int32)
     info[6], info[7] = total, stage
     return U, info.to(dev), V0
 
 
 def gagm_solve(apack, W, U0, gr, sizes, cfg=None):
-    """Returns (U (M,32) 0/1, info int32[16] on device, V0 (M,32) first-iteration V)."""
+    """Returns (U (M,32) 0/1, info int32[24] on device (include/ttdg_mgm.h), V0 (M,32) first-iteration V).  With the cooperative
+    one-launch form (TTDG_GAGM_ONE_LAUNCH) the status word info[8] is read back and a failed grid barrier raises."""
     M = sum(sizes)
     cfg = cfg or gagm_cfg()
     nbytes = _lib.load().ttdg_gagm_workspace_bytes(M)
     ws = torch.empty(nbytes // 4, device=W.device, dtype=torch.float32)
     U = torch.empty(M, UNIV, device=W.device, dtype=torch.float32)
-    info = torch.zeros(16, device=W.device, dtype=torch.int32)
+    info = torch.zeros(24, device=W.device, dtype=torch.int32)
     timers = KERNEL_TIMERS
     if timers is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -420,6 +421,10 @@ def gagm_solve(apack, W, U0, gr, sizes, cfg=None):
     if timers is not None:
         e1.record()
         timers.append(("gagm", e0, e1, list(sizes), info))
+    if int(getattr(cfg, "variant", 0)) & 64:          # TTDG_GAGM_ONE_LAUNCH: a barrier failure would otherwise only show as NaN in U
+        status = int(info[8])
+        if status:
+            raise RuntimeError("ttdg_gagm_solve (one cooperative launch): status %d (%s)" % (status, "a grid barrier timed out" if status == 1 else "the stage machine did not stop"))
     gagm_solve.last_U1 = ws[M * UNIV:2 * M * UNIV].view(M, UNIV)   # first projected U (debug / parity tests)
     return U, info, ws[:M * UNIV].view(M, UNIV)
 
