@@ -581,7 +581,7 @@ def gpu_main(args, rank, world, local):
     tf = bool(args.teacher_forced)
     main = timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, world, device, tf)
     eager_probe = None
-    if _graphed.ENABLED and model.__dict__.get("_graphed") is not None and model.__dict__["_graphed"].stats["eval_replays"] + model.__dict__["_graphed"].stats["train_replays"] > 0:
+    if _graphed.ENABLED and model.__dict__.get("_graphed") is not None and model.__dict__["_graphed"].stats["eval_replays"] > 0:
         # Inside a graph replay no HIP event can be placed around a single kernel from here.  The per-kernel durations of the
         # rooflines therefore come from a SECOND timed pass over the same K batches with the backbone launched eagerly (live HIP
         # events on the launch stream, as before); its images/s is the graphs-off A/B figure of the line.
@@ -756,7 +756,7 @@ def gpu_main(args, rank, world, local):
         "eager_pass": (None if eager_probe is None else {"value": images / eager_probe["elapsed"], "unit": "images/s", "dice": eager_probe["dice"],
                                                           "note": "same K batches, backbone launched kernel by kernel (graphs off): the pass the per-kernel HIP-event durations of `roofline` come from"}),
         "backbone_launches": ("hipGraph replay of the backbone's no-grad forward (Dice pass); the TTA step's forward + backward eagerly (modeling/graphed.py): %s (A/B: --graphs)" % (model.__dict__["_graphed"].stats,)
-                              if model.__dict__.get("_graphed") is not None and model.__dict__["_graphed"].stats["eval_replays"] + model.__dict__["_graphed"].stats["train_replays"] > 0 else "eager, kernel by kernel (A/B: --graphs replays the Dice pass's backbone forward from a hipGraph)"),
+                              if model.__dict__.get("_graphed") is not None and model.__dict__["_graphed"].stats["eval_replays"] > 0 else "eager, kernel by kernel (A/B: --graphs replays the Dice pass's backbone forward from a hipGraph)"),
         "vendor_convolutions": ("MIOpen immediate mode, solvers from the find-db shipped in ttdg-mgm_amd/miopen_db (tools/tune_miopen.sh; A/B: --no-miopen-db)"
                                 if os.path.basename(os.environ.get("MIOPEN_USER_DB_PATH", "").rstrip("/")).startswith(("miopen_db", "ttdg_miopen_db")) and not args.miopen_search else
                                 "MIOpen timing its solvers in this process (--miopen-search)" if args.miopen_search else "MIOpen immediate mode, heuristic solver choice"),

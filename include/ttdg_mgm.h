@@ -163,7 +163,7 @@ int ttdg_mha_adjacency(const float* q, const float* k, int d, ttdg_graphs_t gr, 
  * info (int32[24], device, zero-initialised by the caller): [0..5] iterations per stage, [6] total, [7] stages run,
  * [8] STATUS and nothing else (0 = ok; the cooperative multi-workgroup kernel: 1 = a grid barrier timed out, 2 = the stage
  * machine did not stop - U is then NaN); [12] Hungarian-stage LAPs solved with a uniqueness certificate, [13] LAPs that fell back to
- * the scipy-order solver (multi-workgroup solver); [14], [15] period and detection iteration of a Hungarian-stage cycle;
+ * the scipy-order solver (multi-workgroup solver), [21] narrow-range LAPs solved by the integer scipy-order solver; [14], [15] period and detection iteration of a Hungarian-stage cycle;
  * cfg.profile != 0: single-workgroup kernel [9..13] = cycle-counter ticks / 64 spent in B, S, V, projection, convergence;
  * multi-workgroup solver [16..20] = cycles / 1024 per phase (csrc/gagm_large.hip: gl_write_result).
  * ws: workspace of ttdg_gagm_workspace_bytes(M) bytes; its first 2*M*32 floats receive the
@@ -186,7 +186,10 @@ typedef struct {
                               *                               default: two launches per iteration enqueued by the host in chunks)
                               *   TTDG_GAGM_SCIPY_ORDER_LAP   multi-workgroup solver: every Hungarian-stage LAP by the one-wavefront scipy-order
                               *                               solver (default: warm-started workgroup LAP + uniqueness certificate,
-                              *                               csrc/lap_certified.h, scipy-order only when the certificate fails) */
+                              *                               csrc/lap_certified.h, scipy-order only when the certificate fails)
+                              *   TTDG_GAGM_NO_INT_LAP        multi-workgroup solver: uncertifiable blocks of a narrow value range (what follows a
+                              *                               collapsed Sinkhorn stage) also go through the fp64 step-by-step scipy-order solver
+                              *                               (default: its integer statement, lap_wave_solve_int - same decisions) */
 } ttdg_gagm_cfg_t;
 #define TTDG_GAGM_LDS_PROJECTORS 1
 #define TTDG_GAGM_FORCE_LARGE 2
@@ -195,6 +198,7 @@ typedef struct {
 #define TTDG_GAGM_COLUMN_PROJECTOR 16
 #define TTDG_GAGM_SCIPY_ORDER_LAP 32
 #define TTDG_GAGM_ONE_LAUNCH 64
+#define TTDG_GAGM_NO_INT_LAP 128
 size_t ttdg_gagm_workspace_bytes(int M);
 int ttdg_gagm_solve(const float* Apack, const float* W, const float* U0, ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg,
                     float* U, int32_t* info, void* ws, ttdg_stream_t stream);

@@ -1204,7 +1204,7 @@ def test_large_solver_certified_lap_equals_scipy_and_the_scipy_order_solver(dev,
     (Uf, inf_f), (Us, inf_s) = res[0], res[_lib.GAGM_SCIPY_ORDER_LAP]
     assert torch.equal(Uf, Us) and inf_f[:8] == inf_s[:8], (inf_f, inf_s)
     assert inf_s[12] == 0 and inf_s[13] == 0
-    assert inf_f[12] + inf_f[13] == big * inf_f[6], (inf_f, big)
+    assert inf_f[12] + inf_f[13] + inf_f[21] == big * inf_f[6], (inf_f, big)
     assert inf_f[12] >= 0.7 * big * inf_f[6], inf_f                   # generic inputs: the optimum is unique (the rest: attempts given up after the pricing step)
     print(sizes, "Hungarian stage: %d iterations, %d certified LAPs, %d fallbacks" % (inf_f[6], inf_f[12], inf_f[13]))
     # (c)
@@ -1225,9 +1225,53 @@ def test_large_solver_certified_lap_equals_scipy_and_the_scipy_order_solver(dev,
         assert float((V0f[o:o + n] - V0f[o:o + 1]).abs().max()) == 0.0, "the tie construction needs bit-identical rows of V"
         o += n
     assert torch.equal(Uf, Us) and inf_f[:8] == inf_s[:8], (inf_f, inf_s)
-    assert inf_f[12] == 0 and inf_f[13] == big * inf_f[6], inf_f
+    assert inf_f[12] == 0 and inf_f[13] + inf_f[21] == big * inf_f[6] and inf_f[21] >= big, inf_f      # [r5] constant blocks: the integer solver
     U1 = ops.gagm_one_step(apt, Wt, U0d, gr, list(sizes), None, variant=_lib.GAGM_FORCE_LARGE)[0]
     assert torch.equal(U1.cpu(), _scipy_projection(V0f, sizes)), "all-ties block: scipy's own tie rules decide"
+
+
+@pytest.mark.parametrize("sizes,seed", [((256,) * 8, 640), ((129, 64, 300, 33, 40), 641), ((512, 40, 65), 642), ((520, 100, 257), 643)])
+def test_large_solver_integer_lap_on_narrow_range_blocks_equals_scipy(dev, sizes, seed):
+    """[r5] The block behind a collapsed Sinkhorn stage: U ~ 1 / n, V agrees along the universe index to an ulp and across the nodes
+    to a few thousand ulp; no uniqueness certificate exists and scipy's tie rules decide over 528 Dijkstra steps per graph (1.2 M
+    cycles in the fp64 step-by-step solver: a quarter of the BASELINE cfg-3 solve).  Blocks of a narrow value range take the INTEGER
+    statement of the scipy-order solver (csrc/lap_device.h: lap_wave_solve_int; exact because scipy's own float64 arithmetic is
+    exact on such a block - argument in the header).  Two constructions, a Hungarian iteration entered from each:
+      U0 exactly uniform                       -> V bit-constant along the universe index, distinct node values;
+      U0 uniform x (1 + 1e-4 noise) per entry   -> the real thing: near-ties everywhere, rounding decides;
+    on both the projection IS scipy.optimize.linear_sum_assignment on the device's own V (reference utils/hungarian.py:63), it is
+    identical to the fp64 step-by-step solver's (cfg.variant = TTDG_GAGM_NO_INT_LAP), and info[21] counts one integer solve per
+    graph of 33 .. 512 nodes (a 520-node graph keeps the one-wavefront fp64 solver)."""
+    from ttdg_mgm_amd import _lib, ops
+    g = torch.Generator().manual_seed(seed)
+    M = sum(sizes)
+    # near-uniform adjacency blocks and affinities (relative noise 1e-4): the node values of V agree to ~1e-5, i.e. to a few hundred ulp
+    A = torch.zeros(M, M)
+    o = 0
+    for n in sizes:
+        A[o:o + n, o:o + n] = (1.0 / n) * (1.0 + 1e-4 * torch.randn(n, n, generator=g))
+        o += n
+    A.fill_diagonal_(0.0)
+    W = 0.3 * (1.0 + 1e-4 * torch.randn(M, M, generator=g))
+    W = 0.5 * (W + W.t())
+    ap, Wd, gr = _pack(A, sizes).to(dev), W.to(dev).contiguous(), ops.graphs(sizes)
+    big = sum(1 for n in sizes if 32 < n <= 512)
+    for noise in (0.0, 1e-4):
+        U0 = torch.cat([torch.full((n, 32), 1.0 / n) * (1.0 + noise * torch.randn(n, 32, generator=g)) for n in sizes]).to(dev).contiguous()
+        res = {}
+        for var in (0, _lib.GAGM_NO_INT_LAP):
+            cfg = ops.gagm_cfg(start_hungarian=True, max_stages=1, no_cycle_skip=True, max_iter=1, variant=var | _lib.GAGM_FORCE_LARGE)
+            Ub, info, V0 = ops.gagm_solve(ap, Wd, U0, gr, list(sizes), cfg)
+            res[var] = (Ub.cpu(), info.cpu().tolist(), V0.cpu())
+        (Uf, inf_f, V0f), (Us, inf_s, V0s) = res[0], res[_lib.GAGM_NO_INT_LAP]
+        assert torch.equal(V0f, V0s)
+        if noise == 0.0:
+            assert float((V0f - V0f[:, :1]).abs().max()) == 0.0, "V constant along the universe index, bit for bit"
+        assert torch.equal(Uf, Us) and inf_f[:8] == inf_s[:8], (noise, inf_f, inf_s)
+        assert torch.equal(Uf, _scipy_projection(V0f, sizes)), noise
+        assert inf_f[21] == big and inf_f[12] == 0 and inf_f[13] == 0, (noise, inf_f)
+        assert inf_s[21] == 0 and inf_s[13] == big, (noise, inf_s)
+        LEDGER["large_solver.integer_lap_blocks_equal_to_scipy"] += inf_f[21]
 
 
 @pytest.mark.parametrize("sizes,seed", [((256,) * 8, 630), ((129, 64, 300, 33, 40), 631), ((520, 100, 257), 632), ((200, 150), 633),

@@ -114,3 +114,4 @@ def test_lap_certificate_on_solver_sized_blocks():
         same = np.repeat(rng.normal(size=(32, 1)), nc, axis=1)
         m2, _, v2 = lc.ssp_duals(same)
         assert not lc.certificate(same, m2, v2)
+

@@ -22,7 +22,7 @@ class Graphs(C.Structure):
     _fields_ = [("G", C.c_int32), ("off", C.c_int32 * (MAX_GRAPHS + 1))]
 
 
-GAGM_LDS_PROJECTORS, GAGM_FORCE_LARGE, GAGM_FORCE_SINGLE, GAGM_256_THREADS, GAGM_COLUMN_PROJECTOR, GAGM_SCIPY_ORDER_LAP, GAGM_ONE_LAUNCH = 1, 2, 4, 8, 16, 32, 64    # ttdg_gagm_cfg_t.variant
+GAGM_LDS_PROJECTORS, GAGM_FORCE_LARGE, GAGM_FORCE_SINGLE, GAGM_256_THREADS, GAGM_COLUMN_PROJECTOR, GAGM_SCIPY_ORDER_LAP, GAGM_ONE_LAUNCH, GAGM_NO_INT_LAP = 1, 2, 4, 8, 16, 32, 64, 128    # ttdg_gagm_cfg_t.variant
 
 
 class GagmCfg(C.Structure):

@@ -799,11 +799,25 @@ __device__ __forceinline__ void gl_project_graph(const ttdg_graphs_t& gr, const 
         if (tid < NU) Unew[cs.col4row[tid] * NU + tid] = 1.f;
         for (int j = tid; j < n; j += PT) w.lapv[o + j] = cs.v[j];
       }
-      if (tid == 0) { w.lapok[g] = certified ? 1 : 0; atomicAdd(&w.lapstat[certified ? 0 : 1], 1); }
+      if (tid == 0) { w.lapok[g] = certified ? 1 : 0; if (certified) atomicAdd(&w.lapstat[0], 1); }
       GL_PHASE(3)
     }
     __syncthreads();                                                     // zeros land before the ones are written
-    if (!certified && tr && n <= PT && !(cfg.variant & TTDG_GAGM_SCIPY_ORDER_LAP)) {
+    // [r5] blocks of a narrow value range (what follows a collapsed Sinkhorn stage: scipy's tie rules decide) take the INTEGER
+    // statement of the scipy-order solver on one wavefront (lap_device.h: lap_wave_solve_int; admission + conversion of the tile by
+    // the whole workgroup, lap_certified.h: lap_int_admit) - the same decisions at a quarter of the cycles per step
+    bool intlap = false;
+    if (!certified && tr && n <= 512 && !(cfg.variant & TTDG_GAGM_SCIPY_ORDER_LAP)) {
+      intlap = !(cfg.variant & TTDG_GAGM_NO_INT_LAP) && lap_int_admit<PT>(n, vl, (int*)lscr);
+      if (intlap && wave == 0) {
+        const int b = n <= 256 ? lap_wave_solve_int<4>(n, (const int*)vl, 33) : lap_wave_solve_int<8>(n, (const int*)vl, 33);
+        wave_sync();
+        if (lane < NU) Unew[b * NU + lane] = 1.f;
+      }
+      if (tid == 0) atomicAdd(&w.lapstat[intlap ? 5 : 1], 1);      // integer scipy-order solve / fp64 step-by-step fallback
+    }
+    if (intlap) {
+    } else if (!certified && tr && n <= PT && !(cfg.variant & TTDG_GAGM_SCIPY_ORDER_LAP)) {
       // scipy-order LAP over all wavefronts of the workgroup (lap_certified.h: lap_block_solve_exact), one column per thread
       const LapBlockScratch bs = lap_block_carve(lscr, n);
       lap_block_solve_exact<PT>(n, vl, bs);
@@ -873,6 +887,7 @@ __device__ __forceinline__ void gl_write_result(const GlWs& w, const GlCtl* c, f
     info[6] = c->total; info[7] = c->stage;
     info[14] = c->cyc_p; info[15] = c->cyc_i;
     info[12] = w.lapstat[0]; info[13] = w.lapstat[1];      // Hungarian stage: certified workgroup LAPs / scipy-order fallbacks
+    info[21] = w.lapstat[5];                               // ... / narrow-range blocks solved by the integer scipy-order solver
     // info[8] is the STATUS word and nothing else (written by the cooperative kernel on a barrier failure, 0 otherwise - the caller
     // zero-initialises info).  cfg.profile != 0: info[16..20], cycles / 1024 summed over graphs and iterations:
     //   profile 1: [16] operands + S, [17] V, [18] projector (Sinkhorn + both LAPs), [19] norms / hash

@@ -422,3 +422,59 @@ __device__ __forceinline__ void lap_block_solve_exact(int nc, const float* vl, c
     if (is_col) row4col = s.row4col[j];
   }
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// [r5] Admission to the integer scipy-order solver (lap_device.h: lap_wave_solve_int) and the conversion of the block, by the whole
+// workgroup: every entry of the graph's V tile (vl[node * 33 + slot], n nodes x 32 slots) must be a normal float32, the binary
+// exponents must span <= 6, and the integer range R = (max - min) / 2^(emin - 150) must stay below 2^LAP_INT_RANGE_BITS.  Then the
+// tile is overwritten IN PLACE with the shifted integer costs of the minimisation scipy solves (cost = -V: c' = (max V - V) / q >= 0)
+// and true is returned (workgroup-uniform); otherwise the tile is untouched.  scr: 8 ints of LDS.  Every thread must call.
+template <int PT>
+__device__ __forceinline__ bool lap_int_admit(int n, float* vl, int* scr) {
+  const int tid = threadIdx.x, ne = n * 32;
+  if (tid == 0) { scr[0] = 1; scr[1] = 255; scr[2] = 0; scr[3] = 0x7fffffff; scr[4] = -0x7fffffff; }
+  __syncthreads();
+  {
+    int lo = 255, hi = 0;
+    bool ok = true;
+    for (int e = tid; e < ne; e += PT) {
+      const int ex = (__float_as_int(vl[(e >> 5) * 33 + (e & 31)]) >> 23) & 0xff;
+      ok &= ex != 0 && ex != 255;
+      lo = min(lo, ex); hi = max(hi, ex);
+    }
+    lo = wave_min_i32_dpp(lo); hi = wave_max_i32_dpp(hi);
+    if ((tid & 63) == 0) { atomicMin(&scr[1], lo); atomicMax(&scr[2], hi); }
+    if (!ok) scr[0] = 0;
+  }
+  __syncthreads();
+  const int emin = scr[1];
+  const bool narrow = scr[0] != 0 && scr[2] - emin <= 6;
+  __syncthreads();                       // (a declining workgroup reuses the scratch at once)
+  if (!narrow) return false;
+  auto as_int = [emin](float x) {
+    const int b = __float_as_int(x);
+    const int m = ((b & 0x7fffff) | 0x800000) << (((b >> 23) & 0xff) - emin);       // < 2^30
+    return b < 0 ? -m : m;
+  };
+  {
+    int lo = 0x7fffffff, hi = -0x7fffffff;
+    for (int e = tid; e < ne; e += PT) {
+      const int iv = as_int(vl[(e >> 5) * 33 + (e & 31)]);
+      lo = min(lo, iv); hi = max(hi, iv);
+    }
+    lo = wave_min_i32_dpp(lo); hi = wave_max_i32_dpp(hi);
+    if ((tid & 63) == 0) { atomicMin(&scr[3], lo); atomicMax(&scr[4], hi); }
+  }
+  __syncthreads();
+  const int vmax = scr[4];
+  const bool small = (long long)vmax - (long long)scr[3] < (1ll << LAP_INT_RANGE_BITS);
+  __syncthreads();
+  if (!small) return false;
+  for (int e = tid; e < ne; e += PT) {
+    float* p = vl + (e >> 5) * 33 + (e & 31);
+    *p = __int_as_float(vmax - as_int(*p));
+  }
+  __syncthreads();
+  return true;
+}

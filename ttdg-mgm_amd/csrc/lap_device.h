@@ -431,3 +431,115 @@ __device__ __forceinline__ int lap_wave_solve_regw(int nr, int nc, const float* 
   }
   return col4row;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// [r5] INTEGER statement of lap_wave_solve_regw for cost blocks of a narrow range - the blocks scipy's tie rules decide.
+// What follows a collapsed Sinkhorn stage (U ~ 1 / n) is a V whose entries agree to a few thousand ulp: no uniqueness certificate
+// exists (lap_certified.h), and the step-by-step fp64 solver spends ~2400 cycles per Dijkstra step on it (528 steps: 1.2 M cycles per
+// graph, a quarter of the BASELINE cfg-3 solve) in one dependent chain of two-register DPP moves and v_min_f64.
+// When every entry of the block is a normal float32 and the binary exponents span <= 6, every entry is an integer multiple of
+// q = 2^(emin - 23 - 127) below 2^30 q, and so is everything scipy's solver computes from them in float64 (sums and differences of a
+// few hundred such integers, far below 2^53): its arithmetic is EXACT, its comparisons are integer comparisons.  Two more facts:
+//   * adding a constant K to every cost changes no decision of the solver: by induction over the rows, u_i of every assigned row and
+//     every shortest-path value / minVal of a search carry the offset K, v_j does not, and each comparison has K on both sides;
+//     so the costs may be shifted to c' = c - min c >= 0, R = max c';
+//   * v_j = 0 on unassigned columns (only scanned columns change, and a scanned unassigned column is the sink), so the shortest
+//     augmenting path from the new row is at most its direct edge to a free column: minVal <= R throughout; v_j moves by at most
+//     minVal per augmentation: |v_j| <= 32 R.
+// With R < 2^17 (checked by the caller) the minimum of a scan is below 2^18 and every candidate below 2^24: int32 arithmetic
+// without overflow, and the scan's arg-min - value, then scipy's tie rule (some minimal column unassigned -> the LAST such position
+// of `remaining`, else the FIRST minimal position) - is ONE integer wavefront minimum over the key
+//     (min(spc, 2^19 - 1) << 11) | (unassigned ? 1023 - pos : 1024 + pos)          (pos < 1024; clamped values are never minimal).
+// Same steps, same decisions as lap_wave_solve_regw / oracle/lap.c / scipy, by construction and by test (the parity tests compare
+// the projection with scipy.optimize.linear_sum_assignment on the device's own V, and with cfg.variant = TTDG_GAGM_NO_INT_LAP).
+// cst: shifted integer costs, cst[col * ldc + row] (LDS), nr = 32 rows, nc <= 64 * CW columns; returns col4row of row `lane`.
+#define LAP_INT_RANGE_BITS 17
+template <int CW>
+__device__ __forceinline__ int lap_wave_solve_int(int nc, const int* cst, int ldc) {
+  // Branch-free inner loop: a column's state is five integers - v, spc, path, row4col and pos, with pos = -1 once the column has been
+  // scanned (scipy's SC set; its spc / path are frozen from then on because its candidate is replaced by BIG).
+  constexpr int CAP = (1 << 19) - 1, BIG = 1 << 30;
+  const int lane = threadIdx.x & 63;
+  int u = 0, col4row = -1;
+  int v[CW], spc[CW], row4col[CW], path[CW], pos[CW], cofs[CW], pos0[CW];
+#pragma unroll
+  for (int w = 0; w < CW; ++w) {
+    const int j = lane + 64 * w;
+    v[w] = 0; spc[w] = BIG; row4col[w] = -1; path[w] = -1;
+    pos0[w] = j < nc ? nc - 1 - j : -1;                // position in scipy's `remaining` at the start of every search
+    pos[w] = -1;
+    cofs[w] = min(j, nc - 1) * ldc;
+  }
+  for (int cur = 0; cur < 32; ++cur) {
+    int minVal = 0, nrem = nc, i = cur, sink = -1;
+    int SRm = 0;                                       // rows on the alternating tree, as a bit mask (wavefront-uniform)
+    int csgn[CW], cbase[CW], xun[CW];                  // tie code of the column = cbase + csgn * pos (row4col changes only between the rows)
+#pragma unroll
+    for (int w = 0; w < CW; ++w) {
+      pos[w] = pos0[w]; spc[w] = BIG;
+      const bool un = row4col[w] < 0;
+      csgn[w] = un ? -1 : 1; cbase[w] = un ? 1023 : 1024;
+      xun[w] = un ? -1 - (lane + 64 * w) : row4col[w];   // what the search needs to know about the column it selects: owner row, or (< 0) the sink
+    }
+    while (sink == -1) {
+      SRm |= 1 << i;
+      const int base = minVal - __builtin_amdgcn_readlane(u, i);
+      int c[CW];
+#pragma unroll
+      for (int w = 0; w < CW; ++w) c[w] = cst[cofs[w] + i];
+      int kmin = 0x7fffffff;
+#pragma unroll
+      for (int w = 0; w < CW; ++w) {
+        const int r = pos[w] >= 0 ? base + (c[w] - v[w]) : BIG;
+        path[w] = r < spc[w] ? i : path[w];
+        spc[w] = min(spc[w], r);
+        const int key = (min(spc[w], CAP) << 11) | (cbase[w] + csgn[w] * pos[w]);
+        kmin = min(kmin, pos[w] >= 0 ? key : 0x7fffffff);
+      }
+      const int gkey = wave_min_i32_dpp(kmin);
+      minVal = gkey >> 11;
+      const int code = gkey & 2047;
+      const int selpos = code < 1024 ? 1023 - code : code - 1024;
+      int xv = 0;
+      unsigned long long any = 0ull;
+      --nrem;
+#pragma unroll
+      for (int w = 0; w < CW; ++w) {
+        const bool sel = pos[w] == selpos;             // (selpos >= 0: scanned columns, at -1, never match)
+        any |= __ballot(sel);
+        xv = sel ? xun[w] : xv;
+        pos[w] = sel ? -1 : (pos[w] == nrem ? selpos : pos[w]);     // the last position moves into the hole
+      }
+      const int x = __builtin_amdgcn_readlane(xv, __builtin_ctzll(any));
+      if (x < 0) sink = -1 - x; else i = x;
+      if (nrem <= 0 && sink == -1) sink = 0;           // (cannot happen: a free column always exists; never spin)
+    }
+    // dual updates (u of the rows on the alternating tree, v of the scanned columns)
+    const int c4r = (col4row >= 0) ? col4row : 0;
+    int spc_of_my_col = 0;
+#pragma unroll
+    for (int w = 0; w < CW; ++w) {
+      const int x = __shfl(spc[w], c4r & 63, 64);
+      if ((c4r >> 6) == w) spc_of_my_col = x;
+    }
+    if (lane == cur) u += minVal;
+    else if (lane < 32 && ((SRm >> lane) & 1)) u += minVal - spc_of_my_col;
+#pragma unroll
+    for (int w = 0; w < CW; ++w) if (pos[w] < 0 && pos0[w] >= 0) v[w] -= minVal - spc[w];
+    // augment
+    int j = sink;
+    for (int guard = 0; guard < 34; ++guard) {
+      const int wj = j >> 6, lj = j & 63;
+      int r = 0;
+#pragma unroll
+      for (int w = 0; w < CW; ++w) if (w == wj) r = __builtin_amdgcn_readlane(path[w], lj);
+      const int t = __builtin_amdgcn_readlane(col4row, r);
+#pragma unroll
+      for (int w = 0; w < CW; ++w) if (w == wj && lane == lj) row4col[w] = r;
+      if (lane == r) col4row = j;
+      j = t;
+      if (r == cur) break;
+    }
+  }
+  return col4row;
+}

@@ -7,8 +7,15 @@ image shape, so the backbone's launch sequence is the same every step: it is cap
   eval mode (Dice pass, no gradient)  torch.cuda.CUDAGraph over ``backbone(x)``.  The FrozenBN folds of the ADAPTED filters are
       captured too (their caches are dropped before the capture, so every replay re-folds from the live parameters: a replay after
       a TTA step sees the adapted weights); frozen filters (stem, res2) keep their cached folds - constants for the process.
-  TTT mode (gradients)               torch.cuda.make_graphed_callables over a tuple-returning wrapper: one graph for the forward,
-      one for the backward (custom autograd Functions of ops.* launch on the capturing stream like any other kernel).
+  TTT mode (gradients)               NOT captured (round 5: the forward + backward pair through torch.cuda.make_graphed_callables was
+      removed).  tools/graph_probe.py, profiles/r05_graph_probe.txt: on the stand-alone backbone at 4 x 3 x 800 x 800 a replayed backward
+      FOLLOWS its cotangent (ratio 1.000 in every parameter group, FPN biases exact); what round 4 read as "res4 / res5 filter gradients
+      1-3 % off" is the run-to-run spread of the find-db's weight-gradient kernels (split-K with atomics: the SAME cotangent replayed
+      twice differs by 0.3-2 % of a tensor's largest entry, eager runs differ as much; with torch.backends.cudnn.deterministic or without the
+      find-db the replay equals the eager gradient to 1e-6).  Inside the model the TTT forward runs the detector heads on a side stream
+      (rcnn.forward), autograd warns that the AccumulateGrad nodes live on another stream than the captured backward, and the captured
+      step did not return (bench.py with the pair switched on: killed by the time limit after 20 minutes).  Expected gain was <= 6 %
+      (the < 15 us gaps of the step).
 
 Same kernels in the same order on the same data: a replay returns what the eager call returns (checked once, right after the
 capture, on the capture batch; a mismatch or any capture error switches the graph off for the process and the eager path runs).
@@ -20,11 +27,6 @@ import torch.nn as nn
 ENABLED = False           # OFF by default: measured on MI355X (bench.py --graphs, profiles/r04_bench_graphs_ab.json) the replayed Dice-pass
                           # forward gives 104.6 adapted images/s against 104.5 eager - the eval pass is bound by the vendor convolutions,
                           # not by its launch gaps.  Kept as an A/B switch with its parity test.
-TRAIN_GRAPHS = False      # the forward + backward pair of the TTA step: OFF.  Captured with torch.cuda.make_graphed_callables it is exact
-                          # on the stand-alone FPN at 2 x 3 x 256 x 256 (every gradient equal to the eager one), but at the bench's
-                          # 4 x 3 x 800 x 800 the replayed backward returned FPN bias gradients that did not depend on the cotangent
-                          # (stale values of the capture pass, 6e19 in one of them) and res4 / res5 filter gradients 1-3 % off: some
-                          # vendor kernel of the large shapes is not replayed.  Not understood, therefore not used (round 4).
 MAX_SHAPES = 2            # graphs kept per mode (each holds its own activation pool)
 _FEATS = ("p2", "p3", "p4", "p5", "p6")
 
@@ -45,9 +47,8 @@ class GraphedBackbone:
     def __init__(self, backbone):
         self.backbone = backbone
         self.eval_graphs = {}          # shape -> (graph, static input, static outputs)
-        self.train_graphs = {}         # shape -> graphed callable
         self.broken = False
-        self.stats = dict(eval_captures=0, train_captures=0, eval_replays=0, train_replays=0, disabled=None)
+        self.stats = dict(eval_captures=0, eval_replays=0, disabled=None)
 
     def __deepcopy__(self, memo):
         return None                    # graphs are not copied: the copy of the model captures its own (rcnn._backbone)
@@ -56,7 +57,6 @@ class GraphedBackbone:
         self.broken = True
         self.stats["disabled"] = why
         self.eval_graphs.clear()
-        self.train_graphs.clear()
 
     def usable(self, x):
         return (ENABLED and not self.broken and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled())
@@ -66,7 +66,7 @@ class GraphedBackbone:
             return None
         try:
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.backbone.parameters()):
-                return self._train(x) if TRAIN_GRAPHS else None
+                return None          # the TTA step runs eagerly (module header)
             return self._eval(x)
         except Exception as e:          # capture problems must never take the step down: eager from here on
             self._give_up("%s: %s" % (type(e).__name__, e))
@@ -113,24 +113,3 @@ class GraphedBackbone:
         g.replay()
         self.stats["eval_replays"] += 1
         return out
-
-    # ------------------------------------------------------------------------------------------------------------ TTT
-    def _train(self, x):
-        key = tuple(x.shape)
-        fn = self.train_graphs.get(key)
-        if fn is None:
-            if len(self.train_graphs) >= MAX_SHAPES:
-                return None
-            wrapped = _TupleBackbone(self.backbone)
-            wrapped.train(self.backbone.training)
-            with torch.no_grad():
-                self.backbone(x)                                         # lazily cached constants exist before the capture
-            grads = [p.grad for p in self.backbone.parameters()]         # the warm-up passes of the capture must not leave gradients
-            fn = torch.cuda.make_graphed_callables(wrapped, (x.clone(),), num_warmup_iters=2)
-            for p, g in zip(self.backbone.parameters(), grads):
-                p.grad = g
-            self.train_graphs[key] = fn
-            self.stats["train_captures"] += 1
-        outs = fn(x)
-        self.stats["train_replays"] += 1
-        return dict(zip(_FEATS, outs))
