@@ -187,22 +187,45 @@ extern "C" int ttdg_affinity_pairwise_fwd(const float* P, const float* Q, const 
 //   kRowsAreSrc = false (dQ pass): r = j (tgt node), c = i over graphs strictly after graph(j);   D = dM[c][r]
 // Workgroup = 64 rows x 64 k, thread tile 4 rows (ty*4+a) x 4 k (tx*4+b); the reduced index c is streamed in
 // slabs of 32 through LDS: Dt[c][r] (row index contiguous -> one ds_read_b128 per c) and Ys[c][k] = -Y.
+// [r5] ONE launch for both passes (blockIdx.y >= nrt: the dQ pass).  The reduced range of a row tile is block-triangular - a dP
+// row of graph g reduces over the g graphs before it, a dQ row over the G - 1 - g behind it - so the range of every (pass, row
+// tile) is cut into slices of at most `SL` slabs (nearly equal lengths inside a tile) and ONLY those slices exist: blockIdx.z
+// beyond a tile's slice count returns at once, planes that no slice writes are never read (the finish kernel derives the same
+// counts).  Round 4 cut EVERY tile into the same eight slices: workgroups of 0 .. 7 slabs, and 2 x 8 full planes (64 MB at cfg-3)
+// written and read back where 2 x 3.5 carry data.  The two passes' ranges are complementary, so one launch holds the same work
+// for every row tile.  The next slab travels global -> registers while the current one is consumed from LDS (two LDS buffers,
+// one barrier per slab; unconditional clamped loads, the mask applied on the way to LDS), as in the forward kernel.
 #define BC 32
 #define LDR (TILE + 4)
 
+// reduced range [cbeg, cend) of row tile `rt` in a pass, and the limit of every row (dP: first excluded index; dQ: first included)
+__device__ __forceinline__ void aff_bwd_range(const ttdg_graphs_t& gr, int M, bool rows_are_src, int rt, int& cbeg, int& cend) {
+  const int r0 = rt * TILE, rl = min(r0 + TILE, M) - 1;
+  if (rows_are_src) { cbeg = 0; cend = gr.off[graph_of(gr, rl)]; }
+  else { cbeg = gr.off[graph_of(gr, r0) + 1]; cend = M; }
+}
+__host__ __device__ __forceinline__ int aff_bwd_nslices(int nslab, int SL) { return (nslab + SL - 1) / SL; }
+
 template <bool kRowsAreSrc>
-__global__ __launch_bounds__(256) void affinity_bwd_kernel(const float* __restrict__ X, const float* __restrict__ Y,
-                                                           const float* __restrict__ dM, int H, ttdg_graphs_t gr,
-                                                           float* __restrict__ Opart) {
+__device__ __forceinline__ void affinity_bwd_body(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ dM,
+                                                  int H, const ttdg_graphs_t& gr, int SL, int rt, float* __restrict__ Opart,
+                                                  float (*Dt)[BC][LDR], float (*Ys)[BC][LDR], int* rlim) {
   const int M = gr.off[gr.G];
-  float* O = Opart + (size_t)blockIdx.z * M * H;       // partial plane of this slice of the reduced range
-  const int r0 = blockIdx.y * TILE, k0 = blockIdx.x * TILE;
-  __shared__ __attribute__((aligned(16))) float Dt[BC][LDR];
-  __shared__ __attribute__((aligned(16))) float Ys[BC][LDR];
-  __shared__ int rlim[TILE];  // per row: first (dP) / one-past-last excluded (dQ) reduced index
+  const int r0 = rt * TILE, k0 = blockIdx.x * TILE;
+  int cbeg, cend;
+  aff_bwd_range(gr, M, kRowsAreSrc, rt, cbeg, cend);
+  {
+    const int nslab = (cend - cbeg + BC - 1) / BC, ns = aff_bwd_nslices(nslab, SL);
+    if ((int)blockIdx.z >= ns) return;                       // this slice does not exist (its plane is never read)
+    const int per = (nslab + ns - 1) / ns;                   // nearly equal slices inside the tile
+    const int b0 = cbeg + blockIdx.z * per * BC;
+    cend = min(cend, b0 + per * BC);
+    cbeg = b0;
+  }
+  float* O = Opart + (size_t)blockIdx.z * M * H;             // partial plane of this slice
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
 
-  if (tid < TILE) {
+  if (tid < TILE) {        // rlim, per row: first excluded (dP) / first included (dQ) reduced index
     const int r = r0 + tid;
     int lim = kRowsAreSrc ? 0 : M;
     if (r < M) {
@@ -212,20 +235,6 @@ __global__ __launch_bounds__(256) void affinity_bwd_kernel(const float* __restri
     rlim[tid] = lim;
   }
   __syncthreads();
-  // reduced range for the whole tile
-  int cbeg, cend;
-  {
-    const int rl = min(r0 + TILE, M) - 1;
-    if (kRowsAreSrc) { cbeg = 0; cend = gr.off[graph_of(gr, rl)]; }
-    else { cbeg = gr.off[graph_of(gr, r0) + 1]; cend = M; }
-    // split the reduced range over gridDim.z in multiples of the slab size: more workgroups per CU (latency hiding)
-    // and an even load although the wanted blocks are block-triangular
-    const int nslab = (cend - cbeg + BC - 1) / BC;
-    const int per = (nslab + gridDim.z - 1) / gridDim.z;
-    const int b0 = cbeg + blockIdx.z * per * BC;
-    cend = min(cend, b0 + per * BC);
-    cbeg = b0;
-  }
 
   f32x2 x2[4][2], acc2[4][2];
 #pragma unroll
@@ -237,55 +246,67 @@ __global__ __launch_bounds__(256) void affinity_bwd_kernel(const float* __restri
     acc2[a][0] = acc2[a][1] = (f32x2){0.f, 0.f};
   }
 
-  for (int c0 = cbeg; c0 < cend; c0 += BC) {
-    // stage Y slab: 32 c x 64 k
-    {
-      const int c = tid >> 4, kq = (tid & 15) * 4;
+  // staging maps.  Y slab: 32 c x 64 k, thread -> (c, c + 16) x one float4 of k.  D slab as Dt[c][r]:
+  //   dP: D(r,c) = dM[r][c], global rows are r, contiguous along c -> thread (r, r + 32) x four consecutive c, transposing store;
+  //   dQ: D(r,c) = dM[c][r], global rows are c, contiguous along r -> thread r x eight c (coalesced).
+  const int yc = tid >> 4, ykq = (tid & 15) * 4;
+  const int pr = tid >> 3, pcq = (tid & 7) * 4;             // dP
+  const int qr = tid & 63, qcb = tid >> 6;                  // dQ
+  float4 yv[2];
+  float dv8[8];
+  int plim[2] = {0, 0};
+  bool prok[2] = {false, false};
+  if (kRowsAreSrc) {
 #pragma unroll
-      for (int rr = 0; rr < 2; ++rr) {
-        const int cc = c + 16 * rr;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c0 + cc < M) v = *reinterpret_cast<const float4*>(Y + (size_t)(c0 + cc) * H + k0 + kq);
-        // store -Y: relu'(x + y) = [x > -y] exactly (fp32 sums of finite values never round to 0 unless 0)
-        *reinterpret_cast<float4*>(&Ys[cc][kq]) = make_float4(-v.x, -v.y, -v.z, -v.w);
-      }
+    for (int rr = 0; rr < 2; ++rr) { prok[rr] = r0 + pr + 32 * rr < M; plim[rr] = prok[rr] ? rlim[pr + 32 * rr] : 0; }
+  }
+  const int qlim = rlim[qr];
+  const bool qrok = r0 + qr < M;
+#define AFFB_LOAD(C0)                                                                                         \
+  {                                                                                                            \
+    _Pragma("unroll") for (int rr = 0; rr < 2; ++rr)                                                           \
+      yv[rr] = *reinterpret_cast<const float4*>(Y + (size_t)min((C0) + yc + 16 * rr, M - 1) * H + k0 + ykq);   \
+    if (kRowsAreSrc) {                                                                                         \
+      _Pragma("unroll") for (int rr = 0; rr < 2; ++rr)                                                         \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                            \
+        dv8[4 * rr + e] = dM[(size_t)min(r0 + pr + 32 * rr, M - 1) * M + min((C0) + pcq + e, M - 1)];          \
+    } else {                                                                                                   \
+      _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                            \
+        dv8[e] = dM[(size_t)min((C0) + qcb + 4 * e, M - 1) * M + min(r0 + qr, M - 1)];                         \
+    }                                                                                                          \
+  }
+  if (cbeg < cend) AFFB_LOAD(cbeg)
+  int buf = 0;
+  for (int c0 = cbeg; c0 < cend; c0 += BC, buf ^= 1) {
+    // registers -> LDS: -Y (relu'(x + y) = [x > -y] exactly: fp32 sums of finite values never round to 0 unless 0), and the D slab
+    // masked to the wanted blocks (everything else contributes 0)
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const bool ok = c0 + yc + 16 * rr < M;
+      const float4 v = yv[rr];
+      *reinterpret_cast<float4*>(&Ys[buf][yc + 16 * rr][ykq]) = ok ? make_float4(-v.x, -v.y, -v.z, -v.w) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // stage D slab as Dt[c][r], masked to the wanted blocks (everything else contributes 0)
     if (kRowsAreSrc) {
-      // D(r,c) = dM[r][c]: global rows are r, contiguous along c -> transposing store
-      const int r = tid >> 3, cq = (tid & 7) * 4;
 #pragma unroll
-      for (int rr = 0; rr < 2; ++rr) {
-        const int rl = r + 32 * rr, rg = r0 + rl;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (rg < M) {
-          const int lim = rlim[rl];
+      for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int c = c0 + cq + e;
-            if (c < lim) v[e] = dM[(size_t)rg * M + c];
-          }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) Dt[cq + e][rl] = v[e];
-      }
+        for (int e = 0; e < 4; ++e) Dt[buf][pcq + e][pr + 32 * rr] = (prok[rr] && c0 + pcq + e < plim[rr]) ? dv8[4 * rr + e] : 0.f;
     } else {
-      // D(r,c) = dM[c][r]: global rows are c, contiguous along r -> direct, coalesced
-      const int rl = tid & 63, cb = tid >> 6;
-      const int rg = r0 + rl, lim = rlim[rl];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int c = cb + 4 * e, cg = c0 + c;
-        float v = 0.f;
-        if (rg < M && cg < M && cg >= lim) v = dM[(size_t)cg * M + rg];
-        Dt[c][rl] = v;
+        const int cg = c0 + qcb + 4 * e;
+        Dt[buf][qcb + 4 * e][qr] = (qrok && cg < M && cg >= qlim) ? dv8[e] : 0.f;
       }
     }
-    __syncthreads();
+    __syncthreads();          // slab c0 is in LDS; the other buffer was last read before the previous barrier
+    {
+      const int cn = c0 + BC < cend ? c0 + BC : c0;          // past the end: the same slab again (never stored)
+      AFFB_LOAD(cn)
+    }
 #pragma unroll 4
     for (int cc = 0; cc < BC; ++cc) {
-      const float4 d = *reinterpret_cast<const float4*>(&Dt[cc][ty * 4]);
-      const float4 y = *reinterpret_cast<const float4*>(&Ys[cc][tx * 4]);
+      const float4 d = *reinterpret_cast<const float4*>(&Dt[buf][cc][ty * 4]);
+      const float4 y = *reinterpret_cast<const float4*>(&Ys[buf][cc][tx * 4]);
       const float dv[4] = {d.x, d.y, d.z, d.w};
       const f32x2 y01 = {y.x, y.y}, y23 = {y.z, y.w};
 #pragma unroll
@@ -298,8 +319,8 @@ __global__ __launch_bounds__(256) void affinity_bwd_kernel(const float* __restri
         acc2[a][1] = __builtin_elementwise_fma(relu_step2(x2[a][1] - y23), (f32x2){dv[a], dv[a]}, acc2[a][1]);
       }
     }
-    __syncthreads();
   }
+#undef AFFB_LOAD
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int r = r0 + ty * 4 + a;
@@ -308,11 +329,26 @@ __global__ __launch_bounds__(256) void affinity_bwd_kernel(const float* __restri
   }
 }
 
+// grid (H / 64, 2 * nrt, max slices): blockIdx.y < nrt -> S planes (dP pass: X = P, Y = Q), else R planes (dQ pass: X = Q, Y = P)
+__global__ __launch_bounds__(256) void affinity_bwd_kernel(const float* __restrict__ P, const float* __restrict__ Q,
+                                                           const float* __restrict__ dM, int H, ttdg_graphs_t gr, int SL, int nrt,
+                                                           float* __restrict__ Spart, float* __restrict__ Rpart) {
+  __shared__ __attribute__((aligned(16))) float Dt[2][BC][LDR];
+  __shared__ __attribute__((aligned(16))) float Ys[2][BC][LDR];
+  __shared__ int rlim[TILE];
+  if ((int)blockIdx.y < nrt) affinity_bwd_body<true>(P, Q, dM, H, gr, SL, blockIdx.y, Spart, Dt, Ys, rlim);
+  else affinity_bwd_body<false>(Q, P, dM, H, gr, SL, blockIdx.y - nrt, Rpart, Dt, Ys, rlim);
+}
+
 // finish, stage 1: S = sum of the partial planes; dP = w2 * S, dQ = w2 * R; per 64-row chunk the partial column sums
-// of P*S + Q*R (-> dw2) and of dM over the wanted blocks (-> db2).  Grid (H/64, ceil(M/64)).
+// of P*S + Q*R (-> dw2) and of dM over the wanted blocks (-> db2).  Grid (H/64, ceil(M/FR)): a chunk of FR = 16 rows lies inside
+// one row tile of the accumulate kernel, so the number of planes that carry its rows is one number per pass (aff_bwd_range /
+// aff_bwd_nslices).  [r5] 16 rows per workgroup instead of 64: every wavefront walks its rows one after the other with one L2 / HBM
+// round trip per row, and 256 workgroups of sixteen such trips took 56 us for 40 MB at cfg-3; now four trips on 1024 workgroups.
+#define FR 16
 __global__ __launch_bounds__(256) void affinity_bwd_finish_kernel(const float* __restrict__ P, const float* __restrict__ Q,
                                                                   const float* __restrict__ w2, const float* __restrict__ dM,
-                                                                  int H, ttdg_graphs_t gr, int nsplit,
+                                                                  int H, ttdg_graphs_t gr, int SL,
                                                                   const float* __restrict__ Spart, const float* __restrict__ Rpart,
                                                                   float* __restrict__ dP, float* __restrict__ dQ,
                                                                   float* __restrict__ dw2part, float* __restrict__ db2part) {
@@ -320,18 +356,26 @@ __global__ __launch_bounds__(256) void affinity_bwd_finish_kernel(const float* _
   const int M = gr.off[gr.G];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + lane;
-  const int m0 = blockIdx.y * 64, m1 = min(M, m0 + 64);
+  const int m0 = blockIdx.y * FR, m1 = min(M, m0 + FR);
+  int nS, nR;
+  {
+    int cb, ce;
+    aff_bwd_range(gr, M, true, m0 / TILE, cb, ce);
+    nS = aff_bwd_nslices((ce - cb + BC - 1) / BC, SL);
+    aff_bwd_range(gr, M, false, m0 / TILE, cb, ce);
+    nR = aff_bwd_nslices((ce - cb + BC - 1) / BC, SL);
+  }
   const float w = w2[k];
   const size_t plane = (size_t)M * H;
   float s = 0.f;
   for (int m = m0 + wave; m < m1; m += 4) {
     const size_t o = (size_t)m * H + k;
-    // all partial planes of this element in flight together (nsplit <= 16), then a fixed-order sum
+    // all partial planes of this element in flight together (<= 16 per pass), then a fixed-order sum
     float sp[16], rp[16];
 #pragma unroll
     for (int z = 0; z < 16; ++z) {
-      sp[z] = (z < nsplit) ? Spart[z * plane + o] : 0.f;
-      rp[z] = (z < nsplit) ? Rpart[z * plane + o] : 0.f;
+      sp[z] = (z < nS) ? Spart[z * plane + o] : 0.f;
+      rp[z] = (z < nR) ? Rpart[z * plane + o] : 0.f;
     }
     float sv = 0.f, rv = 0.f;
 #pragma unroll
@@ -359,22 +403,36 @@ __global__ __launch_bounds__(256) void affinity_bwd_finish_kernel(const float* _
   }
 }
 
-// finish, stage 2: fixed-order sums over the row chunks
-__global__ __launch_bounds__(64) void affinity_bwd_reduce_kernel(const float* __restrict__ dw2part, const float* __restrict__ db2part,
+// finish, stage 2: fixed-order sums over the row chunks.  Workgroup = 64 k x 4 wavefronts: wavefront w adds the chunks w, w + 4, ...
+// in order, the four partials meet in LDS in a fixed tree; db2 (workgroup 0): thread t adds partials t, t + 256, ..., then a
+// fixed tree over the 256 threads.  Deterministic, and no thread walks more than nchunk / 4 dependent loads.
+__global__ __launch_bounds__(256) void affinity_bwd_reduce_kernel(const float* __restrict__ dw2part, const float* __restrict__ db2part,
                                                                  int H, int nchunk, float* __restrict__ dw2, float* __restrict__ db2) {
-  const int k = blockIdx.x * 64 + threadIdx.x;
-  if (k < H) {
-    float s = 0.f;
-    for (int c = 0; c < nchunk; ++c) s += dw2part[(size_t)c * H + k];
-    dw2[k] = s;
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  __shared__ float red[4][64];
+  __shared__ float redb[256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (k < H)
+    for (int c = wave; c < nchunk; c += 4) s += dw2part[(size_t)c * H + k];
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && k < H) dw2[k] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (blockIdx.x == 0) {
     float t = 0.f;
-    for (int c = 0; c < nchunk * (H / 64); ++c) t += db2part[c];      // one partial per (row chunk, column slice)
-    *db2 = t;
+    const int np = nchunk * (H / 64);                                  // one partial per (row chunk, column slice)
+    for (int c = threadIdx.x; c < np; c += 256) t += db2part[c];
+    redb[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) redb[threadIdx.x] += redb[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) *db2 = redb[0];
   }
 }
 
+// planes the workspace holds per pass (an upper bound of every tile's slice count: the slice length is chosen accordingly)
 static int affinity_bwd_nsplit(int M, int H) {
   const int base = (H / TILE) * ((M + TILE - 1) / TILE);
   int ns = (2048 + base - 1) / base;                 // aim at ~8 workgroups per CU
@@ -385,7 +443,7 @@ static int affinity_bwd_nsplit(int M, int H) {
 }
 
 extern "C" size_t ttdg_affinity_bwd_workspace_bytes(int M, int H) {
-  const int ns = affinity_bwd_nsplit(M, H), nchunk = (M + 63) / 64;
+  const int ns = affinity_bwd_nsplit(M, H), nchunk = (M + FR - 1) / FR;
   return ((size_t)2 * ns * M * H + (size_t)nchunk * H + (size_t)nchunk * (H / TILE) + 16) * sizeof(float);
 }
 
@@ -396,17 +454,32 @@ extern "C" int ttdg_affinity_pairwise_bwd(const float* P, const float* Q, const 
   if (int e = ttdg_validate_graphs(gr)) return e;
   TTDG_REQUIRE(H % TILE == 0, "affinity_bwd: H must be a multiple of 64");
   const int M = gr.off[gr.G];
-  const int ns = affinity_bwd_nsplit(M, H), nchunk = (M + 63) / 64;
+  const int nsmax = affinity_bwd_nsplit(M, H), nchunk = (M + FR - 1) / FR, nrt = (M + TILE - 1) / TILE, nkt = H / TILE;
+  // slice length (slabs): ~7 slices of work per CU over both passes, and no tile with more slices than the workspace has planes
+  // (host-side restatement of aff_bwd_range)
+  long total = 0;
+  int longest = 0;
+  for (int rt = 0, g0 = 0, g1 = 0; rt < nrt; ++rt) {
+    const int r0 = rt * TILE, rl = (r0 + TILE < M ? r0 + TILE : M) - 1;
+    while (r0 >= gr.off[g0 + 1]) ++g0;
+    while (rl >= gr.off[g1 + 1]) ++g1;
+    const int sp = (gr.off[g1] + BC - 1) / BC, sq = (M - gr.off[g0 + 1] + BC - 1) / BC;
+    total += sp + sq;
+    longest = sp > longest ? sp : longest;
+    longest = sq > longest ? sq : longest;
+  }
+  int SL = (int)((total * nkt + 1791) / 1792);
+  if (SL < (longest + nsmax - 1) / nsmax) SL = (longest + nsmax - 1) / nsmax;
+  if (SL < 1) SL = 1;
+  const int nz = longest > 0 ? (longest + SL - 1) / SL : 1;
   float* Spart = (float*)ws;
-  float* Rpart = Spart + (size_t)ns * M * H;
-  float* dw2part = Rpart + (size_t)ns * M * H;
+  float* Rpart = Spart + (size_t)nsmax * M * H;
+  float* dw2part = Rpart + (size_t)nsmax * M * H;
   float* db2part = dw2part + (size_t)nchunk * H;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(H / TILE, (M + TILE - 1) / TILE, ns);
-  hipLaunchKernelGGL((affinity_bwd_kernel<true>), grid, dim3(256), 0, st, P, Q, dM, H, gr, Spart);
-  hipLaunchKernelGGL((affinity_bwd_kernel<false>), grid, dim3(256), 0, st, Q, P, dM, H, gr, Rpart);
-  hipLaunchKernelGGL(affinity_bwd_finish_kernel, dim3(H / 64, nchunk), dim3(256), 0, st, P, Q, w2, dM, H, gr, ns, Spart, Rpart,
+  hipLaunchKernelGGL(affinity_bwd_kernel, dim3(nkt, 2 * nrt, nz), dim3(256), 0, st, P, Q, dM, H, gr, SL, nrt, Spart, Rpart);
+  hipLaunchKernelGGL(affinity_bwd_finish_kernel, dim3(H / 64, nchunk), dim3(256), 0, st, P, Q, w2, dM, H, gr, SL, Spart, Rpart,
                      dP, dQ, dw2part, db2part);
-  hipLaunchKernelGGL(affinity_bwd_reduce_kernel, dim3((H + 63) / 64), dim3(64), 0, st, dw2part, db2part, H, nchunk, dw2, db2);
+  hipLaunchKernelGGL(affinity_bwd_reduce_kernel, dim3((H + 63) / 64), dim3(256), 0, st, dw2part, db2part, H, nchunk, dw2, db2);
   return ttdg_launch_status("affinity_bwd");
 }
