@@ -258,6 +258,38 @@ def test_mha_dropout_statistics(dev):
     assert not torch.equal(a1 != 0, a2 != 0)                              # seed changes the mask
 
 
+def test_mha_adjacency_large_graphs_vs_float64(dev):
+    """[r5] graphs of 128+ nodes take another route (csrc/mha.hip: scores by the grouped MFMA GEMM straight into the packed blocks,
+    row softmax in place): ragged batch incl. a small graph beside large ones, against softmax(q k^T * 256^-0.5) in float64
+    (reference utils/attentions.py:72-86), diagonal zeroed (multi_graph_matching.py:502); with dropout the survivors are the
+    rescaled values and the mask is the one the per-row kernel draws for the same (seed, graph, row, column)."""
+    from ttdg_mgm_amd import ops
+    sizes, d = [256, 130, 300, 64], 256
+    g = synth.gen(77)
+    M = sum(sizes)
+    q, k = synth.normal(g, (M, d), 0.3), synth.normal(g, (M, d), 0.3)
+    gr = ops.graphs(sizes)
+    a = ops.mha_adjacency(q.to(dev), k.to(dev), gr, sizes, d ** -0.5, 0.0, 1, zero_diag=True).cpu()
+    ad = ops.mha_adjacency(q.to(dev), k.to(dev), gr, sizes, d ** -0.5, 0.1, 9, zero_diag=True).cpu()
+    o = oa = 0
+    for gi, n in enumerate(sizes):
+        ref = torch.softmax((q[o:o + n].double() @ k[o:o + n].double().t()) * d ** -0.5, dim=1)
+        ref.fill_diagonal_(0.0)
+        blk, blkd = a[oa:oa + n * n].view(n, n), ad[oa:oa + n * n].view(n, n)
+        assert float((blk.double() - ref).abs().max()) <= 1e-5, gi
+        kept = blkd != 0
+        off_diag = ~torch.eye(n, dtype=torch.bool)
+        assert 0.85 < float(kept[off_diag].float().mean()) < 0.95
+        assert float((blkd[kept].double() - (ref / 0.9)[kept]).abs().max()) <= 1e-5
+        o += n
+        oa += n * n
+    # mask identity across the two routes: graph 0 of a batch [64] (per-row kernel) against graph 0 of a batch [64, 256] (GEMM route)
+    q2, k2 = q[:64 + 256].to(dev), k[:64 + 256].to(dev)
+    m_small = ops.mha_adjacency(q2[:64], k2[:64], ops.graphs([64]), [64], d ** -0.5, 0.1, 5, zero_diag=True).view(64, 64) != 0
+    m_large = ops.mha_adjacency(q2, k2, ops.graphs([64, 256]), [64, 256], d ** -0.5, 0.1, 5, zero_diag=True)[:64 * 64].view(64, 64) != 0
+    assert torch.equal(m_small, m_large)
+
+
 # ------------------------------------------------------------------------------------------- A5
 SK_CASES = [  # b, r, c, dummy, tau, iters, n1, n2
     (1, 9, 14, True, 0.05, 20, None, None), (1, 14, 9, True, 0.05, 20, None, None), (3, 16, 16, False, 0.5, 21, None, None),
