@@ -61,6 +61,15 @@ __global__ __launch_bounds__(256) void perm_loss_pair_kernel(const float* __rest
   float acc = 0.f;
   bool bad = false;
   const int j = j0 + tx;
+  // [r5] the thread's sixteen entries of Wds are requested together (clamped addresses, used only where valid): with the load inside
+  // the loop every row paid its own round trip behind the previous row's logarithms (22 us for the 448 tiles of cfg-3)
+  float sv[PL_TILE / 4];
+#pragma unroll
+  for (int rr = 0; rr < PL_TILE / 4; ++rr) {
+    const int i = min(i0 + ty * (PL_TILE / 4) + rr, na - 1);
+    sv[rr] = Wds[(size_t)(gr.off[a] + i) * M + gr.off[b] + min(j, nb - 1)];
+  }
+#pragma unroll
   for (int rr = 0; rr < PL_TILE / 4; ++rr) {
     const int il = ty * (PL_TILE / 4) + rr, i = i0 + il;
     if (i >= na || j >= nb) continue;
@@ -73,7 +82,7 @@ __global__ __launch_bounds__(256) void perm_loss_pair_kernel(const float* __rest
     }
     const float t = t0 + t1;
     const size_t o = (size_t)(gr.off[a] + i) * M + gr.off[b] + j;
-    const float s = Wds[o];
+    const float s = sv[rr];
     bad |= !(s >= 0.f && s <= 1.f) || !(t >= 0.f && t <= 1.f);
     const float p = fminf(fmaxf(s, eps), 1.f - eps);
     const float lp = logf(p), lq = logf(1.f - p);
@@ -91,19 +100,39 @@ __global__ __launch_bounds__(256) void perm_loss_pair_kernel(const float* __rest
 }
 
 // loss = (1/#pairs) * sum_pairs (sum of the pair's tiles, in tile order) / (na nb)
-__global__ void perm_loss_finish_kernel(const float* __restrict__ tile_loss, ttdg_graphs_t gr, float* __restrict__ loss) {
-  float s = 0.f;
-  int wg = 0, npairs = 0;
-  for (int b = 1; b < gr.G; ++b)
-    for (int a = 0; a < b; ++a, ++npairs) {
-      const int na = gr.off[a + 1] - gr.off[a], nb = gr.off[b + 1] - gr.off[b];
-      const int nt = pl_tiles_d(na) * pl_tiles_d(nb);
-      float ps = 0.f;
-      for (int k = 0; k < nt; ++k) ps += tile_loss[wg + k];
-      wg += nt;
-      s += ps / ((float)na * (float)nb);
-    }
-  *loss = s / (float)npairs;
+// [r5] one workgroup: thread 0 lays out the pairs' tile ranges (arithmetic only), every thread adds the tiles of its pairs in tile
+// order, thread 0 adds the pairs in pair order - the same sums in the same order as the one-thread walk over all tiles it replaces
+// (448 dependent loads at cfg-3: 22 us).
+#define PL_MAXPAIRS (TTDG_MAX_GRAPHS * (TTDG_MAX_GRAPHS - 1) / 2)
+__global__ __launch_bounds__(256) void perm_loss_finish_kernel(const float* __restrict__ tile_loss, ttdg_graphs_t gr, float* __restrict__ loss) {
+  __shared__ int pbeg[PL_MAXPAIRS + 1];
+  __shared__ float pinv[PL_MAXPAIRS], psum[PL_MAXPAIRS];
+  __shared__ int s_np;
+  if (threadIdx.x == 0) {
+    int wg = 0, npairs = 0;
+    for (int b = 1; b < gr.G; ++b)
+      for (int a = 0; a < b; ++a, ++npairs) {
+        const int na = gr.off[a + 1] - gr.off[a], nb = gr.off[b + 1] - gr.off[b];
+        pbeg[npairs] = wg;
+        pinv[npairs] = (float)na * (float)nb;
+        wg += pl_tiles_d(na) * pl_tiles_d(nb);
+      }
+    pbeg[npairs] = wg;
+    s_np = npairs;
+  }
+  __syncthreads();
+  const int npairs = s_np;
+  for (int p = threadIdx.x; p < npairs; p += 256) {
+    float ps = 0.f;
+    for (int k = pbeg[p]; k < pbeg[p + 1]; ++k) ps += tile_loss[k];
+    psum[p] = ps / pinv[p];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int p = 0; p < npairs; ++p) s += psum[p];
+    *loss = s / (float)npairs;
+  }
 }
 
 static int pl_total_tiles(const ttdg_graphs_t& gr) {
@@ -128,6 +157,6 @@ extern "C" int ttdg_perm_loss_fwd_bwd(const float* Wds, const float* U, ttdg_gra
   TTDG_HIP(hipMemsetAsync(dWds, 0, (size_t)M * M * sizeof(float), st));
   TTDG_HIP(hipMemsetAsync(flag, 0, sizeof(int32_t), st));
   hipLaunchKernelGGL(perm_loss_pair_kernel, dim3(pl_total_tiles(gr)), dim3(256), 0, st, Wds, U, gr, alpha, eps, pair_ws, dWds, flag);
-  hipLaunchKernelGGL(perm_loss_finish_kernel, dim3(1), dim3(1), 0, st, pair_ws, gr, loss);
+  hipLaunchKernelGGL(perm_loss_finish_kernel, dim3(1), dim3(256), 0, st, pair_ws, gr, loss);
   return ttdg_launch_status("perm_loss");
 }

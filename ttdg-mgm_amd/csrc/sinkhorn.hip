@@ -274,6 +274,22 @@ __device__ __forceinline__ void skr_tile_store(float* __restrict__ base, int64_t
     skr_quad_store<kAlongQ>(base, sp, sq, p0 + 4 * k, q0, r, c, [&](int t, int j) { return val(4 * k + t, j); });
 }
 
+// [r5] column totals of a sweep: every wavefront has written its 256 partials to s_part[wave][.] and the workgroup has met.  Rounds 1-4
+// (and the first scaling-form build) let EVERY wavefront add all sixteen partials of its lanes' columns - 16 x 16 KB of LDS reads per
+// sweep, ~2000 cycles of the LDS port, more than the sweep's arithmetic.  Here the first four wavefronts add one column per thread
+// (the sixteen partials in the same order as before: bit-identical totals), the totals go through 1 KB of LDS and a second barrier.
+__device__ __forceinline__ void skr_column_totals(const float* __restrict__ sp, float* __restrict__ s_col, int tid, int q0, float (&cs)[4]) {
+  if (tid < SKR_C) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < SKR_WAVES; ++w) t += sp[w * SKR_C + tid];
+    s_col[tid] = t;
+  }
+  __syncthreads();
+  const float4 t4 = *reinterpret_cast<const float4*>(&s_col[q0]);
+  cs[0] = t4.x; cs[1] = t4.y; cs[2] = t4.z; cs[3] = t4.w;
+}
+
 // kFlip: the instantiation handles the blocks of that orientation only (rows <= cols after transposition or not) and returns at once
 // on the others - the orientation decides which index is contiguous in memory, and one compiled path per kernel keeps the 64 registers
 // of K next to everything else without spills.  The host launches the instantiation(s) the batch needs (cfg-3: equal sizes, one launch).
@@ -283,6 +299,7 @@ __global__ __launch_bounds__(SKR_THREADS) void sinkhorn_pairs_fwd_scale_kernel(c
                                                                                int iters, float* __restrict__ Wds,
                                                                                float* __restrict__ pot, int cmax) {
   __shared__ __attribute__((aligned(16))) float s_part[2][SKR_WAVES * SKR_C];
+  __shared__ __attribute__((aligned(16))) float s_col[SKR_C];
   __shared__ int s_bad;
   int a, b;
   pair_of(blockIdx.x, gr.G, a, b);
@@ -372,12 +389,8 @@ __global__ __launch_bounds__(SKR_THREADS) void sinkhorn_pairs_fwd_scale_kernel(c
       *reinterpret_cast<float4*>(&s_part[buf][wave * SKR_C + q0]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
       __syncthreads();
       if (s_bad) break;                  // set before this barrier by some wavefront's row sweep: uniform over the workgroup
-      float cs[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int w = 0; w < SKR_WAVES; ++w) {
-        const float4 t = *reinterpret_cast<const float4*>(&s_part[buf][w * SKR_C + q0]);
-        cs[0] += t.x; cs[1] += t.y; cs[2] += t.z; cs[3] += t.w;
-      }
+      float cs[4];
+      skr_column_totals(s_part[buf], s_col, tid, q0, cs);
       buf ^= 1;
       bool cbad = false;
       float gq[4];
@@ -805,6 +818,7 @@ __global__ __launch_bounds__(SKR_THREADS) void sinkhorn_pairs_bwd_scale_kernel(c
   float* s_u = s_b + iters * SKR_C;                    // [iters + 1][256]  u^(k)_p;  index `iters` = the final state
   float* s_v = s_u + (iters + 1) * SKR_C;              // [iters + 1][256]  v^(k)_q
   float* s_ud = s_v + (iters + 1) * SKR_C;             // [iters + 1]       u^(k) of the dummy row
+  float* s_col = s_ud + ((iters + 1 + 3) & ~3);        // [256]             column totals of a sweep (skr_column_totals)
   int a = 1, idx = blockIdx.x;
   while (idx >= a) { idx -= a; ++a; }
   const int b = idx;
@@ -899,13 +913,7 @@ __global__ __launch_bounds__(SKR_THREADS) void sinkhorn_pairs_bwd_scale_kernel(c
     }
     *reinterpret_cast<float4*>(&s_part[(buf * SKR_WAVES + wave) * SKR_C + q0]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) cs[j] = 0.f;
-#pragma unroll
-    for (int w = 0; w < SKR_WAVES; ++w) {
-      const float4 t = *reinterpret_cast<const float4*>(&s_part[(buf * SKR_WAVES + w) * SKR_C + q0]);
-      cs[0] += t.x; cs[1] += t.y; cs[2] += t.z; cs[3] += t.w;
-    }
+    skr_column_totals(&s_part[(buf * SKR_WAVES) * SKR_C], s_col, tid, q0, cs);
     buf ^= 1;
   }
 
@@ -949,12 +957,8 @@ __global__ __launch_bounds__(SKR_THREADS) void sinkhorn_pairs_bwd_scale_kernel(c
       }
       *reinterpret_cast<float4*>(&s_part[(buf * SKR_WAVES + wave) * SKR_C + q0]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
       __syncthreads();
-      float ks[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int w = 0; w < SKR_WAVES; ++w) {
-        const float4 t = *reinterpret_cast<const float4*>(&s_part[(buf * SKR_WAVES + w) * SKR_C + q0]);
-        ks[0] += t.x; ks[1] += t.y; ks[2] += t.z; ks[3] += t.w;
-      }
+      float ks[4];
+      skr_column_totals(&s_part[(buf * SKR_WAVES) * SKR_C], s_col, tid, q0, ks);
       buf ^= 1;
 #pragma unroll
       for (int j = 0; j < 4; ++j) cs[j] = __builtin_fmaf(-v[j], ks[j], cs[j]);
@@ -1017,7 +1021,7 @@ extern "C" int ttdg_sinkhorn_pairs_bwd(const float* part, int ksplit, const floa
     return ttdg_launch_status("sinkhorn_pairs_bwd_reg");
   }
   if (cmax > 128 && cmax <= SKR_C && ksplit == 1) {
-    const size_t skb = (size_t)(2 * SKR_WAVES * SKR_C + (4 * iters + 2) * SKR_C + 64) * sizeof(float);   // column partials + the (a, b) log + the (u, v) tables (117 KB at iters = 20); the cold path's 4 (c + 1) floats fit inside
+    const size_t skb = (size_t)(2 * SKR_WAVES * SKR_C + (4 * iters + 2) * SKR_C + 72 + SKR_C) * sizeof(float);   // column partials + the (a, b) log + the (u, v) tables (117 KB at iters = 20); the cold path's 4 (c + 1) floats fit inside
     bool plain, flipped;
     skr_orientations(gr, plain, flipped);
     skr_launch_block_transpose(dWds, dM, gr, cmax, false, st);             // dM(a, b) <- dWds(b, a)^T: the kernels below work in place
