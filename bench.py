@@ -495,10 +495,28 @@ def plumbing_only(args, rank, world):
     t = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ev.gather_scores()
+    # the strong-scaling pass of a launch, with stand-in clocks: rank r "spends" (r + 1) ms on its shard of the fixed stream, rank 0 alone
+    # 1 ms per rank's share x 0.9: same barrier, same max over the ranks, same arithmetic (strong_record) as the GPU pass
+    T = max(1, args.strong_images // (world * B)) * world * B
+    ts = torch.tensor([0.001 * (rank + 1)], dtype=torch.float64)
+    dist.barrier()
+    dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+    strong = strong_record(T, float(ts[0]), 0.001 * world * 0.9, world, B) if rank == 0 else None
     if rank == 0:
-        print(json.dumps({"plumbing_only": True, "n_gpus": world, "ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
+        print(json.dumps({"plumbing_only": True, "strong": strong, "n_gpus": world, "ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
                           "steps": K, "shard_rank0": [lo, hi], "images_total": n, "max_time": float(t[0]),
                           "gathered_scores": len(ev.dice_scores), "scaling": "strong" if args.images else "weak"}))
+
+
+def strong_record(T, elapsed_sharded, elapsed_solo, world, B):
+    """The strong-scaling arithmetic of a launch (rank 0): `elapsed_sharded` = the max-over-ranks time of the fixed T-image stream
+    sharded over `world` ranks, `elapsed_solo` = rank 0 alone on the whole stream in the same process.  Shared by the GPU pass and
+    by --plumbing-only (CPU test), so the first real 8-GPU launch computes its efficiency with tested code."""
+    return {"images": T, "value": T / elapsed_sharded, "unit": "images/s", "n1_value_same_stream": T / elapsed_solo,
+            "efficiency_vs_n1": (T / elapsed_sharded) / (world * T / elapsed_solo), "steps_per_rank": T // (world * B),
+            "ranks": dist.get_world_size(), "backend": dist.get_backend(),
+            "note": "fixed %d-image stream sharded over the ranks (continual TTA per shard, then the Dice pass + RCCL score all-gather); "
+                    "n1 = rank 0 alone on the whole stream, same process, other ranks idle" % T}
 
 
 def steps_per_rank(args, world):
@@ -672,11 +690,8 @@ def gpu_main(args, rank, world, local):
         BaselineTrainer.rank, BaselineTrainer.world = rank, world
         dist.barrier()
         if rank == 0:
-            strong = {"images": T, "value": T / rs["elapsed"], "unit": "images/s", "n1_value_same_stream": T / solo["elapsed"],
-                      "efficiency_vs_n1": (T / rs["elapsed"]) / (world * T / solo["elapsed"]), "steps_per_rank": T // (world * B),
-                      "ranks": dist.get_world_size(), "backend": dist.get_backend(), "dice": rs["dice"], "kept_masks": rs["kept_masks"],
-                      "note": "fixed %d-image stream sharded over the ranks (continual TTA per shard, then the Dice pass + RCCL score all-gather); "
-                              "n1 = rank 0 alone on the whole stream, same process, other ranks idle" % T}
+            strong = strong_record(T, rs["elapsed"], solo["elapsed"], world, B)
+            strong.update(dice=rs["dice"], kept_masks=rs["kept_masks"])
         note("strong-scaling pass done")
         del sb, sd
 

@@ -342,6 +342,9 @@ def test_bench_launches_its_own_ranks():
         line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["backend"] == "gloo" and line["gathered_scores"] == 3
         assert abs(line["max_time"] - 0.002) < 1e-9
+        st = line["strong"]                            # stand-in clocks: sharded 2 ms (max over the ranks), rank 0 alone 1.8 ms
+        assert st["images"] == 512 and st["steps_per_rank"] == 64 and st["ranks"] == 2
+        assert abs(st["value"] - 512 / 0.002) < 1e-6 and abs(st["efficiency_vs_n1"] - 0.0018 / (2 * 0.002)) < 1e-12
         for k, v in want.items():
             assert line[k] == v, (k, line)
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--plumbing-only", "--images", "30"],

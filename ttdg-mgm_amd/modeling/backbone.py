@@ -219,28 +219,34 @@ class ResNet50(nn.Module):
     autocast_upto = None
     _ORDER = ("stem", "res2", "res3", "res4", "res5")
 
+    def _in_island(self, name):
+        return self._ORDER.index(name) <= self._ORDER.index(self.autocast_upto)
+
     def _run(self, name, mod, x):
-        upto = self.autocast_upto
-        if upto is None:
+        """``x`` is already fp32 for a stage behind the island (forward up-casts ONCE per stage boundary)."""
+        if self.autocast_upto is None:
             return mod(x)
-        if self._ORDER.index(name) <= self._ORDER.index(upto):
+        if self._in_island(name):
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 return mod(x)
-        return mod(x.float())
+        return mod(x)
 
     def forward(self, x):
         x = self._run("stem", self.stem, x)
         outs = []
         for name in ("res2", "res3", "res4", "res5"):
             stage = getattr(self, name)
-            island = self.autocast_upto is not None and self._ORDER.index(name) <= self._ORDER.index(self.autocast_upto)
-            staged = None if island else _fold_stage(stage, x.float() if self.autocast_upto is not None else x)
+            islands = self.autocast_upto is not None
+            island = islands and self._in_island(name)
+            if islands and not island and x.dtype != torch.float32:
+                x = x.float()                      # the one up-cast at the island's edge: fold, stage and feature map share it
+            staged = None if island else _fold_stage(stage, x)
             try:
                 x = self._run(name, stage, x)
             finally:
                 for c in staged or ():
                     c._staged_w = None
-            outs.append(x.float() if self.autocast_upto is not None else x)
+            outs.append(x.float() if islands and x.dtype != torch.float32 else x)
         return tuple(outs)
 
 

@@ -106,9 +106,11 @@ class GraphedBackbone:
                     if not float((out[k] - ref[k]).abs().max()) <= 1e-5 * max(1.0, float(ref[k].abs().max())):
                         self._give_up("eval replay differs from the eager forward on %s" % k)
                         return None
-            ent = self.eval_graphs[key] = (g, static_in, out)
+            ent = self.eval_graphs[key] = (g, static_in, out, torch.cuda.current_stream(x.device))
             self.stats["eval_captures"] += 1
-        g, static_in, out = ent
+        g, static_in, out, home = ent
+        if torch.cuda.current_stream(x.device) != home:
+            return None          # static input / outputs belong to the stream of the capture: another stream's inference runs eagerly
         static_in.copy_(x)
         g.replay()
         self.stats["eval_replays"] += 1
