@@ -501,3 +501,22 @@ def test_mode_s_flattens_gradients_in_the_parameters_storage_order():
     assert su.storage_flat(q, q).data_ptr() == q.data_ptr() and torch.equal(su.storage_unflat(q.reshape(-1), q), q)
     one = torch.randn(8, 1, 1, 1)              # both layouts at once: stays the plain path
     assert su.storage_flat(one, one).data_ptr() == one.data_ptr()
+
+
+def test_evaluator_centroids_batched_equals_the_per_mask_form():
+    """ground-truth centroids of a streamed item are computed in ONE batched reduction (one host read per image, not one
+    per annotation); same exact integer sums as the per-mask form (reference dice_metric.py:196-200), NaN for an empty map."""
+    import math
+    import torch
+    from ttdg_mgm_amd.evaluation import DiceEvaluator
+    g = torch.Generator().manual_seed(3)
+    masks = [torch.rand(37, 53, generator=g) > t for t in (0.5, 0.9, 0.999, 2.0)]
+    cens = DiceEvaluator._centroids(masks)
+    for m, (cy, cx) in zip(masks, cens):
+        n = int(m.sum())
+        if n == 0:
+            assert math.isnan(cy) and math.isnan(cx)
+            continue
+        ys, xs = torch.nonzero(m, as_tuple=True)
+        assert cy == float(ys.sum()) / n and cx == float(xs.sum()) / n
+    assert DiceEvaluator._centroids([]) == [] and DiceEvaluator._centroid(masks[0]) == cens[0]

@@ -172,15 +172,21 @@ class DiceEvaluator:
         self._pending = []
 
     @staticmethod
+    def _centroids(masks):
+        """(mean row, mean column) of the set pixels of every boolean map of a list - what dice_metric.py:196-200 derives from the
+        GT - from the row / column histograms (exact: integer sums), NaN for an empty map.  ONE batched reduction and one host read
+        for the whole list, wherever the maps live (a streamed item may carry its ground truth as device tensors only)."""
+        if not masks:
+            return []
+        m = torch.stack(list(masks))
+        rows, cols = m.sum(2, dtype=torch.int64), m.sum(1, dtype=torch.int64)
+        ar, ac = torch.arange(m.shape[1], device=m.device), torch.arange(m.shape[2], device=m.device)
+        t = torch.stack([rows.sum(1), (rows * ar).sum(1), (cols * ac).sum(1)], 1).tolist()
+        return [(float("nan"), float("nan")) if cnt == 0 else (sr / cnt, sc / cnt) for cnt, sr, sc in t]
+
+    @staticmethod
     def _centroid(m):
-        """(mean row, mean column) of the set pixels of a boolean map - what dice_metric.py:196-200 derives from the GT -
-        from the row / column histograms (exact: integer sums), NaN for an empty map."""
-        m = m.cpu()                      # a streamed item may carry its ground truth as device tensors only
-        rows, cols = m.sum(1, dtype=torch.int64), m.sum(0, dtype=torch.int64)
-        cnt = int(rows.sum())
-        if cnt == 0:
-            return float("nan"), float("nan")
-        return (float((rows * torch.arange(m.shape[0])).sum()) / cnt, float((cols * torch.arange(m.shape[1])).sum()) / cnt)
+        return DiceEvaluator._centroids([m])[0]
 
     def _gt(self, image_id, dev, record=None):
         key = (image_id, str(dev))
@@ -190,7 +196,9 @@ class DiceEvaluator:
             while len(self._gt_cache) >= self.GT_CACHE_IMAGES:
                 self._gt_cache.pop(next(iter(self._gt_cache)))
             anns = record["annotations"]
-            cens = [a["centroid"] if "centroid" in a else self._centroid(a["mask"]) for a in anns]
+            missing = [k for k, a in enumerate(anns) if "centroid" not in a]
+            found = dict(zip(missing, self._centroids([anns[k]["mask"] for k in missing])))
+            cens = [a["centroid"] if "centroid" in a else found[k] for k, a in enumerate(anns)]
             dm = record.get("device_masks")              # a streaming loader uploads the masks with the image (pinned, side stream)
             if dm is None or dm.device != torch.device(dev):
                 dm = torch.stack([a["mask"] for a in anns]).to(dev, non_blocking=True) if anns else None      # one upload per image
