@@ -30,6 +30,7 @@
 #pragma once
 #include "lap_device.h"
 
+#define LAP_CERT_MAX_TIGHT 256
 struct LapCertScratch {
   double* v;      // [nc] column duals (<= 0)
   double* u;      // [32] row duals
@@ -215,7 +216,7 @@ __device__ __forceinline__ bool lap_certified_solve(int nc, const float* vl, con
   // ---- 3. certificate on (m, v)
   for (int j = tid; j < nc; j += PT) s.row4col[j] = -1;
   if (tid < 66) s.adj[tid] = 0u;
-  if (tid == 0) { s.flag[2] = 0; s.flag[3] = 0; }
+  if (tid == 0) { s.flag[0] = 0; s.flag[2] = 0; s.flag[3] = 0; }
   __syncthreads();
   {
     float mc = 0.f, mv = 0.f;
@@ -242,36 +243,43 @@ __device__ __forceinline__ bool lap_certified_solve(int nc, const float* vl, con
   const double S = (double)__int_as_float(s.flag[2]) + (double)__int_as_float(s.flag[3]);
   const double t_lo = 1e-12 * S, t_hi = 1e-9 * S;
   bool ok = S > 0.0 && S < 1e300;                  // (an all-zero block is all ties; a non-finite entry certifies nothing)
-  // nc <= PT on every caller: a thread owns at most ONE column.  The tight entries of a row are OR-ed over the wavefront first
-  // (DPP) and reach LDS as one atomic per row and wavefront: with one atomic per tight ENTRY a degenerate block (the first
-  // Hungarian iteration behind a collapsed Sinkhorn stage: thousands of ties) spent a million cycles serialised on 33 words.
+  // nc <= PT on every caller: a thread owns at most ONE column.  [r5] Every thread walks the 32 entries of its column on its own
+  // (reduced costs in float64, dual feasibility, a 32-bit mask of its tight entries: no cross-lane traffic), the workgroup counts
+  // the tight entries, and only then the few that exist go to the 33 adjacency words as LDS atomics.  A block with more than
+  // LAP_CERT_MAX_TIGHT tight entries is refused outright (ties all over: the graph would be cyclic, and one atomic per tight entry
+  // of such a block once cost a million cycles) - refusing is always safe, the caller runs the scipy-order solver.  Round 4 reduced
+  // every ROW's tight entries over the wavefront first (32 x a six-stage DPP OR + ballot + readlane per wavefront): 20 k of the
+  // 35 k cycles of a certified LAP at 32 x 256 (in-kernel clocks, round 5).
   {
     const int j = tid;
     const bool have = j < nc;
     const double vj = have ? s.v[j] : 0.0;
     const int rj = have ? s.row4col[j] : -1;
+    unsigned tmask = 0u;
     if (have) {
       if (!(vj <= 0.0)) ok = false;
       if (rj < 0 && vj != 0.0) ok = false;
-      if (rj >= 0 && vj > -t_hi) atomicOr(&s.adj[2 * 32], 1u << rj);                    // F -> rj (at most 32 of these)
-    }
-    const unsigned mybit = rj >= 0 ? (1u << rj) : 0u;
-    for (int i = 0; i < 32; ++i) {
-      bool tight = false;
-      if (have && i != rj) {
-        const double rc = (-(double)vl[j * 33 + i] - s.u[i]) - vj;
-        if (!(rc >= -t_lo)) ok = false;
-        else tight = rc < t_hi;
+      const float* col = vl + j * 33;
+#pragma unroll 8
+      for (int i = 0; i < 32; ++i) {
+        const double rc = (-(double)col[i] - s.u[i]) - vj;
+        if (i != rj) {
+          if (!(rc >= -t_lo)) ok = false;
+          else if (rc < t_hi) tmask |= 1u << i;
+        }
       }
-      const unsigned long long tf = __ballot(tight && rj < 0);                          // i -> F
-      int m = (tight && rj >= 0) ? (int)mybit : 0;                                      // i -> rj
-#define OP(C, R) m |= dpp_mov<C, R>(m);
-      TTDG_DPP_REDUCE(OP)
-#undef OP
-      m = __builtin_amdgcn_readlane(m, 63);
-      if (lane == 0) {
-        if (m != 0) atomicOr(&s.adj[2 * i], (unsigned)m);
-        if (tf != 0ull) atomicOr(&s.adj[2 * i + 1], 1u);
+    }
+    const int wcnt = wave_sum_i32_dpp(__popc(tmask));
+    if (lane == 0 && wcnt) atomicAdd(&s.flag[0], wcnt);      // (flag[0] is free again: zeroed below before the count)
+    __syncthreads();
+    if (s.flag[0] > LAP_CERT_MAX_TIGHT) ok = false;
+    else if (have) {
+      if (rj >= 0 && vj > -t_hi) atomicOr(&s.adj[2 * 32], 1u << rj);                      // F -> rj (at most 32 of these)
+      while (tmask) {
+        const int i = __builtin_ctz(tmask);
+        tmask &= tmask - 1;
+        if (rj >= 0) atomicOr(&s.adj[2 * i], 1u << rj);                                   // i -> rj
+        else atomicOr(&s.adj[2 * i + 1], 1u);                                             // i -> F
       }
     }
   }

@@ -182,6 +182,12 @@ __device__ __forceinline__ float wave_sum_f32_dpp(float v) {
 #undef OP
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+__device__ __forceinline__ int wave_sum_i32_dpp(int v) {
+#define OP(C, R) v += __builtin_amdgcn_update_dpp(0, v, C, R, 0xf, false);
+  TTDG_DPP_REDUCE(OP)
+#undef OP
+  return __builtin_amdgcn_readlane(v, 63);
+}
 // value held by the lane 32 positions away (v_permlane32_swap)
 __device__ __forceinline__ float other_half(float v) {
   const int x = __float_as_int(v);
