@@ -230,6 +230,44 @@ def test_affinity_large_matches_oracle(dev):
     assert maxerr(m(X.to(dev), Y.to(dev)), ref) <= 2e-5
 
 
+@pytest.mark.parametrize("sizes,seed", [((130, 70, 257, 33), 51), ((64, 64, 64), 52), ((200, 9), 53), ((96,) * 5, 54)])
+def test_affinity_pairwise_bwd_ragged_vs_float64(dev, sizes, seed):
+    """[r5] the stand-alone affinity backward (csrc/affinity.hip: both passes in one launch, slices of the block-triangular range that
+    exist only where it has data, partial planes summed by the finish kernel) on ragged batches: node counts that are no multiple of
+    the 64-row tile or of 4, row tiles that span two graphs (per-row limits inside a tile), a first graph without any dP range and a
+    last one without any dQ range.  Reference: S[i,k] = sum_{j in earlier graphs} dM[i,j] [P[i,k] > -Q[j,k]] (the fp32 comparison the
+    kernel makes: reference utils/affinity.py:44-57 through relu'), R likewise over later graphs, dP = w2 S, dQ = w2 R,
+    dw2 = sum P S + sum Q R, db2 = sum dM - accumulated in float64."""
+    from ttdg_mgm_amd import ops
+    g = synth.gen(seed)
+    M, H = sum(sizes), 512
+    P, Q = synth.normal(g, (M, H), 0.5), synth.normal(g, (M, H), 0.5)
+    w2 = synth.normal(g, (H,), 0.3)
+    dM = synth.normal(g, (M, M), 1.0)
+    gid = torch.cat([torch.full((n,), k) for k, n in enumerate(sizes)])
+    wanted = gid[:, None] > gid[None, :]
+    dMw = torch.where(wanted, dM, torch.zeros(()))
+    S, R = torch.zeros(M, H, dtype=torch.float64), torch.zeros(M, H, dtype=torch.float64)
+    off = [0]
+    for n in sizes:
+        off.append(off[-1] + n)
+    for a in range(len(sizes)):
+        for b in range(a):
+            ia, ib = slice(off[a], off[a + 1]), slice(off[b], off[b + 1])
+            step = (P[ia][:, None, :] > -Q[ib][None, :, :]).double()                    # (na, nb, H)
+            D = dM[ia, ib].double()
+            S[ia] += torch.einsum("ij,ijk->ik", D, step)
+            R[ib] += torch.einsum("ij,ijk->jk", D, step)
+    ref = dict(dP=S * w2.double(), dQ=R * w2.double(), dw2=(P.double() * S).sum(0) + (Q.double() * R).sum(0), db2=dMw.double().sum().reshape(1))
+    # garbage outside the wanted blocks must not matter (the header: dM is read only where g(i) > g(j))
+    dM_dev = torch.where(wanted, dM, torch.full((), float("nan"))).to(dev).contiguous()
+    dP, dQ, dw2, db2 = ops.affinity_pairwise_bwd(P.to(dev), Q.to(dev), w2.to(dev), dM_dev, ops.graphs(list(sizes)))
+    for name, got in (("dP", dP), ("dQ", dQ), ("dw2", dw2), ("db2", db2)):
+        r = ref[name]
+        err = float((got.cpu().double() - r).abs().max()) / max(1.0, float(r.abs().max()))
+        assert err <= 1e-5, (name, err)
+
+
 # ------------------------------------------------------------------------------------------- A3
 @pytest.mark.parametrize("ci", range(len(cases.MHA_CASES)))
 def test_mha_adjacency_golden(dev, golden, ci):
