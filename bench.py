@@ -444,7 +444,7 @@ def parity_block():
                 "identical permutation matrices and Sinkhorn-stage iteration counts; Hungarian-stage count +-1",
             "trained-regime free-running solve": "stage-end states within 1e-4 of the oracle wherever the reference's own eight runs define them; final answers: gross-error bound per batch, "
                                                  "rank-sum over the census batches, and exchangeability with the reference's own runs on 8 recorded inputs (pooled |z| <= 3.5 at 1e-5 input noise)",
-            "continual TTA (8 steps, momentum carried)": "per tensor group and step |device - float64 trajectory| <= 4 x max_{j<=k} |float32 host - float64 trajectory| + (k + 1) ulp; Dice within 1e-3 relative",
+            "continual TTA (8 steps, momentum carried)": "per tensor group and step |device - float64 trajectory| <= 4 x max(max_{j<=k} h_j, (k + 1) / K h_{K-1}) + (k + 1) ulp, h = |float32 host - float64 trajectory| (reference side only); Dice within 1e-3 relative",
             "Dice / E / S vs the reference's numpy functions": "1e-9 / 1e-9 / 1e-6",
         },
     }
