@@ -115,3 +115,61 @@ def test_lap_certificate_on_solver_sized_blocks():
         m2, _, v2 = lc.ssp_duals(same)
         assert not lc.certificate(same, m2, v2)
 
+
+# ---- [r5] the integer statement of the scipy-order LAP for narrow-range blocks (csrc/lap_device.h: lap_wave_solve_int) -------------
+def _scipy_slots(V):
+    """What the reference does with an (n x 32) block (utils/hungarian.py:34-63): node of every universe slot."""
+    r, c = scipy.optimize.linear_sum_assignment(np.asarray(V, np.float32) * -1)
+    out = np.full(32, -1, np.int64)
+    out[c] = r
+    return out
+
+
+def _narrow_blocks():
+    g = synth.gen(9500)
+    for n in (33, 40, 64, 100, 256):
+        for kind in range(6):
+            base = np.float32(2.0 ** g.integers(-10, 4)) * (1.0 + g.random())
+            ulp = np.spacing(np.float32(base))
+            if kind == 0:      # what follows a collapsed Sinkhorn stage: node values a few thousand ulp apart, +- 1 ulp along the universe
+                V = base + ulp * (g.integers(0, 4000, size=(n, 1)) + g.integers(0, 2, size=(n, 32)))
+            elif kind == 1:    # every entry equal: scipy's tie rules alone
+                V = np.full((n, 32), base)
+            elif kind == 2:    # a handful of levels
+                V = base + ulp * g.integers(0, 3, size=(n, 32))
+            elif kind == 3:    # generic inside the admitted range
+                V = base + ulp * g.integers(0, 100000, size=(n, 32))
+            elif kind == 4:    # identical rows of the transposed problem (cost independent of the slot), distinct nodes
+                V = np.repeat(base + ulp * g.permutation(n)[:, None], 32, axis=1)
+            else:              # negative values
+                V = -(base + ulp * g.integers(0, 500, size=(n, 32)))
+            yield n, kind, V.astype(np.float32)
+
+
+def test_integer_lap_statement_is_scipy_on_admitted_blocks():
+    from oracle import lap_int
+    done = 0
+    for n, kind, V in _narrow_blocks():
+        C = lap_int.admit(V)
+        assert C is not None, (n, kind)
+        assert C.min() == 0 and C.max() < (1 << lap_int.RANGE_BITS)
+        assert np.array_equal(lap_int.solve(C), _scipy_slots(V)), (n, kind)
+        done += 1
+    assert done == 30
+
+
+def test_integer_lap_admission_declines_what_the_argument_does_not_cover():
+    from oracle import lap_int
+    g = synth.gen(9501)
+    V = (1.0 + 1e-4 * g.random((64, 32))).astype(np.float32)
+    assert lap_int.admit(V) is not None
+    W = V.copy(); W[3, 5] = 0.0
+    assert lap_int.admit(W) is None                       # zero
+    W = V.copy(); W[3, 5] = np.float32("inf")
+    assert lap_int.admit(W) is None
+    W = V.copy(); W[3, 5] = np.float32(1e-30)
+    assert lap_int.admit(W) is None                       # exponent span
+    W = (1.0 + 0.5 * g.random((64, 32))).astype(np.float32)
+    assert lap_int.admit(W) is None                       # range: 2^22 quanta
+    W = V.copy(); W[3, 5] = np.float32(1e-39)
+    assert lap_int.admit(W) is None                       # denormal

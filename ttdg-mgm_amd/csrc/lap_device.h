@@ -456,8 +456,10 @@ __device__ __forceinline__ int lap_wave_solve_regw(int nr, int nc, const float* 
 // without overflow, and the scan's arg-min - value, then scipy's tie rule (some minimal column unassigned -> the LAST such position
 // of `remaining`, else the FIRST minimal position) - is ONE integer wavefront minimum over the key
 //     (min(spc, 2^19 - 1) << 11) | (unassigned ? 1023 - pos : 1024 + pos)          (pos < 1024; clamped values are never minimal).
-// Same steps, same decisions as lap_wave_solve_regw / oracle/lap.c / scipy, by construction and by test (the parity tests compare
-// the projection with scipy.optimize.linear_sum_assignment on the device's own V, and with cfg.variant = TTDG_GAGM_NO_INT_LAP).
+// Same steps, same decisions as lap_wave_solve_regw / oracle/lap.c / scipy, by construction and by test: oracle/lap_int.py restates the
+// admission, the shift and the one-key arg-min in numpy and tests/test_oracle_lap.py holds that statement to scipy on the CPU; the GPU
+// parity tests compare the projection with scipy.optimize.linear_sum_assignment on the device's own V and with
+// cfg.variant = TTDG_GAGM_NO_INT_LAP.
 // cst: shifted integer costs, cst[col * ldc + row] (LDS), nr = 32 rows, nc <= 64 * CW columns; returns col4row of row `lane`.
 #define LAP_INT_RANGE_BITS 17
 template <int CW>
