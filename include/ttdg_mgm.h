@@ -349,6 +349,40 @@ int ttdg_bias_act_nhwc(float* y, const float* bias, const float* residual, const
  * behind F.relu_, one pass; the result is the gradient of both the convolution output and the residual branch). */
 int ttdg_relu_bwd(const float* gout, const float* out, float* gin, size_t total, ttdg_stream_t stream);
 
+/* The backbone's pointwise (1 x 1) convolutions in channels-last memory as ONE streaming fp32 MFMA product with the epilogue
+ * above applied where the accumulators leave the matrix cores (the detectron2 Conv2d + FrozenBatchNorm2d + F.relu_ blocks [3P]
+ * that rcnn.py:331-345 runs; twice per adapted batch, trainer.py:469-485), and their two backward products:
+ *     C[m, n] = act( sum_k A'(m, k) B(n, k) + bias[n] + (res[r(m), n] + bias2[n]) ),   A' = A or relu(A + pbias[k])
+ * a_layout / b_layout: 0 = the reduction index k is the contiguous one (A[m * lda + k]), 1 = the output index is
+ * (A[k * lda + m]); (1, 0) is not built.  a_stride > 1: A row m = pixel (img, ho, wo) of the strided output map reads input pixel
+ * (img, a_stride * ho, a_stride * wo) of an (a_h, a_w) map (a stride-2 pointwise convolution).  res_up: the residual row of
+ * pixel (img, h, w) of a (res_h, res_w) map is pixel (img, h / 2, w / 2) of the half-size map (the FPN's top-down sum).
+ * kslices > 1: the reduction is split over workgroup planes in `ws` (ttdg_mm_workspace_bytes) and added in a fixed order by a
+ * second kernel (weight gradients: dW = dY^T X over hundreds of thousands of pixels); no residual / ReLU then.
+ * tile: 0 = chosen by the library, 1 + code (code bit 1: 64 instead of 128 rows, bit 0: 64 instead of 128 columns) = forced.
+ * N, K (k-contiguous operands), leading dimensions: multiples of 4; every pointer 16-byte aligned.  The order of the additions
+ * inside an accumulator is fixed per shape (deterministic), not ascending in k (csrc/pointwise.hip). */
+typedef struct {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  const float* res;
+  const float* bias2;
+  const float* pbias;
+  void* ws;
+  int64_t lda, ldb, ldc, ldres;
+  int32_t M, N, K;
+  int32_t a_layout, b_layout;
+  int32_t a_stride, a_h, a_w;
+  int32_t res_up, res_h, res_w;
+  int32_t relu, prelu;
+  int32_t kslices;
+  int32_t tile;
+} ttdg_mm_t;
+size_t ttdg_mm_workspace_bytes(int M, int N, int kslices);
+int ttdg_mm_f32(const ttdg_mm_t* desc, ttdg_stream_t stream);
+
 /* detectron2 ROIPooler [3P] in one launch: every ROI (image, x1, y1, x2, y2) picks its FPN level
  * clamp(floor(canonical_level + log2(sqrt(area) / canonical_size + 1e-8)), min_level, min_level + fp.n - 1) inside the
  * kernel and is ROIAlign-ed (aligned, adaptive sampling) from that level's map; lv.stride[l] gives the level scales.

@@ -66,6 +66,17 @@ class RpnLevel(C.Structure):
                 ("k", C.c_int32), ("col0", C.c_int32)]
 
 
+class Mm(C.Structure):
+    """ttdg_mm_t: one streaming product with fused input activation / epilogue (csrc/pointwise.hip)."""
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p), ("bias2", C.c_void_p),
+                ("pbias", C.c_void_p), ("ws", C.c_void_p),
+                ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64), ("ldres", C.c_int64),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("a_layout", C.c_int32), ("b_layout", C.c_int32),
+                ("a_stride", C.c_int32), ("a_h", C.c_int32), ("a_w", C.c_int32),
+                ("res_up", C.c_int32), ("res_h", C.c_int32), ("res_w", C.c_int32),
+                ("relu", C.c_int32), ("prelu", C.c_int32), ("kslices", C.c_int32), ("tile", C.c_int32)]
+
+
 GEMM_GROUP_MAX = 8
 ROW_SCALE_MAX = 64
 RPN_LEVELS_MAX = 8
@@ -122,6 +133,8 @@ SIGNATURES = {
     "ttdg_bias_act": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _S]),
     "ttdg_bias_act_nhwc": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _S]),
     "ttdg_relu_bwd": (C.c_int, [_P, _P, _P, C.c_size_t, _S]),
+    "ttdg_mm_workspace_bytes": (C.c_size_t, [_I, _I, _I]),
+    "ttdg_mm_f32": (C.c_int, [C.POINTER(Mm), _S]),
     "ttdg_paste_masks": (C.c_int, [_P, _P, _I, _I, _I, _I, _F, _P, _S]),
     "ttdg_mask_pair_counts": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _S]),
     "ttdg_mask_measures": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, C.c_double, _P, _S]),

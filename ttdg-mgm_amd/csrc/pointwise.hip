@@ -1,0 +1,394 @@
+// Streaming fp32 GEMM for the backbone's pointwise (1 x 1) convolutions in channels-last memory, with the FrozenBN shift, the residual
+// sum and the ReLU applied where the accumulators leave the matrix cores (rcnn.py:331-345 runs these layers through detectron2's
+// Conv2d + FrozenBatchNorm2d + F.relu_ [3P]; trainer.py:469-485 runs them twice per adapted batch).
+//
+//   C[m, n] = act( sum_k A'(m, k) B(n, k) + bias[n] + (res[r(m), n] + bias2[n]) ),   A'(m, k) = A(m, k) or relu(A(m, k) + pbias[k])
+//
+// In NHWC a stride-1 pointwise convolution IS this product (m = pixel, k = input channel, n = output channel); a stride-2 one
+// reads every other pixel of every other row (row map `a_map`), the FPN's top-down sum reads its residual from the coarser level
+// (row map `r_up`: nearest-neighbour 2x), and the two backward products are the same kernel with other operand layouts:
+//   dX = dY W            A = dY (k-contiguous), B(n, k) = W[k, n] (n-contiguous)
+//   dW = dY^T X          A(n, m) = dY[m, n], B(k, m) = X[m, k] (both: the reduction index is the strided one), split over pixels.
+//
+// Design (gfx950):
+//  * v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles per instruction per SIMD = the fp32 peak).  256 threads = 4 wavefronts in a
+//    2 x 2 arrangement over a BM x BN tile (128 x 128: every wavefront owns 2 x 2 accumulator blocks of 32 x 32 = 64 registers);
+//    two workgroups per CU (64 KB of LDS each), so one workgroup's barrier / epilogue hides behind the other's MFMAs.
+//  * operands go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass), one 32-deep K slab per
+//    stage, two stages; ONE barrier per slab.  A wave-instruction writes 1 KiB lane-linearly, so the LDS image is chosen through
+//    the per-lane SOURCE address:
+//      - k-contiguous operand: image [row][8 chunks of 16 B], chunk c of row r stored at position c ^ ((r >> 1) & 7).  A lane
+//        reads its fragment with ds_read_b128 (four consecutive k of one row): the 16 lanes the LDS serves per cycle then sit on
+//        16 distinct 16-byte slots (conflict-free; unswizzled it is 16-way).  Eight lanes still read one whole 128-byte line.
+//      - output-index-contiguous operand: image [k][R], fragments by ds_read_b32 (32 consecutive words per half wavefront).
+//    The k order inside an accumulator is therefore (per 32-slab) 0-3, 8-11, 16-19, 24-27 interleaved with 4-7, ... in pairs -
+//    a fixed order, the same for every launch (deterministic), not the ascending order of gemm.hip.
+//  * the epilogue goes through LDS (64 rows at a time): 32 lanes write one 512-byte row segment with 16-byte stores; the residual
+//    is read the same way; bias / residual / ReLU cost no extra pass over HBM.
+//  * tiles are dealt to the XCDs in contiguous runs with the n tiles of one m tile adjacent: the A panel of an m tile is fetched
+//    into ONE L2.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MM_BK 32
+#define MM_PRO_MAXK 2048      /* longest reduction the fused input activation takes (its shift vector is staged in LDS) */
+
+struct mm_args {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  const float* res;
+  const float* bias2;
+  const float* pbias;
+  int64_t lda, ldb, ldc, ldres;
+  int M, N, K;
+  int a_map, a_howo, a_wo, a_hw, a_w, a_s;   // A row m = (img, ho, wo) of an (Ho, Wo) map -> pixel (img, s ho, s wo) of the (H, W) input
+  int r_up, r_hw, r_w;                       // residual row of pixel (img, h, w) of an (H, W) map: (img, h / 2, w / 2) of the (H/2, W/2) map
+  int relu, prelu;
+  int kslices, kc;                           // split of the reduction over blockIdx.y (kc: multiple of MM_BK); partial planes in `part`
+  float* part;
+};
+
+__device__ __forceinline__ void mm_glds16(const float* g, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// rows / columns of operand X that this lane stages, fixed for the whole K loop
+template <int R, bool KC>
+struct mm_loader {
+  static constexpr int IPW = R / 32;                 // wave-instructions per stage and wavefront
+  const float* p[IPW];                               // KC: row pointer + swizzled chunk; !KC: column pointer (k row added per slab)
+  int krow[IPW];                                     // !KC: k row inside the slab
+  int kchunk;                                        // KC: source chunk (0..7) of this lane
+  int64_t ld;
+  __device__ __forceinline__ void init(const float* X, int64_t ld_, int r0, int Rlim, int wave, int lane, const mm_args& a, bool is_a) {
+    ld = ld_;
+    if (KC) {
+      const int sw = (wave * 4 + (lane >> 4)) & 7;
+      kchunk = (lane & 7) ^ sw;
+#pragma unroll
+      for (int q = 0; q < IPW; ++q) {
+        int r = r0 + (q * 4 + wave) * 8 + (lane >> 3);
+        r = r < Rlim ? r : Rlim - 1;                 // beyond the edge: a valid row whose results are never stored
+        int64_t row = r;
+        if (is_a && a.a_map) {
+          const int img = r / a.a_howo, rem = r - img * a.a_howo, ho = rem / a.a_wo, wo = rem - ho * a.a_wo;
+          row = (int64_t)img * a.a_hw + (int64_t)(ho * a.a_s) * a.a_w + wo * a.a_s;
+        }
+        p[q] = X + row * ld;
+      }
+    } else {
+      constexpr int CPR = R / 4;                     // 16-byte chunks per k row
+      constexpr int KPI = 64 / CPR;                  // k rows per wave-instruction
+      int c = r0 + 4 * (lane % CPR);
+      c = c < Rlim ? c : (Rlim - 4 > 0 ? Rlim - 4 : 0);
+#pragma unroll
+      for (int q = 0; q < IPW; ++q) {
+        krow[q] = (q * 4 + wave) * KPI + lane / CPR;
+        p[q] = X + c;
+      }
+      kchunk = 0;
+    }
+  }
+  // one stage: slab [k0, k0 + 32) -> lds (R * 32 floats)
+  __device__ __forceinline__ void issue(float* lds, int k0, int Klim, int wave) const {
+#pragma unroll
+    for (int q = 0; q < IPW; ++q) {
+      float* dst = lds + (q * 4 + wave) * 256;
+      if (KC) {
+        int k = k0 + 4 * kchunk;
+        k = k < Klim ? k : 0;                        // (K % 4 == 0) a chunk is inside or outside; outside: finite filler, zeroed in the fragment
+        mm_glds16(p[q] + k, dst);
+      } else {
+        int k = k0 + krow[q];
+        k = k < Klim ? k : Klim - 1;
+        mm_glds16(p[q] + (int64_t)k * ld, dst);
+      }
+    }
+  }
+};
+
+// the 64 (128 x 128 tile) MFMAs of one 32-deep slab: four groups of eight k; in a group the lower half wavefront owns k 8q .. 8q+3,
+// the upper half 8q+4 .. 8q+7 (one ds_read_b128 per 32 x 32 block and operand)
+template <int BM, int BN, bool AKC, bool BKC, bool PRO, bool TAIL>
+__device__ __forceinline__ void mm_slab(const float* As, const float* Bs, const int* fa, const int* fb, int sw, int h, int k0, int kend,
+                                        const mm_args& p, const float* pb_lds, f32x16 (*acc)[BN / 64]) {
+  constexpr int MB = BM / 64, NB = BN / 64;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float af[MB][4], bf[NB][4];
+    const int kq = 4 * (2 * q + h);                    // this lane's four k of the group
+#pragma unroll
+    for (int b = 0; b < MB; ++b) {
+      if (AKC) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(As + fa[b] + 4 * ((2 * q + h) ^ sw));
+        af[b][0] = v.x, af[b][1] = v.y, af[b][2] = v.z, af[b][3] = v.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) af[b][j] = As[(kq + j) * BM + fa[b]];
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (BKC) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Bs + fb[b] + 4 * ((2 * q + h) ^ sw));
+        bf[b][0] = v.x, bf[b][1] = v.y, bf[b][2] = v.z, bf[b][3] = v.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[b][j] = Bs[(kq + j) * BN + fb[b]];
+      }
+    }
+    if (PRO) {                                         // fused input activation: relu(A + shift[k]); the shift vector sits in LDS
+      const f32x4 pb = *reinterpret_cast<const f32x4*>(pb_lds + (TAIL ? min(k0 + kq, p.K - 4) : k0 + kq));
+#pragma unroll
+      for (int b = 0; b < MB; ++b) {
+        af[b][0] += pb.x, af[b][1] += pb.y, af[b][2] += pb.z, af[b][3] += pb.w;
+        if (p.prelu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) af[b][j] = fmaxf(af[b][j], 0.f);
+        }
+      }
+    }
+    if (TAIL) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool dead = k0 + kq + j >= kend;
+#pragma unroll
+        for (int b = 0; b < MB; ++b) af[b][j] = dead ? 0.f : af[b][j];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) bf[b][j] = dead ? 0.f : bf[b][j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int bm = 0; bm < MB; ++bm)
+#pragma unroll
+        for (int bn = 0; bn < NB; ++bn) acc[bm][bn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[bm][j], bf[bn][j], acc[bm][bn], 0, 0, 0);
+  }
+}
+
+template <int BM, int BN, bool AKC, bool BKC, bool PRO>
+__global__ __launch_bounds__(256, 2) void mm_kernel(const mm_args p) {
+  constexpr int WM = BM / 2, WN = BN / 2, MB = WM / 32, NB = WN / 32;
+  constexpr int ASZ = BM * MM_BK, BSZ = BN * MM_BK, STAGE = ASZ + BSZ;
+  constexpr int CT_LD = BN + 4;
+  constexpr int EPI = 64 * CT_LD;
+  constexpr int PB = PRO ? MM_PRO_MAXK : 0;              // the input shift vector (PRO) lives behind the stages
+  constexpr int SMEM = (2 * STAGE > EPI ? 2 * STAGE : EPI) + PB;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];     // the ONLY LDS object (a second one makes hipcc drain the DMA queue before every ds_read)
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int h = lane >> 5, l32 = lane & 31;
+
+  // tile of this workgroup: XCD x gets a contiguous run of the (m tile, n tile) list, n fastest
+  const int NT = (p.N + BN - 1) / BN;
+  int L = blockIdx.x;
+  {
+    const int T = gridDim.x, q = T >> 3, r = T & 7, x = L & 7, i = L >> 3;
+    L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
+  const int mt = L / NT, nt = L - mt * NT;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int kbeg = p.part ? blockIdx.y * p.kc : 0;
+  const int kend = p.part ? min(p.K, kbeg + p.kc) : p.K;
+  const int nk = (kend - kbeg + MM_BK - 1) / MM_BK;
+
+  mm_loader<BM, AKC> la;
+  mm_loader<BN, BKC> lb;
+  la.init(p.A, p.lda, m0, p.M, wave, lane, p, true);
+  lb.init(p.B, p.ldb, n0, p.N, wave, lane, p, false);
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // fragment addresses (floats, inside a stage)
+  int fa[MB], fb[NB];
+  const int sw = (l32 >> 1) & 7;
+#pragma unroll
+  for (int b = 0; b < MB; ++b) fa[b] = AKC ? (wr * WM + 32 * b + l32) * 32 : wr * WM + 32 * b + l32;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) fb[b] = BKC ? (wc * WN + 32 * b + l32) * 32 : wc * WN + 32 * b + l32;
+
+  const float* pb_lds = smem + SMEM - PB;
+  if (PRO) {
+    for (int k = tid; k < p.K; k += 256) smem[SMEM - PB + k] = p.pbias[k];
+    // (made visible by the first barrier of the K loop; never overwritten: the epilogue buffer ends below it)
+  }
+  if (nk > 0) {
+    la.issue(smem, kbeg, kend, wave);
+    lb.issue(smem + ASZ, kbeg, kend, wave);
+  }
+  for (int t = 0; t < nk; ++t) {
+    const float* As = smem + (t & 1) * STAGE;
+    const float* Bs = As + ASZ;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wavefront's share of slab t has landed
+    __syncthreads();                                     // ... everybody's has, and nobody still reads the other stage
+    const int k0 = kbeg + t * MM_BK;
+    if (t + 1 < nk) {
+      float* nxt = smem + ((t + 1) & 1) * STAGE;
+      la.issue(nxt, k0 + MM_BK, kend, wave);
+      lb.issue(nxt + ASZ, k0 + MM_BK, kend, wave);
+    }
+    // ragged end of the reduction (only the last slab can be ragged): the filler is zeroed in registers
+    if (kend - k0 < MM_BK) mm_slab<BM, BN, AKC, BKC, PRO, true>(As, Bs, fa, fb, sw, h, k0, kend, p, pb_lds, acc);
+    else mm_slab<BM, BN, AKC, BKC, PRO, false>(As, Bs, fa, fb, sw, h, k0, kend, p, pb_lds, acc);
+  }
+
+  // ---- epilogue: 64 tile rows at a time through LDS; C/D fragment: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  float* Ct = smem;
+  const int cq = 4 * (tid & (BN / 4 - 1));               // column quad of this thread inside the tile
+  constexpr int RPP = 256 / (BN / 4);                    // rows covered by the 256 threads in one sweep
+  const int rsub = tid / (BN / 4);
+  const bool ncol = n0 + cq < p.N;                       // (N % 4 == 0: a quad is inside or outside)
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (!p.part && ncol) {
+    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + n0 + cq);
+    if (p.bias2) {
+      const f32x4 b2 = *reinterpret_cast<const f32x4*>(p.bias2 + n0 + cq);
+      bv += b2;
+    }
+  }
+#pragma unroll
+  for (int bm = 0; bm < MB; ++bm) {
+    __syncthreads();                                     // the last slab's readers (bm = 0) / the previous pass's readers are done
+#pragma unroll
+    for (int bn = 0; bn < NB; ++bn)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Ct[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * CT_LD + wc * WN + 32 * bn + l32] = acc[bm][bn][r];
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 64 / RPP; ++s) {
+      const int lr = s * RPP + rsub;                     // buffer row: wavefront row (lr >> 5), row (lr & 31) of its block bm
+      const int m = m0 + (lr >> 5) * WM + 32 * bm + (lr & 31);
+      if (m < p.M && ncol) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(Ct + lr * CT_LD + cq);
+        if (p.part) {
+          *reinterpret_cast<f32x4*>(p.part + ((size_t)blockIdx.y * p.M + m) * p.N + n0 + cq) = v;
+          continue;
+        }
+        v += bv;
+        if (p.res) {
+          int64_t rr = m;
+          if (p.r_up) {
+            const int img = m / p.r_hw, rem = m - img * p.r_hw, hh = rem / p.r_w, ww = rem - hh * p.r_w;
+            rr = (int64_t)img * (p.r_hw >> 2) + (int64_t)(hh >> 1) * (p.r_w >> 1) + (ww >> 1);
+          }
+          v += *reinterpret_cast<const f32x4*>(p.res + rr * p.ldres + n0 + cq);
+        }
+        if (p.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
+        *reinterpret_cast<f32x4*>(p.C + (int64_t)m * p.ldc + n0 + cq) = v;
+      }
+    }
+  }
+}
+
+// partial planes -> C (+ bias), fixed order: deterministic
+__global__ __launch_bounds__(256) void mm_reduce_kernel(const float* __restrict__ part, int kslices, float* __restrict__ C, int64_t ldc,
+                                                        const float* __restrict__ bias, int M, int N) {
+  const size_t q = (size_t)blockIdx.x * 256 + threadIdx.x;          // one column quad each
+  const int nq = N >> 2;
+  if (q >= (size_t)M * nq) return;
+  const int m = (int)(q / nq), n = 4 * (int)(q - (size_t)m * nq);
+  const size_t plane = (size_t)M * N, e = (size_t)m * N + n;
+  f32x4 v = *reinterpret_cast<const f32x4*>(part + e);
+  for (int z = 1; z < kslices; ++z) v += *reinterpret_cast<const f32x4*>(part + z * plane + e);
+  if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+  *reinterpret_cast<f32x4*>(C + (int64_t)m * ldc + n) = v;
+}
+
+template <bool AKC, bool BKC, bool PRO>
+static int mm_launch(int tile, const mm_args& a, dim3 grid_y, hipStream_t st) {
+  const int bm = tile >> 1 ? 64 : 128, bn = tile & 1 ? 64 : 128;
+  const int tiles = ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn);
+  dim3 grid(tiles, grid_y.y);
+  switch (tile) {
+    case 0: hipLaunchKernelGGL((mm_kernel<128, 128, AKC, BKC, PRO>), grid, dim3(256), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((mm_kernel<128, 64, AKC, BKC, PRO>), grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((mm_kernel<64, 128, AKC, BKC, PRO>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((mm_kernel<64, 64, AKC, BKC, PRO>), grid, dim3(256), 0, st, a); break;
+  }
+  return ttdg_launch_status("mm_f32");
+}
+
+// tile code: bit 1 = BM 64 (else 128), bit 0 = BN 64 (else 128).  Largest tile that still gives every CU two workgroups' worth of
+// tiles when the matrix has them; N <= 64 never takes a 128-wide tile.
+static int mm_pick_tile(int M, int N, int kslices) {
+  int best = 3;
+  for (int t = 0; t < 4; ++t) {
+    const int bm = t >> 1 ? 64 : 128, bn = t & 1 ? 64 : 128;
+    if (bn == 128 && N <= 64) continue;
+    const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * (kslices > 0 ? kslices : 1);
+    if (tiles >= 512) return t;
+    best = 3;
+  }
+  return best;
+}
+
+extern "C" size_t ttdg_mm_workspace_bytes(int M, int N, int kslices) { return kslices > 1 ? (size_t)kslices * M * N * sizeof(float) : 0; }
+
+extern "C" int ttdg_mm_f32(const ttdg_mm_t* d, ttdg_stream_t stream) {
+  TTDG_REQUIRE(d && d->A && d->B && d->C, "mm: null operand");
+  TTDG_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, "mm: negative size");
+  if (d->M == 0 || d->N == 0) return 0;
+  TTDG_REQUIRE((d->N & 3) == 0 && (d->ldc & 3) == 0 && ((uintptr_t)d->C & 15) == 0, "mm: N, ldc must be multiples of 4 and C 16-byte aligned");
+  TTDG_REQUIRE(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->B & 15) == 0 && (d->lda & 3) == 0 && (d->ldb & 3) == 0, "mm: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
+  TTDG_REQUIRE(d->a_layout == 0 || d->a_layout == 1, "mm: a_layout");
+  TTDG_REQUIRE(d->b_layout == 0 || d->b_layout == 1, "mm: b_layout");
+  TTDG_REQUIRE(!(d->a_layout == 1 && d->b_layout == 0), "mm: (A output-contiguous, B k-contiguous) is not built");
+  if (d->a_layout == 0 || d->b_layout == 0) TTDG_REQUIRE((d->K & 3) == 0, "mm: K must be a multiple of 4 for a k-contiguous operand");
+  if (d->a_layout == 1) TTDG_REQUIRE((d->M & 3) == 0, "mm: M must be a multiple of 4 for an m-contiguous A");
+  TTDG_REQUIRE(!d->a_stride || d->a_layout == 0, "mm: the strided row map needs a k-contiguous A");
+  TTDG_REQUIRE(!d->res || ((d->ldres & 3) == 0 && ((uintptr_t)d->res & 15) == 0), "mm: residual alignment");
+  TTDG_REQUIRE(!d->bias || ((uintptr_t)d->bias & 15) == 0, "mm: bias alignment");
+  TTDG_REQUIRE(!d->bias2 || ((uintptr_t)d->bias2 & 15) == 0, "mm: bias2 alignment");
+  TTDG_REQUIRE(!d->pbias || (d->a_layout == 0 && d->b_layout == 0 && d->K <= MM_PRO_MAXK), "mm: the input shift needs k-contiguous operands and K <= 2048");
+  TTDG_REQUIRE(d->kslices >= 0 && d->kslices <= 1024, "mm: kslices");
+  TTDG_REQUIRE(d->kslices <= 1 || (d->ws && !d->res && !d->relu), "mm: the split form takes a workspace and no residual / ReLU");
+  mm_args a;
+  a.A = d->A, a.B = d->B, a.C = d->C, a.bias = d->bias, a.res = d->res, a.bias2 = d->bias2, a.pbias = d->pbias;
+  a.lda = d->lda, a.ldb = d->ldb, a.ldc = d->ldc, a.ldres = d->ldres;
+  a.M = d->M, a.N = d->N, a.K = d->K;
+  a.a_map = d->a_stride > 1;
+  a.a_s = d->a_stride > 1 ? d->a_stride : 1;
+  a.a_w = d->a_w, a.a_hw = d->a_h * d->a_w;
+  if (a.a_map) {
+    TTDG_REQUIRE(d->a_h > 0 && d->a_w > 0, "mm: strided row map without an input size");
+    const int ho = (d->a_h - 1) / a.a_s + 1, wo = (d->a_w - 1) / a.a_s + 1;
+    TTDG_REQUIRE(d->M % (ho * wo) == 0, "mm: M is not a whole number of strided maps");
+    a.a_wo = wo, a.a_howo = ho * wo;
+  } else {
+    a.a_wo = a.a_howo = 1;
+  }
+  a.r_up = d->res_up != 0;
+  a.r_w = d->res_w, a.r_hw = d->res_h * d->res_w;
+  if (a.r_up) TTDG_REQUIRE(d->res && d->res_h > 0 && d->res_w > 0 && !(d->res_h & 1) && !(d->res_w & 1) && d->M % a.r_hw == 0, "mm: up-sampled residual needs an even (H, W) map");
+  a.relu = d->relu, a.prelu = d->prelu;
+  const int ks = d->kslices > 1 ? d->kslices : 0;
+  a.kslices = ks;
+  a.kc = ks ? (((d->K + ks - 1) / ks) + MM_BK - 1) / MM_BK * MM_BK : 0;
+  a.part = ks ? (float*)d->ws : nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  int tile = d->tile > 0 ? d->tile - 1 : mm_pick_tile(d->M, d->N, ks);
+  TTDG_REQUIRE(tile >= 0 && tile < 4, "mm: tile code");
+  dim3 gy(1, ks ? ks : 1);
+  int rc;
+  if (d->a_layout == 0 && d->b_layout == 0) rc = d->pbias ? mm_launch<true, true, true>(tile, a, gy, st) : mm_launch<true, true, false>(tile, a, gy, st);
+  else if (d->a_layout == 0) rc = mm_launch<true, false, false>(tile, a, gy, st);
+  else rc = mm_launch<false, false, false>(tile, a, gy, st);
+  if (rc || !ks) return rc;
+  const size_t quads = (size_t)d->M * (d->N >> 2);
+  hipLaunchKernelGGL(mm_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, a.part, ks, d->C, d->ldc, d->bias, d->M, d->N);
+  return ttdg_launch_status("mm_reduce");
+}

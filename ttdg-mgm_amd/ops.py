@@ -104,6 +104,25 @@ def linear_raw(x, W, b=None, w_col_off=0, w_ld=None, out=None):
     return y
 
 
+def mm(A, B, out, M, N, K, lda, ldb, ldc, bias=None, res=None, ldres=0, bias2=None, pbias=None, relu=False, prelu=False,
+       a_layout=0, b_layout=0, a_stride=0, a_hw=(0, 0), res_up=False, res_hw=(0, 0), kslices=0, tile=0):
+    """ttdg_mm_f32 (csrc/pointwise.hip): out[m, n] = act(sum_k A'(m, k) B(n, k) + bias[n] + (res[r(m), n] + bias2[n])).  Tensors are
+    passed as storage (pointer + leading dimensions); see include/ttdg_mgm.h for the row maps and layouts."""
+    d = _lib.Mm()
+    d.A, d.B, d.C, d.bias, d.res, d.bias2, d.pbias = ptr(A), ptr(B), ptr(out), ptr(bias), ptr(res), ptr(bias2), ptr(pbias)
+    ws = None
+    if kslices > 1:
+        ws = torch.empty(kslices * M * N, device=out.device, dtype=torch.float32)
+    d.ws = ptr(ws)
+    d.lda, d.ldb, d.ldc, d.ldres = int(lda), int(ldb), int(ldc), int(ldres)
+    d.M, d.N, d.K, d.a_layout, d.b_layout = int(M), int(N), int(K), int(a_layout), int(b_layout)
+    d.a_stride, d.a_h, d.a_w = int(a_stride), int(a_hw[0]), int(a_hw[1])
+    d.res_up, d.res_h, d.res_w = int(bool(res_up)), int(res_hw[0]), int(res_hw[1])
+    d.relu, d.prelu, d.kslices, d.tile = int(bool(relu)), int(bool(prelu)), int(kslices), int(tile)
+    call("ttdg_mm_f32", C.byref(d), stream())
+    return out
+
+
 def colsum(X):
     out = torch.empty(X.shape[1], device=X.device, dtype=torch.float32)
     call("ttdg_colsum_f32", ptr(X), X.shape[1], ptr(out), X.shape[0], X.shape[1], stream())
