@@ -79,6 +79,11 @@ def parse(argv=None):
     ap.add_argument("--roi-xcd-chunks", action="store_true", help="A/B: channels-last ROIPooler with one contiguous eighth of the ROI list per XCD instead of ROI r on workgroup r")
     ap.add_argument("--roi-chunk", type=int, default=0, help="A/B: bins the channels-last ROIPooler stages per output flush: 49 (round 2), 25 (default) or 13")
     ap.add_argument("--graphs", action="store_true", help="A/B: hipGraph replay of the backbone's no-grad forward in the Dice pass (modeling/graphed.py; default: eager - measured equal)")
+    ap.add_argument("--timer-every", type=int, default=7, help="HIP-event pairs around every N-th launch of the kernels launched dozens of times per batch "
+                    "(ops.KERNEL_TIMER_SAMPLED; 1 = every launch, the round 1-5 protocol, which costs ~4 %% of the timed region)")
+    ap.add_argument("--own-pointwise-backward", action="store_true", help="A/B: dX / dW of the 1 x 1 convolutions on the streaming product's backward layouts instead of MIOpen")
+    ap.add_argument("--no-kernel-timers", action="store_true", help="debug A/B: no HIP events around the hand-written kernels in the timed pass (the rooflines are then empty): what the event pairs themselves cost")
+    ap.add_argument("--vendor-pointwise", action="store_true", help="A/B: the backbone's 1 x 1 convolutions on MIOpen + the one-pass epilogue kernel (round 5) instead of the fused streaming product (csrc/pointwise.hip)")
     ap.add_argument("--no-miopen-db", action="store_true", help="A/B: ignore the tuned MIOpen find-db shipped in ttdg-mgm_amd/miopen_db (MIOpen's heuristic picks the solvers)")
     ap.add_argument("--miopen-search", action="store_true", help="tuning run: torch.backends.cudnn.benchmark = True, i.e. MIOpen times its solvers for every "
                     "convolution shape it meets (minutes) and records the winners in its user find-db (MIOPEN_USER_DB_PATH)")
@@ -222,7 +227,7 @@ def timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, w
     adapt(batches[:W])
     evaluate(batches[:W])
     stamps = []
-    ops.KERNEL_TIMERS = stamps          # (name, start_event, end_event, meta, info) recorded around our kernels
+    ops.KERNEL_TIMERS = None if args.no_kernel_timers else stamps          # (name, start_event, end_event, meta, info) recorded around our kernels
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -281,6 +286,13 @@ def kernel_rooflines(run):
             e["work"] += 2 * sum(8 * r * c for r, c in _pairs(meta))
         elif nm in ("sgd", "bias_act", "relu_bwd", "roi_align_nhwc", "row_scale_multi"):
             e["work"] += meta
+        elif nm in ("pointwise_fwd", "pointwise_dx", "pointwise_dw"):      # meta = (algorithmic bytes, FLOPs) of the product
+            e["work"] += meta[1]
+            e["bytes"] = e.get("bytes", 0) + meta[0]
+    from ttdg_mgm_amd import ops as _o
+
+    def every(nm):
+        return _o.KERNEL_TIMER_EVERY if nm in _o.KERNEL_TIMER_SAMPLED else 1
     out = []
     for nm, e in acc.items():
         hbm = nm in ("sinkhorn_pairs_fwd", "sinkhorn_pairs_bwd", "sgd", "pair_stage_bwd", "bias_act", "relu_bwd", "roi_align_nhwc", "row_scale_multi")
@@ -290,10 +302,17 @@ def kernel_rooflines(run):
                         "affinity_bwd": "affinity_bwd_kernel(+finish)", "sinkhorn_pairs_fwd": "sinkhorn_pairs_fwd_kernel",
                         "sinkhorn_pairs_bwd": "sinkhorn_pairs_bwd_kernel", "pair_stage_fwd": "pair_stage_fwd_kernel",
                         "pair_stage_bwd": "pair_stage_bwd_kernel", "bias_act": BIAS_ACT_KERNEL, "relu_bwd": "relu_bwd_kernel",
-                        "roi_align_nhwc": "roi_align_nhwc_kernel", "row_scale_multi": "row_scale_multi_kernel"}[nm],
+                        "roi_align_nhwc": "roi_align_nhwc_kernel", "row_scale_multi": "row_scale_multi_kernel",
+                        "pointwise_fwd": "mm_kernel (1x1 convolutions, forward + fused epilogue)", "pointwise_dx": "mm_kernel (1x1 convolutions, dX)",
+                        "pointwise_dw": "mm_kernel + mm_reduce_kernel (1x1 convolutions, dW over pixel slices)"}[nm],
              "bound": "hbm" if hbm else "mfma", "achieved": ach, "peak": peak, "unit": "GB/s" if hbm else "TFLOP/s", "frac": ach / peak,
-             "traffic": pmc_traffic(nm), "launches": e["n"], "avg_launch_ms": e["t"] / e["n"] * 1e3, "total_ms": e["t"] * 1e3,
+             "traffic": pmc_traffic(nm), "launches_timed": e["n"], "launches": e["n"] * every(nm), "avg_launch_ms": e["t"] / e["n"] * 1e3,
+             "total_ms": e["t"] * 1e3 * every(nm),
+             "sampling": ("HIP-event pair around every %d-th launch (ops.KERNEL_TIMER_EVERY); launches / total_ms are the timed ones x %d" % (every(nm), every(nm))) if every(nm) > 1 else "every launch timed",
              "algorithmic_work_per_launch": e["work"] / e["n"]}
+        if "bytes" in e:
+            r["algorithmic_hbm_gbs"] = e["bytes"] / e["t"] / 1e9          # the same launches against the other roofline (HBM 8 TB/s)
+            r["frac_hbm"] = r["algorithmic_hbm_gbs"] / HBM_PEAK_GBS
         if nm == "gagm":
             its = [sum(x[1]) for x in e["extra"]]
             r.update({"avg_iterations_per_launch": sum(its) / len(its), "us_per_iteration": e["t"] / max(sum(its), 1) * 1e6,
@@ -314,7 +333,8 @@ def pmc_traffic(stamp_name):
              "affinity_bwd": ("affinity_bwd_kernel", False), "sinkhorn_pairs_fwd": ("sinkhorn_pairs_fwd", False),
              "sinkhorn_pairs_bwd": ("sinkhorn_pairs_bwd", False), "pair_stage_fwd": ("pair_stage_fwd", False),
              "pair_stage_bwd": ("pair_stage_bwd", False), "bias_act": ("bias_act", True), "relu_bwd": ("relu_bwd", True),
-             "roi_align_nhwc": ("roi_align_nhwc", True), "row_scale_multi": ("row_scale_multi", True)}
+             "roi_align_nhwc": ("roi_align_nhwc", True), "row_scale_multi": ("row_scale_multi", True),
+             "pointwise_fwd": ("mm_kernel", True), "pointwise_dx": ("mm_kernel", True), "pointwise_dw": ("mm_kernel", True)}
     kernel, streaming = names[stamp_name]
     import glob
     for f in sorted((os.path.basename(x) for x in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_pmc.json"))), reverse=True):   # newest round first
@@ -568,6 +588,12 @@ def gpu_main(args, rank, world, local):
     from ttdg_mgm_amd.modeling import detector as _det
     from ttdg_mgm_amd.modeling import graphed as _graphed
     _graphed.ENABLED = bool(args.graphs)
+    if args.vendor_pointwise:
+        from ttdg_mgm_amd.modeling import backbone as _bb
+        _bb.OWN_POINTWISE = False
+    if args.own_pointwise_backward:
+        _ops.POINTWISE_BACKWARD = "own"
+    _ops.KERNEL_TIMER_EVERY = max(1, args.timer_every)
     assert _det._backend is _ops, "the GPU legs must run on the HIP operators (detector._backend was re-pointed)"
     if args.gagm_threads or args.roi_align_mode != 3:
         from ttdg_mgm_amd import _lib

@@ -14,7 +14,7 @@ echo "plain bench rc=$?"
 CMD="python bench.py --steps 4 --warmup 2 --no-ab --no-cpu-baseline"
 timeout -k 10 420 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/prof.log
 echo "stats pass rc=$?"
-OURS="gagm_|affinity_|sinkhorn_|pair_stage|sgd_multi|mask_pair|perm_loss|node_|roi_align|paste_masks|mha_adj|gemm_f32|gemm_grouped|bias_act|relu_bwd|resize_|row_scale|rpn_select|mask_measures"
+OURS="gagm_|affinity_|sinkhorn_|pair_stage|sgd_multi|mask_pair|perm_loss|node_|roi_align|paste_masks|mha_adj|gemm_f32|gemm_grouped|bias_act|relu_bwd|resize_|row_scale|rpn_select|mask_measures|mm_kernel|mm_reduce"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "$OURS" --output-format csv -d $OUT/pmc_r -o bench -- $CMD > /dev/null 2> $OUT/pmc_r.log
 echo "FETCH pass rc=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "$OURS" --output-format csv -d $OUT/pmc_w -o bench -- $CMD > /dev/null 2> $OUT/pmc_w.log

@@ -3,7 +3,7 @@ whole-run stats of the hand-written kernels (from *_kernel_stats.csv) + steady-s
 import csv, sys, subprocess, os
 stats, trace, warm, out = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4]
 OURS = ("gagm_", "affinity_", "sinkhorn_", "mha_adj", "perm_loss", "node_", "sgd_multi", "gemm_f32", "gemm_splitk", "colsum", "nms_", "roi_align",
-        "lap_batched", "rpn_decode", "box_inference", "paste_masks", "bias_act", "relu_bwd", "nchw_to_nhwc", "mask_pair_counts", "pair_stage", "gemm_grouped", "resize_", "row_scale", "rpn_select", "mask_measures")
+        "lap_batched", "rpn_decode", "box_inference", "paste_masks", "bias_act", "relu_bwd", "nchw_to_nhwc", "mask_pair_counts", "pair_stage", "gemm_grouped", "resize_", "row_scale", "rpn_select", "mask_measures", "mm_kernel", "mm_reduce")
 rows = list(csv.DictReader(open(stats)))
 with open(out, "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 4 --warmup 2 --no-ab --no-cpu-baseline  (MI355X, gfx950; trained-regime checkpoint, free-running)\n")

@@ -3,7 +3,7 @@ kernels).  usage: pmc_sq_summary.py <counter_collection.csv> <out.json>"""
 import csv, json, statistics, sys
 OURS = ("gagm_kernel", "gagm_large_mul", "gagm_large_project", "affinity_fwd", "affinity_bwd_kernel", "affinity_bwd_finish",
         "sinkhorn_pairs_fwd", "sinkhorn_pairs_bwd", "gemm_f32_kernel", "perm_loss_pair", "mha_adjacency", "sgd_multi_tensor",
-        "bias_act", "roi_align_ml", "rpn_decode", "box_inference", "paste_masks", "nms_group")
+        "bias_act", "mm_kernel", "roi_align_ml", "rpn_decode", "box_inference", "paste_masks", "nms_group")
 acc = {}
 for r in csv.DictReader(open(sys.argv[1])):
     name = r["Kernel_Name"]

@@ -171,7 +171,7 @@ __device__ __forceinline__ void mm_slab(const float* As, const float* Bs, const 
   }
 }
 
-template <int BM, int BN, bool AKC, bool BKC, bool PRO>
+template <int BM, int BN, bool AKC, bool BKC, bool PRO, bool LONGK>
 __global__ __launch_bounds__(256, 2) void mm_kernel(const mm_args p) {
   constexpr int WM = BM / 2, WN = BN / 2, MB = WM / 32, NB = WN / 32;
   constexpr int ASZ = BM * MM_BK, BSZ = BN * MM_BK, STAGE = ASZ + BSZ;
@@ -213,6 +213,16 @@ __global__ __launch_bounds__(256, 2) void mm_kernel(const mm_args p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  f32x16 tot[LONGK ? MB : 1][LONGK ? NB : 1];
+  if (LONGK) {
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tot[i][j][e] = 0.f;
+  }
+
   // fragment addresses (floats, inside a stage)
   int fa[MB], fb[NB];
   const int sw = (l32 >> 1) & 7;
@@ -244,6 +254,24 @@ __global__ __launch_bounds__(256, 2) void mm_kernel(const mm_args p) {
     // ragged end of the reduction (only the last slab can be ragged): the filler is zeroed in registers
     if (kend - k0 < MM_BK) mm_slab<BM, BN, AKC, BKC, PRO, true>(As, Bs, fa, fb, sw, h, k0, kend, p, pb_lds, acc);
     else mm_slab<BM, BN, AKC, BKC, PRO, false>(As, Bs, fa, fb, sw, h, k0, kend, p, pb_lds, acc);
+    if (LONGK && (t & 7) == 7) {
+      // long reductions: every 256 k the running sums move to a second set of registers and the chains restart, so a chain is
+      // 256 products long whatever K is (rounding of a 2048-long fp32 chain measured 4x a vendor kernel's against float64)
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          tot[i][j] += acc[i][j];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        }
+    }
+  }
+  if (LONGK) {
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[i][j] += tot[i][j];
   }
 
   // ---- epilogue: 64 tile rows at a time through LDS; C/D fragment: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
@@ -308,33 +336,25 @@ __global__ __launch_bounds__(256) void mm_reduce_kernel(const float* __restrict_
   *reinterpret_cast<f32x4*>(C + (int64_t)m * ldc + n) = v;
 }
 
-template <bool AKC, bool BKC, bool PRO>
+template <bool AKC, bool BKC, bool PRO, bool LONGK>
 static int mm_launch(int tile, const mm_args& a, dim3 grid_y, hipStream_t st) {
   const int bm = tile >> 1 ? 64 : 128, bn = tile & 1 ? 64 : 128;
   const int tiles = ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn);
   dim3 grid(tiles, grid_y.y);
   switch (tile) {
-    case 0: hipLaunchKernelGGL((mm_kernel<128, 128, AKC, BKC, PRO>), grid, dim3(256), 0, st, a); break;
-    case 1: hipLaunchKernelGGL((mm_kernel<128, 64, AKC, BKC, PRO>), grid, dim3(256), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((mm_kernel<64, 128, AKC, BKC, PRO>), grid, dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((mm_kernel<64, 64, AKC, BKC, PRO>), grid, dim3(256), 0, st, a); break;
+    case 0: hipLaunchKernelGGL((mm_kernel<128, 128, AKC, BKC, PRO, LONGK>), grid, dim3(256), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((mm_kernel<128, 64, AKC, BKC, PRO, LONGK>), grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((mm_kernel<64, 128, AKC, BKC, PRO, LONGK>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((mm_kernel<64, 64, AKC, BKC, PRO, LONGK>), grid, dim3(256), 0, st, a); break;
   }
   return ttdg_launch_status("mm_f32");
 }
 
-// tile code: bit 1 = BM 64 (else 128), bit 0 = BN 64 (else 128).  Largest tile that still gives every CU two workgroups' worth of
-// tiles when the matrix has them; N <= 64 never takes a 128-wide tile.
-static int mm_pick_tile(int M, int N, int kslices) {
-  int best = 3;
-  for (int t = 0; t < 4; ++t) {
-    const int bm = t >> 1 ? 64 : 128, bn = t & 1 ? 64 : 128;
-    if (bn == 128 && N <= 64) continue;
-    const long tiles = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn) * (kslices > 0 ? kslices : 1);
-    if (tiles >= 512) return t;
-    best = 3;
-  }
-  return best;
-}
+// tile code: bit 1 = BM 64 (else 128), bit 0 = BN 64 (else 128).  Measured on every pointwise layer of the bench shape, forward and
+// both backward products (profiles/r06_pointwise_ab_*.txt): the 64 x 64 tile - five workgroups per CU, 16 accumulator registers per
+// wavefront - wins or ties everywhere (the 128 x 128 tile's two workgroups per CU expose the LDS-DMA latency of its two-stage ring);
+// the larger tiles stay selectable per call for the A/B.
+static int mm_pick_tile(int M, int N, int kslices) { return 3; }
 
 extern "C" size_t ttdg_mm_workspace_bytes(int M, int N, int kslices) { return kslices > 1 ? (size_t)kslices * M * N * sizeof(float) : 0; }
 
@@ -384,9 +404,12 @@ extern "C" int ttdg_mm_f32(const ttdg_mm_t* d, ttdg_stream_t stream) {
   TTDG_REQUIRE(tile >= 0 && tile < 4, "mm: tile code");
   dim3 gy(1, ks ? ks : 1);
   int rc;
-  if (d->a_layout == 0 && d->b_layout == 0) rc = d->pbias ? mm_launch<true, true, true>(tile, a, gy, st) : mm_launch<true, true, false>(tile, a, gy, st);
-  else if (d->a_layout == 0) rc = mm_launch<true, false, false>(tile, a, gy, st);
-  else rc = mm_launch<false, false, false>(tile, a, gy, st);
+  const bool longk = (ks ? a.kc : d->K) >= 1024;                  // (per workgroup: a split reduction restarts its chains per slice anyway)
+#define MM_GO(AKC, BKC, PRO) (longk ? mm_launch<AKC, BKC, PRO, true>(tile, a, gy, st) : mm_launch<AKC, BKC, PRO, false>(tile, a, gy, st))
+  if (d->a_layout == 0 && d->b_layout == 0) rc = d->pbias ? MM_GO(true, true, true) : MM_GO(true, true, false);
+  else if (d->a_layout == 0) rc = MM_GO(true, false, false);
+  else rc = MM_GO(false, false, false);
+#undef MM_GO
   if (rc || !ks) return rc;
   const size_t quads = (size_t)d->M * (d->N >> 2);
   hipLaunchKernelGGL(mm_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, a.part, ks, d->C, d->ldc, d->bias, d->M, d->N);

@@ -24,6 +24,18 @@ FUSED_HEADS = True
 # FPN.forward moves its filters to channels-last storage at the first GPU forward and converts the image batch; every kernel behind ops.* takes either
 # layout.  (False keeps NCHW: the layout parity test.)
 CHANNELS_LAST = True
+# The pointwise (1 x 1) convolutions of the channels-last backbone - bottleneck conv1 / conv3 / projection shortcut, FPN laterals -
+# run on the repo's own streaming MFMA product with shift, residual (+ the FPN's up-sampled top-down map) and ReLU applied in its
+# epilogue (ops.pointwise_conv, csrc/pointwise.hip): no epilogue pass over HBM, and where gradients flow the two backward products
+# without MIOpen's atomic weight-gradient kernels and their zero fills (ops.PointwiseConvFn).  False: vendor convolution + the
+# one-pass epilogue kernel (the A/B arm, and the exact-equality parity tests of the epilogue kernels).
+OWN_POINTWISE = True
+# ... and in the blocks without a tape the 3 x 3 convolution's own epilogue (shift + ReLU) is applied by the NEXT product while it
+# fetches its operand (ops.pointwise_conv(pbias=, prelu=)), instead of an in-place pass over the 3 x 3 output
+FUSED_INPUT_ACTIVATION = True
+# stages whose pointwise convolutions stay on the vendor kernels: at 25 x 25 x 4 = 2500 pixels the streaming product's 64 x 64 tiles
+# leave CUs idle (in-situ A/B per block, profiles/r06_pointwise_ab_in_situ.txt: res2 - res4 x1.04 - 1.18, res5 x0.91 - 0.96)
+POINTWISE_MIN_PIXELS = 4096
 
 
 _CAPTURING = False      # set by modeling/graphed.py while a hipGraph capture records the forward: no host synchronisation then
@@ -90,14 +102,24 @@ class ConvNorm(nn.Conv2d):
         self._staged_w = None            # the folded filter of the current forward pass, when the stage folded all of its filters at once
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")
 
-    def raw(self, x):
-        """(convolution with the folded filter, WITHOUT its shift; the shift) - for the fused in-place epilogue."""
+    def folded_const(self):
+        """(folded filter, shift) as constants: frozen filter or a no-grad pass; cached until the weights move."""
         scale, shift = self.norm.folded()
         key = (self.weight._version, self.weight.data_ptr(), self.norm._fold[0])
         if self._wfold is None or self._wfold[0] != key:
             with torch.no_grad():
                 self._wfold = (key, _publish(self.weight * scale))
-        return F.conv2d(x, self._wfold[1], None, self.stride, self.padding), shift
+        return self._wfold[1], shift
+
+    def folded_on_tape(self):
+        """(folded filter on the autograd tape, shift) for a filter that is being adapted."""
+        scale, shift = self.norm.folded()
+        return (self._staged_w if self._staged_w is not None else self.weight * scale), shift
+
+    def raw(self, x):
+        """(convolution with the folded filter, WITHOUT its shift; the shift) - for the fused in-place epilogue."""
+        w, shift = self.folded_const()
+        return F.conv2d(x, w, None, self.stride, self.padding), shift
 
     def raw_on_tape(self, x):
         """raw() for a filter that is being adapted: the folded filter stays on the autograd tape."""
@@ -175,7 +197,44 @@ class Bottleneck(nn.Module):
         self.conv2 = ConvNorm(mid, mid, 3, padding=1)
         self.conv3 = ConvNorm(mid, cout, 1)
 
+    def _own(self, x):
+        st = self.conv1.stride[0]
+        pixels = x.shape[0] * ((x.shape[2] - 1) // st + 1) * ((x.shape[3] - 1) // st + 1)
+        return OWN_POINTWISE and pixels >= POINTWISE_MIN_PIXELS and ops.pointwise_ok(x, self.conv1.weight) and ops.pointwise_ok(x, self.conv3.weight)
+
     def forward(self, x):
+        if _fusable(x, self) and self._own(x):
+            # no gradient through this block: the two pointwise convolutions (and the projection shortcut) on the streaming product
+            # with their epilogues fused, the 3 x 3 convolution on the vendor kernel + the in-place epilogue
+            w1, b1 = self.conv1.folded_const()
+            y = ops.pointwise_conv(x, w1, b1, relu=True, stride=self.conv1.stride[0])
+            y, b2 = self.conv2.raw(y)
+            w3, b3 = self.conv3.folded_const()
+            if self.shortcut is not None:
+                ws, bs = self.shortcut.folded_const()
+                sc = ops.pointwise_conv(x, ws, bs, relu=False, stride=self.shortcut.stride[0])
+            else:
+                sc = x
+            if FUSED_INPUT_ACTIVATION:
+                # conv2's shift + ReLU ride on conv3's operand fetch (relu(y + b2[k]) on the fragments): the 3 x 3 output is read once
+                return ops.pointwise_conv(y, w3, b3, residual=sc, relu=True, pbias=b2, prelu=True)
+            return ops.pointwise_conv(ops.bias_act_(y, b2), w3, b3, residual=sc, relu=True)
+        if _fusable_on_tape(x) and self._own(x):
+            pw, fused = ops.PointwiseConvFn.apply, ops.BiasActFn.apply
+            w1, b1 = self.conv1.folded_on_tape()
+            st = self.conv1.stride[0]
+            if st > 1:                        # conv1 and the projection shortcut read the same strided pixels: compacted once
+                x = ops.StridedSliceFn.apply(x, st)
+            y = pw(x, w1, b1, None, None, True, 1, False)
+            y, b2 = self.conv2.raw_on_tape(y)
+            y = fused(y, b2, None, None)
+            w3, b3 = self.conv3.folded_on_tape()
+            if self.shortcut is not None:
+                ws, bs = self.shortcut.folded_on_tape()
+                sc = pw(x, ws, bs, None, None, False, 1, False)
+            else:
+                sc = x
+            return pw(y, w3, b3, sc, None, True, 1, False)
         if _fusable(x, self):
             # no gradient through this block: three in-place epilogues instead of eight elementwise passes
             y, b = self.conv1.raw(x)
@@ -279,6 +338,19 @@ class FPN(nn.Module):
             return ops.BiasAddFn.apply(y, conv.bias, residual)
         return ops.bias_act_(y, conv.bias, residual, None, relu=False)
 
+    @staticmethod
+    def _lateral(conv, c, coarse=None):
+        """lateral(c) + bias (+ the coarser level, nearest-neighbour up-sampled): one fused product on the GPU's channels-last fp32
+        path (the up-sampled map is never materialised), conv + interpolate + add otherwise."""
+        if OWN_POINTWISE and FUSED_HEADS and FUSED_EPILOGUE and not torch.is_autocast_enabled() and ops.pointwise_ok(c, conv.weight) \
+                and c.shape[0] * c.shape[2] * c.shape[3] >= POINTWISE_MIN_PIXELS \
+                and (coarse is None or (coarse.is_contiguous(memory_format=torch.channels_last) and coarse.dtype == torch.float32
+                                        and coarse.shape[2] * 2 == c.shape[2] and coarse.shape[3] * 2 == c.shape[3])):
+            if torch.is_grad_enabled() and (c.requires_grad or conv.weight.requires_grad or conv.bias.requires_grad or (coarse is not None and coarse.requires_grad)):
+                return ops.PointwiseConvFn.apply(c, conv.weight, conv.bias, coarse, None, False, 1, coarse is not None)
+            return ops.pointwise_conv(c, conv.weight, conv.bias, residual=coarse, res_up=coarse is not None)
+        return FPN._conv(conv, c, None if coarse is None else F.interpolate(coarse, scale_factor=2.0, mode="nearest"))
+
     def forward(self, x):
         if CHANNELS_LAST and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled():
             if not self.fpn_output2.weight.is_contiguous(memory_format=torch.channels_last):
@@ -287,11 +359,11 @@ class FPN(nn.Module):
                 self.to(memory_format=torch.channels_last)
             x = x.contiguous(memory_format=torch.channels_last)
         c2, c3, c4, c5 = self.bottom_up(x)
-        prev = self._conv(self.fpn_lateral5, c5)
+        prev = self._lateral(self.fpn_lateral5, c5)
         p5 = self._conv(self.fpn_output5, prev)
         outs = [p5]
         for i, c in ((4, c4), (3, c3), (2, c2)):
-            prev = self._conv(getattr(self, "fpn_lateral%d" % i), c, F.interpolate(prev, scale_factor=2.0, mode="nearest"))
+            prev = self._lateral(getattr(self, "fpn_lateral%d" % i), c, prev)
             outs.insert(0, self._conv(getattr(self, "fpn_output%d" % i), prev))
         outs.append(F.max_pool2d(p5, kernel_size=1, stride=2, padding=0))
         return dict(zip(("p2", "p3", "p4", "p5", "p6"), outs))
