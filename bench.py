@@ -82,6 +82,8 @@ def parse(argv=None):
     ap.add_argument("--timer-every", type=int, default=7, help="HIP-event pairs around every N-th launch of the kernels launched dozens of times per batch "
                     "(ops.KERNEL_TIMER_SAMPLED; 1 = every launch, the round 1-5 protocol, which costs ~4 %% of the timed region)")
     ap.add_argument("--own-pointwise-backward", action="store_true", help="A/B: dX / dW of the 1 x 1 convolutions on the streaming product's backward layouts instead of MIOpen")
+    ap.add_argument("--no-cfg3", action="store_true", help="skip the cfg-3 operator-level block and the whole-step FLOP count")
+    ap.add_argument("--stamp-all", action="store_true", help="rounds 1-5 protocol: the headline pass itself stamps every hand-written kernel (no separate instrumented pass)")
     ap.add_argument("--no-kernel-timers", action="store_true", help="debug A/B: no HIP events around the hand-written kernels in the timed pass (the rooflines are then empty): what the event pairs themselves cost")
     ap.add_argument("--vendor-pointwise", action="store_true", help="A/B: the backbone's 1 x 1 convolutions on MIOpen + the one-pass epilogue kernel (round 5) instead of the fused streaming product (csrc/pointwise.hip)")
     ap.add_argument("--no-miopen-db", action="store_true", help="A/B: ignore the tuned MIOpen find-db shipped in ttdg-mgm_amd/miopen_db (MIOpen's heuristic picks the solvers)")
@@ -193,7 +195,7 @@ def build_model(cfg, args, device, weights, calib_batch, world):
 
 
 # ------------------------------------------------------------------------------------------- the timed pass
-def timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, world, device, teacher_forced, loader_factory=None):
+def timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, world, device, teacher_forced, loader_factory=None, only=None):
     """W untimed warm-up batches, then EXACTLY K adapted batches (K TTA steps, then the Dice pass over the same K batches)
     between barrier + synchronize on both sides.  ``loader_factory`` (A/B): the K timed batches come from a streaming loader
     (decode / synthesise + resize + H2D inside the loop, 2-deep prefetch) instead of the resident list."""
@@ -228,6 +230,7 @@ def timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, w
     evaluate(batches[:W])
     stamps = []
     ops.KERNEL_TIMERS = None if args.no_kernel_timers else stamps          # (name, start_event, end_event, meta, info) recorded around our kernels
+    ops.KERNEL_TIMER_ONLY = None if only is None else set(only)           # which kernels carry HIP-event pairs in THIS pass
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -241,6 +244,7 @@ def timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, w
         dist.barrier()
     t1 = time.perf_counter()
     ops.KERNEL_TIMERS = None
+    ops.KERNEL_TIMER_ONLY = None
     el, tta = t1 - t0, t_mid - t0
     if world > 1:
         t = torch.tensor([el, tta], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
@@ -348,6 +352,102 @@ def pmc_traffic(stamp_name):
                 return rec["hbm_bytes_per_launch_mean_streaming_corrected"]        # many launch sizes: mean, like `achieved`
             return rec["hbm_bytes_per_launch_streaming_corrected" if streaming else "hbm_bytes_per_launch_raw"]
     return None
+
+
+# ------------------------------------------------------------------------------------------- whole-step roofline + cfg-3
+def step_flops(cfg, model, init_state, batch, teacher_forced):
+    """Algorithmic fp32 FLOPs of ONE adapted batch (TTA step forward + backward, then the eval-mode inference): counted, not
+    estimated - torch.utils.flop_counter over the aten convolutions / matrix products of one un-timed batch with the pointwise
+    convolutions routed to aten (same arithmetic as the fused product: 2 * pixels * Cin * Cout), plus the hand-written matching
+    kernels' own formulas (affinity 4 h n_i n_j per ordered pair, x 3 with its backward; they are < 0.1 % of the
+    step).  ROIAlign, NMS, Sinkhorn sweeps and element-wise work are not counted (they are not matrix work)."""
+    from torch.utils.flop_counter import FlopCounterMode
+    from ttdg_mgm_amd.engine import BaselineTrainer
+    from ttdg_mgm_amd.engine.trainer import run_eval_batches
+    from ttdg_mgm_amd.evaluation import DiceEvaluator
+    from ttdg_mgm_amd.modeling import backbone as bb
+    model.load_state_dict(init_state)
+    model.teacher_forced = teacher_forced
+    opt = BaselineTrainer.build_optimizer(cfg, model)
+    keep = bb.OWN_POINTWISE
+    bb.OWN_POINTWISE = False
+    try:
+        model.train()
+        with FlopCounterMode(display=False) as fc_tta:
+            BaselineTrainer.tta_step(model, opt, batch)
+        model.eval()
+
+        class _Sink:
+            def process(self, *a, **k):
+                pass
+        with FlopCounterMode(display=False) as fc_eval:
+            run_eval_batches(model, [batch], _Sink(), 1, 1)
+        model.train()
+    finally:
+        bb.OWN_POINTWISE = keep
+    tta, ev = float(fc_tta.get_total_flops()), float(fc_eval.get_total_flops())
+    return {"flops_per_step": tta + ev, "tta_step_flops": tta, "eval_pass_flops": ev,
+            "counted": "aten convolution / addmm / mm / bmm FLOPs (2 per multiply-add) of one adapted batch of %d images, forward and backward, torch.utils.flop_counter; "
+                       "hand-written matching kernels and element-wise work not included (< 0.1 %%)" % len(batch),
+            "peak_tflops": FP32_PEAK_TFLOPS, "peak": "fp32 matrix = fp32 vector peak (MI355X_MICROARCH.md)"}
+
+
+def cfg3_block(device, seeds=(0, 1, 2, 3, 4), reps=20):
+    """BASELINE.json configs[2]: MGM3_unsup on 8 graphs x 256 nodes (nodes = randn(256, 256) * 0.1, labels in
+    {1, 2}, U = randn(32, 256) + 1/32, weights std 0.05, seeds 0..4), forward + backward, HIP events on the launch stream, `reps`
+    repetitions per seed after 3 warm-up steps; per-kernel averages from a separate stamped repetition set (rooflines as in
+    kernel_rooflines: SURVEY.md §8d algorithmic work / live duration)."""
+    from ttdg_mgm_amd import ops, synth
+    from ttdg_mgm_amd.GModule import MGM3_unsup
+    sizes = (256,) * 8
+    fb, fw, its, solver_us, kern = [], [], [], [], {}
+    for seed in seeds:
+        params, U = synth.mgm3_params(9000 + seed), synth.universe(9100 + seed)
+        nodes, labels = synth.node_sets(9200 + seed, sizes, scale=0.1)
+        m = MGM3_unsup(2, 32).to(device).eval()
+        m.load_state_dict(params)
+        dn = [x.to(device).requires_grad_() for x in nodes]
+        dl = [l.to(device) for l in labels]
+        Ud = U.to(device)
+        for _ in range(3):
+            m(dn, dl, Ud).backward()
+        torch.cuda.synchronize()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        for _ in range(reps):
+            m(dn, dl, Ud).backward()
+        e[1].record()
+        with torch.no_grad():
+            for _ in range(reps):
+                m(dn, dl, Ud)
+        e[2].record()
+        torch.cuda.synchronize()
+        fb.append(e[0].elapsed_time(e[1]) / reps)
+        fw.append(e[1].elapsed_time(e[2]) / reps)
+        stamps = []
+        ops.KERNEL_TIMERS, keep_every = stamps, ops.KERNEL_TIMER_EVERY
+        ops.KERNEL_TIMER_EVERY = 1
+        try:
+            for _ in range(5):
+                m(dn, dl, Ud).backward()
+            torch.cuda.synchronize()
+        finally:
+            ops.KERNEL_TIMERS, ops.KERNEL_TIMER_EVERY = None, keep_every
+        for r in kernel_rooflines({"stamps": stamps}):
+            k = kern.setdefault(r["kernel"], {"avg_us": [], "frac": [], "work": [], "bound": r["bound"], "unit": r["unit"]})
+            k["avg_us"].append(r["avg_launch_ms"] * 1e3)
+            k["frac"].append(r["frac"])
+            k["work"].append(r["algorithmic_work_per_launch"])
+            if r["kernel"] == "gagm_kernel":
+                its.append(r["avg_iterations_per_launch"])
+                solver_us.append(r["avg_launch_ms"] * 1e3)
+    mean = lambda v: sum(v) / max(1, len(v))
+    return {"workload": "cfg-3: MGM3_unsup forward + backward, 8 graphs x 256 nodes, d = 256, h = 512, seeds %s, %d repetitions each (HIP events on the launch stream)" % (list(seeds), reps),
+            "fwd_bwd_ms": mean(fb), "fwd_bwd_ms_per_seed": fb, "fwd_ms": mean(fw), "fwd_ms_per_seed": fw,
+            "solver_us": mean(solver_us) if solver_us else None, "executed_iterations": mean(its) if its else None,
+            "solver_us_per_iteration": (mean(solver_us) / mean(its)) if its and mean(its) else None,
+            "kernels": {k: {"avg_us": mean(v["avg_us"]), "algorithmic_work": mean(v["work"]), "frac": mean(v["frac"]), "bound": v["bound"],
+                            "unit": "bytes" if v["bound"] == "hbm" else "FLOP"} for k, v in kern.items()}}
 
 
 # ------------------------------------------------------------------------------------------- CPU baseline + Dice parity
@@ -623,7 +723,13 @@ def gpu_main(args, rank, world, local):
     model = build_model(cfg, args, device, weights, batches[0], world)
     init_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
     tf = bool(args.teacher_forced)
-    main = timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, world, device, tf)
+    # The headline pass carries HIP-event pairs around ONE kernel family only - the dominant hand-written kernel, whose live average
+    # feeds `roofline` - sampled every --timer-every-th launch.  Every other hand-written kernel is timed in a SECOND, fully stamped
+    # pass over the same batches (`instrumented_pass`, the source of `roofline_other_kernels`): an event pair is two marker packets in
+    # the launch queue, and ~250 pairs per batch cost 1.7 ms of a 38.4 ms batch (profiles/r06_event_overhead.txt).
+    dominant = ("bias_act",) if args.vendor_pointwise else ("pointwise_fwd",)
+    main = timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, world, device, tf, only=None if args.stamp_all else dominant)
+    instrumented = main if args.stamp_all or args.no_kernel_timers else timed_pass(cfg, model, init_state, batches, local_dicts, name, K, W, args, world, device, tf)
     eager_probe = None
     if _graphed.ENABLED and model.__dict__.get("_graphed") is not None and model.__dict__["_graphed"].stats["eval_replays"] > 0:
         # Inside a graph replay no HIP event can be placed around a single kernel from here.  The per-kernel durations of the
@@ -771,10 +877,22 @@ def gpu_main(args, rank, world, local):
         note("Dice parity leg (GPU)")
         parity = {"gpu": gpu_dice_parity_leg(cfg, model, init_state, batches[0], local_dicts, name, tf)}
 
+    step_roof = cfg3 = None
+    if world == 1 and not args.no_cfg3:
+        try:
+            note("whole-step FLOP count")
+            step_roof = step_flops(cfg, model, init_state, batches[W], tf)
+            note("cfg-3 operator-level block (8 graphs x 256 nodes)")
+            cfg3 = cfg3_block(device)
+        except Exception as e:          # reports, never a reason to lose the headline
+            note("cfg-3 / step-roofline block failed: %r" % (e,))
+            cfg3 = {"error": repr(e)}
     if rank != 0:
         return
     images = world * K * B
-    roofs = kernel_rooflines(main)
+    roofs_head = kernel_rooflines(main)
+    roofs_all = roofs_head if instrumented is main else kernel_rooflines(instrumented)
+    roofs = roofs_head[:1] + [r for r in roofs_all if not roofs_head or r["kernel"] != roofs_head[0]["kernel"]]
     out = {
         "metric": "adapted images/sec (%dx%d, %d-class)" % (args.size, args.size, args.num_cls), "value": images / main["elapsed"], "unit": "images/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": main["elapsed"] / K * 1e3,
@@ -806,6 +924,18 @@ def gpu_main(args, rank, world, local):
         out["roofline"] = roofs[0]          # the hand-written kernel with the largest total time in the timed region (live HIP events)
         out["roofline"]["traffic_note"] = "HBM bytes per launch from the committed PMC passes of this command (profiles/), null when not collected"
         out["roofline_other_kernels"] = roofs[1:]
+        if instrumented is not main:
+            dom_all = roofs_all[0]["kernel"] if roofs_all else None
+            out["instrumented_pass"] = {"value": images / instrumented["elapsed"], "unit": "images/s", "ms_per_step": instrumented["elapsed"] / K * 1e3,
+                                        "dominant_kernel_by_total_time": dom_all,
+                                        "note": "same K batches with HIP-event pairs around EVERY hand-written kernel family (the per-layer ones every %d-th launch): the source of "
+                                                "roofline_other_kernels; the headline pass stamps %s only" % (args.timer_every, "/".join(dominant))}
+    if world == 1 and step_roof is not None:
+        step_roof.update(achieved_tflops=step_roof["flops_per_step"] / (main["elapsed"] / K) / 1e12)
+        step_roof["frac_fp32_mfma"] = step_roof["achieved_tflops"] / FP32_PEAK_TFLOPS
+        out["roofline_step"] = step_roof
+    if cfg3 is not None:
+        out["cfg3"] = cfg3
     if strong is not None:
         out["strong"] = strong
     if ab:

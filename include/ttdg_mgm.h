@@ -37,7 +37,10 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define TTDG_VERSION 100 /* 0.1.0 */
+#define TTDG_VERSION 110 /* 0.1.1: ttdg_gagm_solve writes TTDG_GAGM_INFO_WORDS = 24 int32 into `info` (0.1.0: 16, profile clocks at [8..11]);
+                          * a caller built against 0.1.0 that passes a 16-word buffer must be rebuilt (INTEGRATION.md "ABI changes");
+                          * new entry points ttdg_mm_f32 / ttdg_mm_workspace_bytes */
+#define TTDG_GAGM_INFO_WORDS 24 /* int32 words of the `info` buffer of ttdg_gagm_solve */
 #define TTDG_MAX_GRAPHS 64
 #define TTDG_UNIV 32            /* universe size (rcnn.py:116) */
 #define TTDG_EINVAL (-1)
@@ -160,7 +163,7 @@ int ttdg_mha_adjacency(const float* q, const float* k, int d, ttdg_graphs_t gr, 
  * (multi_graph_matching.py:223-244, 300-389 with num_clusters == 1; utils/hungarian.py:8-66 ->
  * scipy.optimize.linear_sum_assignment [3P] re-implemented on device, one wavefront per LAP.)
  * Apack as above, W = Wds (M x M), U0 (M x 32).  U (M x 32) receives the 0/1 matching.
- * info (int32[24], device, zero-initialised by the caller): [0..5] iterations per stage, [6] total, [7] stages run,
+ * info (int32[TTDG_GAGM_INFO_WORDS], device, zero-initialised by the caller): [0..5] iterations per stage, [6] total, [7] stages run,
  * [8] STATUS and nothing else (0 = ok; the cooperative multi-workgroup kernel: 1 = a grid barrier timed out, 2 = the stage
  * machine did not stop - U is then NaN); [12] Hungarian-stage LAPs solved with a uniqueness certificate, [13] LAPs that fell back to
  * the scipy-order solver (multi-workgroup solver), [21] narrow-range LAPs solved by the integer scipy-order solver; [14], [15] period and detection iteration of a Hungarian-stage cycle;

@@ -427,18 +427,25 @@ def test_sinkhorn_module_2d_and_transposed_view(dev):
     assert maxerr(sk(s.to(dev).t(), dummy_row=True), osk(s.t(), dummy_row=True, max_iter=20, tau=0.05)) <= TOL
 
 
-@pytest.mark.parametrize("sizes,ks", [((9, 14), 2), ((22, 22, 22), 2), ((22, 35, 28, 40), 2), ((5, 3), 2), ((70, 120), 1),
-                                      ((140, 200, 256), 1), ((256, 130), 1), ((200, 31, 200), 1), ((150, 129), 2)])
-def test_pair_sinkhorn_forward_backward(dev, sizes, ks):
+@pytest.mark.parametrize("sizes,ks,spike", [((9, 14), 2, None), ((22, 22, 22), 2, None), ((22, 35, 28, 40), 2, None), ((5, 3), 2, None), ((70, 120), 1, None),
+                                            ((140, 200, 256), 1, None), ((256, 130), 1, None), ((200, 31, 200), 1, None), ((150, 129), 2, None),
+                                            ((200, 150), 1, -12.0), ((256, 256), 1, -10.0), ((256, 3, 2), 1, None), ((130, 1, 3), 1, None)])
+def test_pair_sinkhorn_forward_backward(dev, sizes, ks, spike):
     """Pair stage (Wds) and its backward against autograd through the oracle's Sinkhorn.  Sizes above 128 nodes with a
     single K plane run the register-resident kernels (matrix / dY in the register file of one workgroup); with two
-    planes they fall back to the LDS / L2 kernels."""
+    planes they fall back to the LDS / L2 kernels.  ``spike`` (one column and one row of every block shifted: the scaling form's
+    potentials leave its range) sends the register kernels' BACKWARD through the log-domain fall-back, where the incoming gradient and
+    the result share one buffer; graphs of 1 - 3 nodes next to a graph above 128 exercise the blocks without a whole 16-byte piece."""
     from oracle import gmodule as og
     from ttdg_mgm_amd import ops
     G, M = len(sizes), sum(sizes)
     off = np.concatenate([[0], np.cumsum(sizes)])
     g = synth.gen(sum(sizes) * 13)
     Mraw = synth.normal(g, (M, M), 0.1)
+    if spike is not None:
+        for a in range(G):
+            Mraw[:, off[a] + 3] += spike
+            Mraw[off[a] + 5, :] += spike
     Rw = synth.normal(g, (M, M), 1.0)
     b2 = torch.tensor([0.03])
     # oracle: same loop as multi_graph_matching.py:504-525 on the raw affinities

@@ -13,6 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libttdg_mgm.so")
 
+GAGM_INFO_WORDS = 24      # TTDG_GAGM_INFO_WORDS (include/ttdg_mgm.h): int32 words ttdg_gagm_solve writes into `info`
 MAX_GRAPHS = 64
 MAX_LEVELS = 8
 UNIV = 32

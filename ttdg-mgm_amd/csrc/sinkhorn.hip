@@ -183,6 +183,16 @@ __device__ __forceinline__ void skr_quad_load(const float* __restrict__ base, in
   if (kAlongQ) {
     // every lane issues the 16-byte load from an in-bounds address (lanes at or beyond the block's last columns read the block's last
     // four columns: those values are never used); the one lane that straddles the edge then fetches its valid elements one by one
+    // (a block of fewer than four columns has no in-bounds 16-byte piece at all: every lane takes the clamped scalar loads)
+    if (c < 4) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float* rowp = base + (int64_t)min(pp + t, r - 1) * sp;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) D[t][j] = rowp[min(q0 + j, c - 1)];
+      }
+      return;
+    }
     const int qs = min(q0, c - 4);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -544,8 +554,10 @@ extern "C" int ttdg_sinkhorn_pairs_fwd(const float* part, int ksplit, const floa
 // pt: logged potentials of the forward (iters x potld); dout(p,q) / dm(p,q) addressed with the given strides.
 // smem carve: [f: c+1][g: c][ls: c+1][dd: c][L: r*ldm (kLds)][dY: r*ldm (kLds)]
 template <bool kLds>
-__device__ void sk_backward(const SkProb& pb, const float* __restrict__ pt, int potld, const float* __restrict__ dout, int64_t dop,
-                            int64_t doq, float* __restrict__ dm, int64_t dmp, int64_t dmq, float* smem, int iters, float tau) {
+// dout and dm MAY ALIAS (the scaling-form backward's cold path passes the dM block as both: every thread reads exactly the
+// elements it overwrites at the end) - no __restrict__ on either.
+__device__ void sk_backward(const SkProb& pb, const float* __restrict__ pt, int potld, const float* dout, int64_t dop,
+                            int64_t doq, float* dm, int64_t dmp, int64_t dmq, float* smem, int iters, float tau) {
   const int r = pb.r, c = pb.c, mult = pb.mult;
   const int ldm = c | 1;
   float* f = smem;            // r+1

@@ -22,6 +22,7 @@ KERNEL_TIMERS = None
 # positions rotate through all layers over the timed batches); kernels launched once or twice per batch are always stamped.
 KERNEL_TIMER_EVERY = 1
 KERNEL_TIMER_SAMPLED = ("bias_act", "relu_bwd", "pointwise_fwd", "pointwise_dx", "pointwise_dw")
+KERNEL_TIMER_ONLY = None          # a set of stamp names: only these are recorded (the headline pass stamps its dominant kernel only)
 _timer_counts = {}
 
 
@@ -29,7 +30,7 @@ class _timed:
     """Records (name, start_event, end_event, meta, None) into KERNEL_TIMERS around a launch when bench.py asks for it."""
 
     def __init__(self, name, meta):
-        self.name, self.meta, self.on = name, meta, KERNEL_TIMERS is not None
+        self.name, self.meta, self.on = name, meta, KERNEL_TIMERS is not None and (KERNEL_TIMER_ONLY is None or name in KERNEL_TIMER_ONLY)
         if self.on and KERNEL_TIMER_EVERY > 1 and name in KERNEL_TIMER_SAMPLED:
             n = _timer_counts.get(name, 0)
             _timer_counts[name] = n + 1
@@ -422,22 +423,23 @@ def gagm_solve_hostloop(apack, W, U0, sizes, cfg, states=None):
             tau *= float(cfg.gamma)
         else:
             hung = True
-    info = torch.zeros(24, dtype=torch.int32)
+    info = torch.zeros(_lib.GAGM_INFO_WORDS, dtype=torch.int32)
     info[:len(iters)] = torch.tensor(iters, dtype=torch.int32)
     info[6], info[7] = total, stage
     return U, info.to(dev), V0
 
 
-def gagm_solve(apack, W, U0, gr, sizes, cfg=None):
-    """Returns (U (M,32) 0/1, info int32[24] on device (include/ttdg_mgm.h), V0 (M,32) first-iteration V).  With the cooperative
-    one-launch form (TTDG_GAGM_ONE_LAUNCH) the status word info[8] is read back and a failed grid barrier raises."""
+def gagm_solve(apack, W, U0, gr, sizes, cfg=None, check_status=True):
+    """Returns (U (M,32) 0/1, info int32[TTDG_GAGM_INFO_WORDS] on device (include/ttdg_mgm.h), V0 (M,32) first-iteration V).  With the
+    cooperative one-launch form (TTDG_GAGM_ONE_LAUNCH) the status word info[8] is read back (a host synchronisation; pass
+    ``check_status=False`` to leave it to the caller, who reads ``info`` anyway) and a failed grid barrier raises."""
     M = sum(sizes)
     cfg = cfg or gagm_cfg()
     nbytes = _lib.load().ttdg_gagm_workspace_bytes(M)
     ws = torch.empty(nbytes // 4, device=W.device, dtype=torch.float32)
     U = torch.empty(M, UNIV, device=W.device, dtype=torch.float32)
-    info = torch.zeros(24, device=W.device, dtype=torch.int32)
-    timers = KERNEL_TIMERS
+    info = torch.zeros(_lib.GAGM_INFO_WORDS, device=W.device, dtype=torch.int32)
+    timers = KERNEL_TIMERS if (KERNEL_TIMER_ONLY is None or "gagm" in KERNEL_TIMER_ONLY) else None
     if timers is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -445,7 +447,7 @@ def gagm_solve(apack, W, U0, gr, sizes, cfg=None):
     if timers is not None:
         e1.record()
         timers.append(("gagm", e0, e1, list(sizes), info))
-    if int(getattr(cfg, "variant", 0)) & 64:          # TTDG_GAGM_ONE_LAUNCH: a barrier failure would otherwise only show as NaN in U
+    if check_status and int(getattr(cfg, "variant", 0)) & _lib.GAGM_ONE_LAUNCH:          # a barrier failure would otherwise only show as NaN in U
         status = int(info[8])
         if status:
             raise RuntimeError("ttdg_gagm_solve (one cooperative launch): status %d (%s)" % (status, "a grid barrier timed out" if status == 1 else "the stage machine did not stop"))

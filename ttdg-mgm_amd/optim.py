@@ -102,7 +102,7 @@ class FusedSGD(torch.optim.Optimizer):
         self._copied[slot] = ev
         base = devbuf.data_ptr()
         from . import ops
-        timers = ops.KERNEL_TIMERS
+        timers = ops.KERNEL_TIMERS if (ops.KERNEL_TIMER_ONLY is None or "sgd" in ops.KERNEL_TIMER_ONLY) else None
         if timers is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
