@@ -217,6 +217,8 @@ def _outside_round4_bound(obj, ref_objs, sizes):
 
 
 CENSUS_STEPS = 16
+CENSUS_MAX_OUTSIDE_R4 = 2       # pre-registered count of batches allowed outside round 4's per-batch bound (recorded per batch as outside_round4_bound)
+CENSUS_ARITH_Z = 3.5            # two-sided gate of the rank sum against the four arithmetic-only oracle members (4.7e-4 for independent batches)
 CENSUS_MIN_DEFINED_STATES = 40  # of 16 x 3 stage-end states (tau = 0.1, 0.05, 0.025) on which the reference's own eight runs must agree to
                                 # STATE_TOL for the state statement to be non-vacuous: a property of the REFERENCE ALGORITHM on the bench's inputs
                                 # (its final answer is well defined on 0 of 16 batches - profiles/r03_trained_census.json - its early states are)
@@ -291,21 +293,46 @@ def test_trained_regime_solver_census(trained):
     # extreme one).  A solver that is systematically worse - every batch below the reference's worst answer - gives z = -6.2.
     assert z_obj >= -5.0, z_obj                  # one-sided: never systematically below the reference's objective
     assert abs(z_loss) <= 5.0, z_loss
+    # [r6, VERDICT r5 item 4] The eight members are TWO populations: runs 0-3 differ from the float32 run by arithmetic only (float64;
+    # inputs x (1 +- 1e-7), x (1 +- 1e-6)), runs 4-7 multiply noise into EVERY Sinkhorn-stage projection - an annealing that reaches
+    # better optima of the chaotic last stage (their objectives sit above the others': profiles/r06_census_restated.txt, device
+    # against the noise members alone z = -1.2 ... -3.0).  A second fp32 implementation of the same arithmetic belongs to the FIRST
+    # population, so the asserted statistic is the rank sum against runs 0-3, two-sided, at 3.5: over the four boxes whose per-batch
+    # records are committed (r03, r04, r05, r06 box 1) it reads -1.41 ... +1.68 (objective) and -0.80 ... +2.30 (loss), mean
+    # -0.42 / +0.77 - inside +- 2 / sqrt(4).  The eight-member figures above stay asserted at their old width and recorded.
+    z_obj_a = admission.rank_sum_z([r["objective_device"] for r in weak], [r["objective_oracle_runs"][:4] for r in weak]) if weak else 0.0
+    z_loss_a = admission.rank_sum_z([r["loss_device"] for r in weak], [r["loss_oracle_runs"][:4] for r in weak]) if weak else 0.0
+    z_obj_n = admission.rank_sum_z([r["objective_device"] for r in weak], [r["objective_oracle_runs"][4:] for r in weak]) if weak else 0.0
+    z_loss_n = admission.rank_sum_z([r["loss_device"] for r in weak], [r["loss_oracle_runs"][4:] for r in weak]) if weak else 0.0
+    assert abs(z_obj_a) <= CENSUS_ARITH_Z and abs(z_loss_a) <= CENSUS_ARITH_Z, (z_obj_a, z_loss_a)
+    # RECORDED, not asserted (it fails on real boxes and says why): min(arithmetic-only) - range(arithmetic-only) as a per-batch floor.
+    # On some batches the four arithmetic members agree to < 1e-4 of the median while the device sits in another optimum of the same
+    # multimodal map (r06 box 1: 3 of 16 batches, worst 11 % of the median below - the reference's own eight answers differ by up to
+    # 13 - 55 % of the median on the batches of the same boxes).  The asserted per-batch statement stays the gross-error floor.
+    below_arith = sum(r["objective_device"] < min(r["objective_oracle_runs"][:4]) - (max(r["objective_oracle_runs"][:4]) - min(r["objective_oracle_runs"][:4])) for r in weak)
     outside = sum(not admission.within_spread(r["objective_device"], r["objective_oracle_runs"]) for r in weak) + \
         sum(not admission.within_spread(r["loss_device"], r["loss_oracle_runs"]) for r in weak)
     summary = dict(steps=len(rec), strong=nstrong, weak=len(rec) - nstrong, first_three_stage_counts_identical=len(rec), first_four_stage_counts_identical=n4, device_equals_oracle32=sum(r["device_equals_oracle32"] for r in rec),
                    mean_iterations=sum(sum(r["device_iters"]) for r in rec) / len(rec),
                    stage_states_defined_by_the_reference=ndef, stage_states_worst_device_deviation=worst, state_tolerance=STATE_TOL,
                    rank_sum_z_objective=z_obj, rank_sum_z_loss=z_loss, outside_reference_min_max=outside, min_max_checks=2 * len(weak),
+                   rank_sum_z_objective_arithmetic_only=z_obj_a, rank_sum_z_loss_arithmetic_only=z_loss_a,
+                   rank_sum_z_objective_projection_noise=z_obj_n, rank_sum_z_loss_projection_noise=z_loss_n,
+                   below_arithmetic_only_floor=below_arith,
                    outside_round4_bound=sum(r["outside_round4_bound"] for r in rec),
                    records=rec)
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "trained_census.json"), "w") as f:
         json.dump(summary, f, indent=1)
+    # [r6, ADVICE r5] round 4's per-batch bound is no longer a per-batch assertion (it failed once on a fresh box with unchanged kernels),
+    # but its violation COUNT is pre-registered: 0 on the eleven boxes recorded since (profiles/r05_boxes.json, r06), 1 on the box that
+    # retired it - more than CENSUS_MAX_OUTSIDE_R4 of 16 batches outside it fails the run.
+    assert summary["outside_round4_bound"] <= CENSUS_MAX_OUTSIDE_R4, summary["outside_round4_bound"]
     print("trained-regime census: stage states defined by the reference (of %d batches) %s, worst device deviation there %s; final answer well "
-          "defined on %d; rank-sum z objective %.2f loss %.2f; outside the reference's min-max %d of %d checks"
-          % (len(rec), ndef, ["%.1e" % w for w in worst], nstrong, z_obj, z_loss, outside, 2 * len(weak)))
+          "defined on %d; rank-sum z objective %.2f loss %.2f (arithmetic-only members %.2f / %.2f, projection-noise members %.2f / %.2f); "
+          "outside the reference's min-max %d of %d checks; below the arithmetic-only floor %d"
+          % (len(rec), ndef, ["%.1e" % w for w in worst], nstrong, z_obj, z_loss, z_obj_a, z_loss_a, z_obj_n, z_loss_n, outside, 2 * len(weak), below_arith))
     assert len(rec) == CENSUS_STEPS
 
 
@@ -327,7 +354,15 @@ def test_solver_answers_are_exchangeable_with_the_reference():
                   draws and the device 25): the two mixtures may legitimately differ, so only the direction that would be a defect is
                   gated - the device must not be systematically WORSE: pooled z of the objective >= -3.5, of the loss <= +3.5.
     Recorded at the freeze (profiles/r05_census_exchangeability.json): eps 1e-5: z objective +1.49, z loss -1.38; eps 1e-7: +3.08 / -4.20
-    (the device's answers are, if anything, better)."""
+    (the device's answers are, if anything, better).
+    [r6] Where the -4.20 comes from (per input, same record): three of the eight inputs carry it - input 5 (z loss -2.62; the oracle's
+    48 draws land on 4 distinct answers, the device's on 7), input 6 (-2.99; 3 and 4 distinct answers) and input 7 (-3.83; 48 distinct
+    answers on both sides, device mean objective 210.9 against 205.1, mean loss 0.0094 against 0.0114); input 2 has ONE oracle answer
+    for 48 draws and 15 device answers.  At one ulp a side does not sample a neighbourhood, it enumerates the few basins its own
+    rounding sequence can reach from that input; the two implementations' sequences differ by ~1e-6, so they enumerate different
+    (overlapping) basin sets with different weights, and a rank test between two short lists of atoms reads as a large |z|.  At
+    eps = 1e-5 both sides spread over the same neighbourhood (48 distinct answers each on 6 of 8 inputs) and the same inputs read
+    -0.41, -2.07, -2.87 - pooled -1.38."""
     import json
     import subprocess
     out = os.path.join(ROOT, "gpurun_out", "census_exchangeability.json")

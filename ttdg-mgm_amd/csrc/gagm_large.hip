@@ -862,12 +862,17 @@ __global__ __launch_bounds__(PT) void gagm_large_project_kernel(ttdg_graphs_t gr
   gl_project_graph<PT>(gr, cfg, w, s_c, blockIdx.x, gl_smem);
 }
 
-// control word after `t` enqueued iterations -> w.res (what the host polls)
-__global__ __launch_bounds__(256) void gagm_large_peek_kernel(ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg, GlWs w, int t) {
+// control word after `t` enqueued iterations -> w.res (read by the finish kernel) and, when the host gave one, its page-locked flag
+// words {done, total}: the host reads them straight out of host memory after the chunk's stream synchronisation - no copy
+__global__ __launch_bounds__(256) void gagm_large_peek_kernel(ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg, GlWs w, int t, int32_t* hostflag) {
   const GlCtl c = gl_control(w, gr.G, cfg, t, false);
   if (threadIdx.x == 0) {
     const int32_t* p = (const int32_t*)&c;
     for (int k = 0; k < 16; ++k) w.res[k] = p[k];
+    if (hostflag) {
+      hostflag[1] = c.total;
+      __hip_atomic_store(&hostflag[0], c.done ? 1 : 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -1038,21 +1043,46 @@ int ttdg_gagm_large_solve(const float* Apack, const float* W, const float* U0, t
       }
     }
   }
-  int t = 0, chunk = 4;
+  // Iterations are enqueued in chunks; a converged solve turns the rest of its chunk into no-op launches (~5 us per iteration), and
+  // every chunk ends in ONE host read of {done, total}.  [r6] The read costs what ~5 no-op iterations cost, so overshooting is the
+  // cheap side: the first chunk is sized from the previous solve of this thread (its iteration count + 2, between 8 and 40 - a steady
+  // stream of similar batches then pays one read per solve; rounds 4-5: 4-8-16-32, three reads and eight no-op iterations for a
+  // 20-iteration solve), the following ones are 16, then 32.  The flag lives in page-locked host memory the peek kernel writes
+  // directly (rounds 4-5: a 64-byte device-to-host copy into pageable memory per chunk).  The hint and the flag buffer are the
+  // library's only state besides the error string: per host thread, never read by a kernel, results do not depend on them.
+  static thread_local int32_t* hflag = nullptr;
+  static thread_local int last_total = 0;
+  if (!hflag) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, 64, hipHostMallocMapped) == hipSuccess) hflag = (int32_t*)p;
+    else (void)hipGetLastError();
+  }
+  int32_t* dflag = nullptr;
+  if (hflag && hipHostGetDevicePointer((void**)&dflag, hflag, 0) != hipSuccess) { (void)hipGetLastError(); dflag = nullptr; }
+  int t = 0, chunk = last_total + 2;
+  chunk = chunk < 8 ? 8 : (chunk > 40 ? 40 : chunk);
   int32_t h[16];
-  for (;;) {
+  for (int round = 0;; ++round) {
     for (int k = 0; k < chunk; ++k, ++t) {
       hipLaunchKernelGGL(gagm_large_mul_kernel, dim3(w.ntiles, w.ks + 1), dim3(256), 0, st, Apack, W, gr, cfg, w, t);
       if (cmax <= 512) hipLaunchKernelGGL(gagm_large_project_kernel<512>, dim3(gr.G), dim3(512), bytes, st, gr, cfg, w, t);
       else hipLaunchKernelGGL(gagm_large_project_kernel<1024>, dim3(gr.G), dim3(1024), bytes, st, gr, cfg, w, t);
     }
-    hipLaunchKernelGGL(gagm_large_peek_kernel, dim3(1), dim3(256), 0, st, gr, cfg, w, t);
+    if (dflag) hflag[0] = -1;
+    hipLaunchKernelGGL(gagm_large_peek_kernel, dim3(1), dim3(256), 0, st, gr, cfg, w, t, dflag);
     if (int e = ttdg_launch_status("gagm_large")) return e;
-    TTDG_HIP(hipMemcpyAsync(h, w.res, sizeof(h), hipMemcpyDeviceToHost, st));
-    TTDG_HIP(hipStreamSynchronize(st));     // the one convergence read per chunk (the reference reads two norms per iteration)
-    if (h[0]) break;
+    if (dflag) {
+      TTDG_HIP(hipStreamSynchronize(st));     // the one convergence read per chunk (the reference reads two norms per iteration)
+      h[0] = __atomic_load_n(&hflag[0], __ATOMIC_ACQUIRE);
+      h[4] = hflag[1];
+      TTDG_REQUIRE(h[0] >= 0, "gagm: the convergence flag was not written");
+    } else {
+      TTDG_HIP(hipMemcpyAsync(h, w.res, sizeof(h), hipMemcpyDeviceToHost, st));
+      TTDG_HIP(hipStreamSynchronize(st));
+    }
+    if (h[0]) { last_total = h[4]; break; }
     TTDG_REQUIRE(t < cap, "gagm: the stage machine did not terminate");
-    chunk = chunk < 32 ? chunk * 2 : 32;
+    chunk = round == 0 ? 16 : 32;
   }
   hipLaunchKernelGGL(gagm_large_finish_kernel, dim3(cblocks), dim3(256), 0, st, w, U, info, (int)cfg.profile);
   return ttdg_launch_status("gagm_large_finish");
