@@ -527,26 +527,44 @@ def test_cfg5_own_checkpoint_bf16_backbone_vs_fp32(trained):
     cfg = get_cfg()
     cfg.merge_from_file(os.path.join(ROOT, "configs", "test_segment.yaml"))
     cfg.MODEL.DEVICE, cfg.MODEL.ROI_HEADS.NUM_CLASSES, cfg.INPUT.MIN_SIZE_TEST = "cuda:0", 3, 384
-    path, rep = sc.get_or_make(cfg, dev, log=lambda m: None, kind="polyp", size=384)
     data.register_synthetic("cfg5_own", 48, size=384, cfg_id=5, kind="polyp", num_cls=3)
     BaselineTrainer.rank, BaselineTrainer.world, BaselineTrainer.device = 0, 1, dev
     loader = BaselineTrainer.build_test_loader(cfg, "cfg5_own")
-    out = {}
-    models = {}
-    for name in ("f32", "bf16"):
-        m = BaselineTrainer.build_model(cfg)
-        load_weights(m, path)
-        m.autocast_backbone = name == "bf16"
-        ev = DiceEvaluator("cfg5_own", cfg.TEST.DICE_THRES, dataset_dicts=loader.dataset_dicts)
-        res, _ = inference_on_dataset(m, loader, ev, cfg)
-        out[name] = dict(res, kept=len(ev.dice_scores))
-        models[name] = m
-    rel = {k: abs(out["bf16"][k] - out["f32"][k]) / abs(out["f32"][k]) for k in ("Dice Coefficient", "Enhanced Alignment Metric", "Structural Similarity Metric")}
-    print("cfg-5 own checkpoint: fp32 backbone %s | bf16 backbone %s | relative differences %s" % (out["f32"], out["bf16"], rel))
-    assert out["f32"]["kept"] >= 8 and out["f32"]["Dice Coefficient"] > 50.0, "the polyp checkpoint must segment its own stream"
-    assert abs(out["bf16"]["kept"] - out["f32"]["kept"]) <= max(2, out["f32"]["kept"] // 8)
+    # [r6] The statement is made on the MEDIAN over CFG5_FITS independently fitted checkpoints, at the unchanged CFG5_DICE_TOL.  The
+    # ten-fit study of this round (tools/cfg5_island.py 10, profiles/r06_cfg5_islands.json) shows what one fit is worth: relative Dice
+    # difference of the bf16 backbone 1.9e-3 ... 2.8e-2, median 1.0e-2 (bf16 in res2 ALONE: 1.8e-3 ... 2.5e-2, median 8e-3; the fp32
+    # path under a 1e-7 perturbation: <= 1.7e-6) - kept-mask counts differ on 10 of 10 fits, every difference a 0.9-threshold crossing of
+    # the mask score.  A single fit sits within 8 % of the 3e-2 gate once in ten draws; the median of three is a statistic the gate can
+    # hold (every single fit is still bounded at twice the gate).  north_star's "Dice within 1e-3" is NOT met under a bf16 backbone -
+    # by a factor of ten at the median - and no fp32 island short of the whole backbone changes that.
+    import tempfile
+    keys = ("Dice Coefficient", "Enhanced Alignment Metric", "Structural Similarity Metric")
+    rels, models, out = [], {}, {}
+    for fit in range(CFG5_FITS):
+        with tempfile.TemporaryDirectory() as td:
+            path, rep = sc.get_or_make(cfg, dev, cache_dir=td, log=lambda m: None, kind="polyp", size=384, seed=fit)
+            o = {}
+            for name in ("f32", "bf16"):
+                m = BaselineTrainer.build_model(cfg)
+                load_weights(m, path)
+                m.autocast_backbone = name == "bf16"
+                ev = DiceEvaluator("cfg5_own", cfg.TEST.DICE_THRES, dataset_dicts=loader.dataset_dicts)
+                res, _ = inference_on_dataset(m, loader, ev, cfg)
+                o[name] = dict(res, kept=len(ev.dice_scores))
+                if fit == 0:
+                    models[name] = m
+        rel = {k: abs(o["bf16"][k] - o["f32"][k]) / abs(o["f32"][k]) for k in keys}
+        print("cfg-5 own checkpoint, fit %d: fp32 backbone %s | bf16 backbone %s | relative differences %s" % (fit, o["f32"], o["bf16"], rel))
+        assert o["f32"]["kept"] >= 8 and o["f32"]["Dice Coefficient"] > 50.0, "the polyp checkpoint must segment its own stream"
+        assert abs(o["bf16"]["kept"] - o["f32"]["kept"]) <= max(2, o["f32"]["kept"] // 8)
+        for k, v in rel.items():
+            assert v <= 2.0 * CFG5_DICE_TOL, (fit, k, v)
+        rels.append(rel)
+        if fit == 0:
+            out = o
+    rel = {k: sorted(r[k] for r in rels)[len(rels) // 2] for k in keys}
     for k, v in rel.items():
-        assert v <= CFG5_DICE_TOL, (k, v)
+        assert v <= CFG5_DICE_TOL, (k, v, rels)
     # (2) fp32 matching on the bf16 backbone's node features
     m16 = models["bf16"]
     m16.train()
@@ -582,6 +600,7 @@ def test_cfg5_own_checkpoint_bf16_backbone_vs_fp32(trained):
         json.dump(dict(checkpoint=rep, f32=out["f32"], bf16=out["bf16"], relative_difference=rel, tolerance=CFG5_DICE_TOL), f, indent=1, default=str)
 
 
+CFG5_FITS = 3
 CFG5_DICE_TOL = 3e-2        # every box fits its own polyp checkpoint (the fit is not bit-reproducible), so the figure has a spread.  Twelve fits
                             # over rounds 3 and 4: relative Dice difference of the bf16-backbone run 1.6e-4 ... 1.7e-2 (48 images, 70-80 kept masks).
                             # Round 4 looked for an fp32 island that brings it under 1e-3 (tools/cfg5_island.py, profiles/r04_cfg5_islands*.json,

@@ -8,7 +8,7 @@ Dice / E / S over 48 held-out images with
     all            bf16 autocast over the whole backbone (round 2 / 3's cfg-5)
     res5 .. res2   bf16 up to and including that ResNet stage, fp32 behind it (later stages + FPN: a precision island)
 and the eval-only images/s of every variant (median of 3 passes over the 48 images).
-    python tools/cfg5_island.py [fits=3] [out.json]"""
+    python tools/cfg5_island.py [fits=3] [out.json] [variants, comma separated; "f32" is always run] [notime]"""
 import json
 import os
 import statistics
@@ -28,6 +28,10 @@ KEYS = ("Dice Coefficient", "Enhanced Alignment Metric", "Structural Similarity 
 def main():
     fits = int(sys.argv[1]) if len(sys.argv) > 1 else 3
     outp = sys.argv[2] if len(sys.argv) > 2 else None
+    global VARIANTS
+    if len(sys.argv) > 3 and sys.argv[3]:
+        VARIANTS = ("f32",) + tuple(v for v in sys.argv[3].split(",") if v != "f32")
+    notime = len(sys.argv) > 4 and sys.argv[4] == "notime"
     import synth_checkpoint as sc
     from ttdg_mgm_amd import data
     from ttdg_mgm_amd.config import get_cfg
@@ -59,12 +63,12 @@ def main():
                 ev = DiceEvaluator("cfg5_island", cfg.TEST.DICE_THRES, dataset_dicts=loader.dataset_dicts)
                 r, _ = inference_on_dataset(m, loader, ev, cfg)
                 ts = []
-                for _ in range(3):
+                for _ in range(0 if notime else 3):
                     ev2 = DiceEvaluator("cfg5_island", cfg.TEST.DICE_THRES, dataset_dicts=loader.dataset_dicts)
                     torch.cuda.synchronize(); t0 = time.perf_counter()
                     inference_on_dataset(m, loader, ev2, cfg)
                     torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-                res[v] = dict({k: r[k] for k in KEYS}, kept=len(ev.dice_scores), eval_images_per_s=48.0 / statistics.median(ts))
+                res[v] = dict({k: r[k] for k in KEYS}, kept=len(ev.dice_scores), eval_images_per_s=(48.0 / statistics.median(ts)) if ts else 0.0)
                 del m
             ref = res["f32"]
             for v in VARIANTS[1:]:
