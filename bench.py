@@ -315,6 +315,7 @@ def kernel_rooflines(run):
              "sampling": ("HIP-event pair around every %d-th launch (ops.KERNEL_TIMER_EVERY); launches / total_ms are the timed ones x %d" % (every(nm), every(nm))) if every(nm) > 1 else "every launch timed",
              "algorithmic_work_per_launch": e["work"] / e["n"]}
         if "bytes" in e:
+            r["algorithmic_bytes_per_launch"] = e["bytes"] / e["n"]       # what `traffic` (PMC) compares with
             r["algorithmic_hbm_gbs"] = e["bytes"] / e["t"] / 1e9          # the same launches against the other roofline (HBM 8 TB/s)
             r["frac_hbm"] = r["algorithmic_hbm_gbs"] / HBM_PEAK_GBS
         if nm == "gagm":
@@ -348,7 +349,7 @@ def pmc_traffic(stamp_name):
         except (OSError, ValueError):
             continue
         if rec:
-            if stamp_name in ("bias_act", "relu_bwd", "roi_align_nhwc") and "hbm_bytes_per_launch_mean_streaming_corrected" in rec:
+            if stamp_name in ("bias_act", "relu_bwd", "roi_align_nhwc", "pointwise_fwd", "pointwise_dx", "pointwise_dw") and "hbm_bytes_per_launch_mean_streaming_corrected" in rec:
                 return rec["hbm_bytes_per_launch_mean_streaming_corrected"]        # many launch sizes: mean, like `achieved`
             return rec["hbm_bytes_per_launch_streaming_corrected" if streaming else "hbm_bytes_per_launch_raw"]
     return None

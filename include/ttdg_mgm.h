@@ -17,7 +17,11 @@
  *    ttdg_debug_set_lap_variant (which of two arg-min lowerings ttdg_lap_batched
  *    uses) and ttdg_debug_set_roi_align_sliced (which of the ROIPooler kernels
  *    serves a call).  Every other A/B choice travels per call
- *    (ttdg_gagm_cfg_t.variant);
+ *    (ttdg_gagm_cfg_t.variant).  A third, on the product path and per HOST THREAD:
+ *    ttdg_gagm_solve's multi-workgroup solver keeps a 64-byte page-locked buffer
+ *    (its convergence flag, written by the device, read by the host without a copy)
+ *    and the iteration count of the thread's previous solve (sizes the first chunk
+ *    of enqueued iterations); no kernel reads either, results do not depend on them;
  *  - all work is enqueued on `stream` (a hipStream_t); no implicit device sync;
  *  - return value 0 = ok, otherwise a negative TTDG_E* code or a positive
  *    hipError_t; ttdg_last_error() describes the last failure on this thread.
@@ -382,6 +386,14 @@ typedef struct {
   int32_t relu, prelu;
   int32_t kslices;
   int32_t tile;
+  /* optional second reduction segment (A2 != NULL): + sum_{k < K2} A2(m, k) B2(n, k), both k-contiguous, A2 with its own strided
+   * row map (a2_stride / a2_h / a2_w as a_stride / a_h / a_w) - the projection shortcut of a bottleneck's first block accumulated
+   * into conv3's product: bias = conv3's shift, bias2 = the shortcut's, no residual.  K and K2 multiples of 32; 64 x 64 tiles. */
+  const float* A2;
+  const float* B2;
+  int64_t lda2, ldb2;
+  int32_t K2;
+  int32_t a2_stride, a2_h, a2_w;
 } ttdg_mm_t;
 size_t ttdg_mm_workspace_bytes(int M, int N, int kslices);
 int ttdg_mm_f32(const ttdg_mm_t* desc, ttdg_stream_t stream);

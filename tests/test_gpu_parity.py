@@ -2051,6 +2051,21 @@ def test_pointwise_product_backward_layouts_row_maps_and_split(dev):
             got = ops.pointwise_conv(xs, w, b, residual=coarse, res_up=True)
             want = torch.nn.functional.conv2d(xs.double(), w.double(), b.double()) + torch.nn.functional.interpolate(coarse.double(), scale_factor=2.0, mode="nearest")
             assert maxerr(got, want) <= 1e-5 * float(want.abs().max())
+    # second reduction segment: conv3(relu(y + b2)) + shortcut(x[::s, ::s]) in one product (a bottleneck's first block)
+    for (B, Cmid, Cin2, Cout, H, W, s) in ((2, 64, 64, 256, 12, 20, 1), (1, 128, 256, 512, 14, 18, 2), (2, 512, 1024, 2048, 6, 10, 2)):
+        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        y = synth.normal(g, (B, Cmid, Ho, Wo), 1.0).to(dev).contiguous(memory_format=CL)
+        x2 = synth.normal(g, (B, Cin2, H, W), 1.0).to(dev).contiguous(memory_format=CL)
+        w3, ws = synth.normal(g, (Cout, Cmid, 1, 1), 0.1).to(dev), synth.normal(g, (Cout, Cin2, 1, 1), 0.1).to(dev)
+        b3, bs, b2 = synth.normal(g, (Cout,), 1.0).to(dev), synth.normal(g, (Cout,), 1.0).to(dev), synth.normal(g, (Cmid,), 1.0).to(dev)
+        got = ops.pointwise_conv(y, w3, b3, bias2=bs, relu=True, pbias=b2, prelu=True, second=(x2, ws, s))
+        f64 = torch.nn.functional.conv2d
+        want = (f64((y.double() + b2.double().view(1, -1, 1, 1)).relu(), w3.double(), b3.double()) + f64(x2.double(), ws.double(), bs.double(), s)).relu()
+        assert got.shape == want.shape and maxerr(got, want) <= 2e-6 * float(want.abs().max()) * max(1.0, (Cmid + Cin2) ** 0.5 / 8), (B, Cmid, Cin2, Cout, s)
+        two = ops.pointwise_conv(ops.bias_act_(y.clone(), b2), w3, b3, residual=ops.pointwise_conv(x2, ws, bs, stride=s), relu=True)
+        assert maxerr(got, two) <= 1e-5 * float(want.abs().max())
+    with pytest.raises(ValueError):
+        ops.pointwise_conv(y, w3, b3, residual=y, second=(x2, ws, s))               # a second segment takes no residual
     with pytest.raises(TypeError):
         ops.pointwise_conv(x.contiguous(), w)                                     # NCHW activation
     with pytest.raises(ValueError):
@@ -2124,11 +2139,17 @@ def test_own_pointwise_backbone_vs_vendor_backbone_and_float64(dev):
     g64 = {n: p.grad for n, p in net64.named_parameters() if p.grad is not None}
     from ttdg_mgm_amd import ops
     res = {}
-    keep, keep_b, keep_p, keep_a = bb.OWN_POINTWISE, ops.POINTWISE_BACKWARD, bb.POINTWISE_MIN_PIXELS, bb.FUSED_INPUT_ACTIVATION
+    keep, keep_b, keep_p, keep_a, keep_s = bb.OWN_POINTWISE, ops.POINTWISE_BACKWARD, bb.POINTWISE_MIN_PIXELS, bb.FUSED_INPUT_ACTIVATION, bb.FUSED_SHORTCUT
+    # MIOpen restricted to its deterministic solvers for all three arms: with the default choice its backward kernels for these small
+    # maps differ from run to run by 1e-3 ... 1e-2 relative in single filter gradients (recorded in round 5: profiles/r05_graph_probe.txt,
+    # "default" 2.7e-3 ... 2.2e-2 against 2.4e-6 "deterministic"; seen again here with every hand-written kernel switched off:
+    # res3.0.conv1.weight 1.7e-3 from float64 in 4 of 6 identical runs) - a vendor property that would otherwise decide this comparison
+    keep_det = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
     for own in (True, "own-backward", False):
         bb.OWN_POINTWISE = bool(own)
         bb.POINTWISE_MIN_PIXELS = 0                  # every stage of this small input on the streaming product (the bench routes res5's 2500 pixels to the vendor)
-        bb.FUSED_INPUT_ACTIVATION = own is True      # the second arm applies conv2's epilogue with the in-place kernel
+        bb.FUSED_INPUT_ACTIVATION = bb.FUSED_SHORTCUT = own is True      # the second arm applies conv2's epilogue with the in-place kernel and runs the shortcut as its own product
         ops.POINTWISE_BACKWARD = "own" if own == "own-backward" else "vendor"
         try:
             nd = copy.deepcopy(net).to(dev)
@@ -2139,7 +2160,9 @@ def test_own_pointwise_backbone_vs_vendor_backbone_and_float64(dev):
                 quiet = nd(x0.to(dev))
             res[own] = ({k: v.detach().cpu() for k, v in outs.items()}, grads, {k: v.cpu() for k, v in quiet.items()})
         finally:
-            bb.OWN_POINTWISE, ops.POINTWISE_BACKWARD, bb.POINTWISE_MIN_PIXELS, bb.FUSED_INPUT_ACTIVATION = keep, keep_b, keep_p, keep_a
+            bb.OWN_POINTWISE, ops.POINTWISE_BACKWARD, bb.POINTWISE_MIN_PIXELS, bb.FUSED_INPUT_ACTIVATION, bb.FUSED_SHORTCUT = keep, keep_b, keep_p, keep_a, keep_s
+            if own is False:
+                torch.backends.cudnn.deterministic = keep_det
     assert set(res[True][1]) == set(res["own-backward"][1]) == set(res[False][1]) == set(g64) and len(g64) > 50
     for arm in (True, "own-backward"):
         worst = {"out": (0.0, 0.0), "grad": (0.0, 0.0)}

@@ -9,9 +9,9 @@ R=${1:-r03}
 export TMPDIR=/tmp
 OUT=gpurun_out/$R
 mkdir -p $OUT
-timeout -k 10 600 python bench.py --steps 16 --warmup 2 --no-ab --no-cpu-baseline > $OUT/bench_noab.json 2> $OUT/bench_noab.err   # also fills the checkpoint cache
+timeout -k 10 600 python bench.py --steps 16 --warmup 2 --no-ab --no-cpu-baseline --no-cfg3 > $OUT/bench_noab.json 2> $OUT/bench_noab.err   # also fills the checkpoint cache
 echo "plain bench rc=$?"
-CMD="python bench.py --steps 4 --warmup 2 --no-ab --no-cpu-baseline"
+CMD="python bench.py --steps 4 --warmup 2 --no-ab --no-cpu-baseline --no-cfg3"
 timeout -k 10 420 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- $CMD > $OUT/bench_under_rocprof.json 2> $OUT/prof.log
 echo "stats pass rc=$?"
 OURS="gagm_|affinity_|sinkhorn_|pair_stage|sgd_multi|mask_pair|perm_loss|node_|roi_align|paste_masks|mha_adj|gemm_f32|gemm_grouped|bias_act|relu_bwd|resize_|row_scale|rpn_select|mask_measures|mm_kernel|mm_reduce"

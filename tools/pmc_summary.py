@@ -5,7 +5,7 @@ import csv, json, statistics, sys
 OURS = ("gagm_kernel", "sgd_multi_tensor", "affinity_fwd", "affinity_bwd_kernel", "sinkhorn_pairs_fwd", "sinkhorn_pairs_bwd",
         "perm_loss_pair", "node_gather", "node_labels", "roi_align_fwd", "gagm_large_mul", "gagm_large_project", "mask_pair_counts",
         "roi_align_ml", "roi_align_nhwc", "roi_align_sep", "nchw_to_nhwc", "paste_masks", "bias_act", "relu_bwd", "mha_adjacency", "gemm_f32",
-        "pair_stage_fwd", "pair_stage_bwd", "gemm_grouped", "resize_", "row_scale_multi", "rpn_select", "mask_measures")
+        "pair_stage_fwd", "pair_stage_bwd", "gemm_grouped", "resize_", "row_scale_multi", "rpn_select", "mask_measures", "mm_kernel", "mm_reduce")
 
 
 def collect(path, counter):

@@ -75,7 +75,9 @@ class Mm(C.Structure):
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("a_layout", C.c_int32), ("b_layout", C.c_int32),
                 ("a_stride", C.c_int32), ("a_h", C.c_int32), ("a_w", C.c_int32),
                 ("res_up", C.c_int32), ("res_h", C.c_int32), ("res_w", C.c_int32),
-                ("relu", C.c_int32), ("prelu", C.c_int32), ("kslices", C.c_int32), ("tile", C.c_int32)]
+                ("relu", C.c_int32), ("prelu", C.c_int32), ("kslices", C.c_int32), ("tile", C.c_int32),
+                ("A2", C.c_void_p), ("B2", C.c_void_p), ("lda2", C.c_int64), ("ldb2", C.c_int64), ("K2", C.c_int32),
+                ("a2_stride", C.c_int32), ("a2_h", C.c_int32), ("a2_w", C.c_int32)]
 
 
 GEMM_GROUP_MAX = 8

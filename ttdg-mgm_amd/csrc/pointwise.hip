@@ -50,6 +50,13 @@ struct mm_args {
   int relu, prelu;
   int kslices, kc;                           // split of the reduction over blockIdx.y (kc: multiple of MM_BK); partial planes in `part`
   float* part;
+  // second reduction segment (SEG2 kernels): + sum_k A2(m, k) B2(n, k), both k-contiguous, A2 with its own strided row map - the
+  // projection shortcut of a bottleneck's first block accumulated into conv3's product (its output is never written or re-read)
+  const float* A2;
+  const float* B2;
+  int64_t lda2, ldb2;
+  int K2;
+  int a2_map, a2_howo, a2_wo, a2_hw, a2_w, a2_s;
 };
 
 __device__ __forceinline__ void mm_glds16(const float* g, float* lds_wave_base) {
@@ -64,7 +71,7 @@ struct mm_loader {
   int krow[IPW];                                     // !KC: k row inside the slab
   int kchunk;                                        // KC: source chunk (0..7) of this lane
   int64_t ld;
-  __device__ __forceinline__ void init(const float* X, int64_t ld_, int r0, int Rlim, int wave, int lane, const mm_args& a, bool is_a) {
+  __device__ __forceinline__ void init(const float* X, int64_t ld_, int r0, int Rlim, int wave, int lane, int map, int howo, int wo, int hw, int w_, int st) {
     ld = ld_;
     if (KC) {
       const int sw = (wave * 4 + (lane >> 4)) & 7;
@@ -74,9 +81,9 @@ struct mm_loader {
         int r = r0 + (q * 4 + wave) * 8 + (lane >> 3);
         r = r < Rlim ? r : Rlim - 1;                 // beyond the edge: a valid row whose results are never stored
         int64_t row = r;
-        if (is_a && a.a_map) {
-          const int img = r / a.a_howo, rem = r - img * a.a_howo, ho = rem / a.a_wo, wo = rem - ho * a.a_wo;
-          row = (int64_t)img * a.a_hw + (int64_t)(ho * a.a_s) * a.a_w + wo * a.a_s;
+        if (map) {
+          const int img = r / howo, rem = r - img * howo, ho = rem / wo, wq = rem - ho * wo;
+          row = (int64_t)img * hw + (int64_t)(ho * st) * w_ + wq * st;
         }
         p[q] = X + row * ld;
       }
@@ -171,7 +178,7 @@ __device__ __forceinline__ void mm_slab(const float* As, const float* Bs, const 
   }
 }
 
-template <int BM, int BN, bool AKC, bool BKC, bool PRO, bool LONGK>
+template <int BM, int BN, bool AKC, bool BKC, bool PRO, bool LONGK, bool SEG2>
 __global__ __launch_bounds__(256, 2) void mm_kernel(const mm_args p) {
   constexpr int WM = BM / 2, WN = BN / 2, MB = WM / 32, NB = WN / 32;
   constexpr int ASZ = BM * MM_BK, BSZ = BN * MM_BK, STAGE = ASZ + BSZ;
@@ -198,12 +205,19 @@ __global__ __launch_bounds__(256, 2) void mm_kernel(const mm_args p) {
 
   const int kbeg = p.part ? blockIdx.y * p.kc : 0;
   const int kend = p.part ? min(p.K, kbeg + p.kc) : p.K;
-  const int nk = (kend - kbeg + MM_BK - 1) / MM_BK;
+  const int nk1 = (kend - kbeg + MM_BK - 1) / MM_BK;
+  const int nk = nk1 + (SEG2 ? p.K2 / MM_BK : 0);          // (SEG2: K and K2 are multiples of the slab depth, no split)
 
   mm_loader<BM, AKC> la;
   mm_loader<BN, BKC> lb;
-  la.init(p.A, p.lda, m0, p.M, wave, lane, p, true);
-  lb.init(p.B, p.ldb, n0, p.N, wave, lane, p, false);
+  la.init(p.A, p.lda, m0, p.M, wave, lane, p.a_map, p.a_howo, p.a_wo, p.a_hw, p.a_w, p.a_s);
+  lb.init(p.B, p.ldb, n0, p.N, wave, lane, 0, 1, 1, 0, 0, 1);
+  mm_loader<BM, true> la2;
+  mm_loader<BN, true> lb2;
+  if (SEG2) {
+    la2.init(p.A2, p.lda2, m0, p.M, wave, lane, p.a2_map, p.a2_howo, p.a2_wo, p.a2_hw, p.a2_w, p.a2_s);
+    lb2.init(p.B2, p.ldb2, n0, p.N, wave, lane, 0, 1, 1, 0, 0, 1);
+  }
 
   f32x16 acc[MB][NB];
 #pragma unroll
@@ -248,11 +262,17 @@ __global__ __launch_bounds__(256, 2) void mm_kernel(const mm_args p) {
     const int k0 = kbeg + t * MM_BK;
     if (t + 1 < nk) {
       float* nxt = smem + ((t + 1) & 1) * STAGE;
-      la.issue(nxt, k0 + MM_BK, kend, wave);
-      lb.issue(nxt + ASZ, k0 + MM_BK, kend, wave);
+      if (!SEG2 || t + 1 < nk1) {
+        la.issue(nxt, k0 + MM_BK, kend, wave);
+        lb.issue(nxt + ASZ, k0 + MM_BK, kend, wave);
+      } else {
+        la2.issue(nxt, (t + 1 - nk1) * MM_BK, p.K2, wave);
+        lb2.issue(nxt + ASZ, (t + 1 - nk1) * MM_BK, p.K2, wave);
+      }
     }
     // ragged end of the reduction (only the last slab can be ragged): the filler is zeroed in registers
-    if (kend - k0 < MM_BK) mm_slab<BM, BN, AKC, BKC, PRO, true>(As, Bs, fa, fb, sw, h, k0, kend, p, pb_lds, acc);
+    if (SEG2 && t >= nk1) mm_slab<BM, BN, true, true, false, false>(As, Bs, fa, fb, sw, h, 0, MM_BK, p, pb_lds, acc);   // (no input activation on the second segment)
+    else if (!SEG2 && kend - k0 < MM_BK) mm_slab<BM, BN, AKC, BKC, PRO, true>(As, Bs, fa, fb, sw, h, k0, kend, p, pb_lds, acc);
     else mm_slab<BM, BN, AKC, BKC, PRO, false>(As, Bs, fa, fb, sw, h, k0, kend, p, pb_lds, acc);
     if (LONGK && (t & 7) == 7) {
       // long reductions: every 256 k the running sums move to a second set of registers and the chains restart, so a chain is
@@ -342,12 +362,20 @@ static int mm_launch(int tile, const mm_args& a, dim3 grid_y, hipStream_t st) {
   const int tiles = ((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn);
   dim3 grid(tiles, grid_y.y);
   switch (tile) {
-    case 0: hipLaunchKernelGGL((mm_kernel<128, 128, AKC, BKC, PRO, LONGK>), grid, dim3(256), 0, st, a); break;
-    case 1: hipLaunchKernelGGL((mm_kernel<128, 64, AKC, BKC, PRO, LONGK>), grid, dim3(256), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((mm_kernel<64, 128, AKC, BKC, PRO, LONGK>), grid, dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((mm_kernel<64, 64, AKC, BKC, PRO, LONGK>), grid, dim3(256), 0, st, a); break;
+    case 0: hipLaunchKernelGGL((mm_kernel<128, 128, AKC, BKC, PRO, LONGK, false>), grid, dim3(256), 0, st, a); break;
+    case 1: hipLaunchKernelGGL((mm_kernel<128, 64, AKC, BKC, PRO, LONGK, false>), grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((mm_kernel<64, 128, AKC, BKC, PRO, LONGK, false>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((mm_kernel<64, 64, AKC, BKC, PRO, LONGK, false>), grid, dim3(256), 0, st, a); break;
   }
   return ttdg_launch_status("mm_f32");
+}
+
+// two reduction segments: 64 x 64 tiles, k-contiguous operands
+template <bool PRO, bool LONGK>
+static int mm_launch_seg2(const mm_args& a, hipStream_t st) {
+  const int tiles = ((a.M + 63) / 64) * ((a.N + 63) / 64);
+  hipLaunchKernelGGL((mm_kernel<64, 64, true, true, PRO, LONGK, true>), dim3(tiles), dim3(256), 0, st, a);
+  return ttdg_launch_status("mm_f32 (two segments)");
 }
 
 // tile code: bit 1 = BM 64 (else 128), bit 0 = BN 64 (else 128).  Measured on every pointwise layer of the bench shape, forward and
@@ -395,6 +423,23 @@ extern "C" int ttdg_mm_f32(const ttdg_mm_t* d, ttdg_stream_t stream) {
   a.r_w = d->res_w, a.r_hw = d->res_h * d->res_w;
   if (a.r_up) TTDG_REQUIRE(d->res && d->res_h > 0 && d->res_w > 0 && !(d->res_h & 1) && !(d->res_w & 1) && d->M % a.r_hw == 0, "mm: up-sampled residual needs an even (H, W) map");
   a.relu = d->relu, a.prelu = d->prelu;
+  a.A2 = d->A2, a.B2 = d->B2, a.lda2 = d->lda2, a.ldb2 = d->ldb2, a.K2 = d->A2 ? d->K2 : 0;
+  a.a2_map = d->a2_stride > 1;
+  a.a2_s = d->a2_stride > 1 ? d->a2_stride : 1;
+  a.a2_w = d->a2_w, a.a2_hw = d->a2_h * d->a2_w;
+  a.a2_wo = a.a2_howo = 1;
+  if (a.K2 > 0) {
+    TTDG_REQUIRE(d->B2 && d->a_layout == 0 && d->b_layout == 0 && d->kslices <= 1, "mm: the second segment needs k-contiguous operands and no split");
+    TTDG_REQUIRE((d->K % MM_BK) == 0 && (d->K2 % MM_BK) == 0, "mm: with a second segment both reductions must be multiples of 32");
+    TTDG_REQUIRE(((uintptr_t)d->A2 & 15) == 0 && ((uintptr_t)d->B2 & 15) == 0 && (d->lda2 & 3) == 0 && (d->ldb2 & 3) == 0, "mm: second-segment operand alignment");
+    TTDG_REQUIRE(d->tile == 0 || d->tile == 4, "mm: the second segment is built for 64 x 64 tiles");
+    if (a.a2_map) {
+      TTDG_REQUIRE(d->a2_h > 0 && d->a2_w > 0, "mm: strided second-segment row map without an input size");
+      const int ho = (d->a2_h - 1) / a.a2_s + 1, wo = (d->a2_w - 1) / a.a2_s + 1;
+      TTDG_REQUIRE(d->M % (ho * wo) == 0, "mm: M is not a whole number of strided maps (second segment)");
+      a.a2_wo = wo, a.a2_howo = ho * wo;
+    }
+  }
   const int ks = d->kslices > 1 ? d->kslices : 0;
   a.kslices = ks;
   a.kc = ks ? (((d->K + ks - 1) / ks) + MM_BK - 1) / MM_BK * MM_BK : 0;
@@ -404,7 +449,11 @@ extern "C" int ttdg_mm_f32(const ttdg_mm_t* d, ttdg_stream_t stream) {
   TTDG_REQUIRE(tile >= 0 && tile < 4, "mm: tile code");
   dim3 gy(1, ks ? ks : 1);
   int rc;
-  const bool longk = (ks ? a.kc : d->K) >= 1024;                  // (per workgroup: a split reduction restarts its chains per slice anyway)
+  const bool longk = (ks ? a.kc : d->K + a.K2) >= 1024;           // (per workgroup: a split reduction restarts its chains per slice anyway)
+  if (a.K2 > 0) {
+    if (d->pbias) return longk ? mm_launch_seg2<true, true>(a, st) : mm_launch_seg2<true, false>(a, st);
+    return longk ? mm_launch_seg2<false, true>(a, st) : mm_launch_seg2<false, false>(a, st);
+  }
 #define MM_GO(AKC, BKC, PRO) (longk ? mm_launch<AKC, BKC, PRO, true>(tile, a, gy, st) : mm_launch<AKC, BKC, PRO, false>(tile, a, gy, st))
   if (d->a_layout == 0 && d->b_layout == 0) rc = d->pbias ? MM_GO(true, true, true) : MM_GO(true, true, false);
   else if (d->a_layout == 0) rc = MM_GO(true, false, false);

@@ -33,6 +33,8 @@ OWN_POINTWISE = True
 # ... and in the blocks without a tape the 3 x 3 convolution's own epilogue (shift + ReLU) is applied by the NEXT product while it
 # fetches its operand (ops.pointwise_conv(pbias=, prelu=)), instead of an in-place pass over the 3 x 3 output
 FUSED_INPUT_ACTIVATION = True
+# ... and the projection shortcut of a stage's first block is accumulated into conv3's product as a second reduction segment
+FUSED_SHORTCUT = True
 # stages whose pointwise convolutions stay on the vendor kernels: at 25 x 25 x 4 = 2500 pixels the streaming product's 64 x 64 tiles
 # leave CUs idle (in-situ A/B per block, profiles/r06_pointwise_ab_in_situ.txt: res2 - res4 x1.04 - 1.18, res5 x0.91 - 0.96)
 POINTWISE_MIN_PIXELS = 4096
@@ -212,6 +214,9 @@ class Bottleneck(nn.Module):
             w3, b3 = self.conv3.folded_const()
             if self.shortcut is not None:
                 ws, bs = self.shortcut.folded_const()
+                if FUSED_SHORTCUT and FUSED_INPUT_ACTIVATION and x.shape[1] % 32 == 0 and y.shape[1] % 32 == 0:
+                    # the projection shortcut is a second reduction segment of conv3's product: its output is never written or re-read
+                    return ops.pointwise_conv(y, w3, b3, bias2=bs, relu=True, pbias=b2, prelu=True, second=(x, ws, self.shortcut.stride[0]))
                 sc = ops.pointwise_conv(x, ws, bs, relu=False, stride=self.shortcut.stride[0])
             else:
                 sc = x

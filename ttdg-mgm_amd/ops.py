@@ -117,7 +117,7 @@ def linear_raw(x, W, b=None, w_col_off=0, w_ld=None, out=None):
 
 
 def mm(A, B, out, M, N, K, lda, ldb, ldc, bias=None, res=None, ldres=0, bias2=None, pbias=None, relu=False, prelu=False,
-       a_layout=0, b_layout=0, a_stride=0, a_hw=(0, 0), res_up=False, res_hw=(0, 0), kslices=0, tile=0):
+       a_layout=0, b_layout=0, a_stride=0, a_hw=(0, 0), res_up=False, res_hw=(0, 0), kslices=0, tile=0, second=None):
     """ttdg_mm_f32 (csrc/pointwise.hip): out[m, n] = act(sum_k A'(m, k) B(n, k) + bias[n] + (res[r(m), n] + bias2[n])).  Tensors are
     passed as storage (pointer + leading dimensions); see include/ttdg_mgm.h for the row maps and layouts."""
     ws = torch.empty(kslices * M * N, device=out.device, dtype=torch.float32) if kslices > 1 else None
@@ -125,6 +125,9 @@ def mm(A, B, out, M, N, K, lda, ldb, ldc, bias=None, res=None, ldres=0, bias2=No
     d = _lib.Mm(ptr(A), ptr(B), ptr(out), ptr(bias), ptr(res), ptr(bias2), ptr(pbias), ptr(ws), int(lda), int(ldb), int(ldc), int(ldres),
                 int(M), int(N), int(K), int(a_layout), int(b_layout), int(a_stride), int(a_hw[0]), int(a_hw[1]),
                 int(bool(res_up)), int(res_hw[0]), int(res_hw[1]), int(bool(relu)), int(bool(prelu)), int(kslices), int(tile))
+    if second is not None:          # (A2, B2, lda2, ldb2, K2, stride, (H, W)): a second reduction segment into the same accumulators
+        A2, B2, lda2, ldb2, K2, st2, hw2 = second
+        d.A2, d.B2, d.lda2, d.ldb2, d.K2, d.a2_stride, d.a2_h, d.a2_w = ptr(A2), ptr(B2), int(lda2), int(ldb2), int(K2), int(st2), int(hw2[0]), int(hw2[1])
     call("ttdg_mm_f32", C.byref(d), stream())
     return out
 
@@ -825,11 +828,12 @@ def _cl_empty(B, Cc, H, W, device):
     return torch.empty(B, H, W, Cc, device=device, dtype=torch.float32).permute(0, 3, 1, 2)
 
 
-def pointwise_conv(x, w, bias=None, residual=None, bias2=None, relu=False, stride=1, res_up=False, pbias=None, prelu=False):
+def pointwise_conv(x, w, bias=None, residual=None, bias2=None, relu=False, stride=1, res_up=False, pbias=None, prelu=False, second=None):
     """1 x 1 convolution of a channels-last activation as ONE fused product: act(conv(x', w) + bias + (residual + bias2)) with
     x' = x or relu(x + pbias[c]) (the previous layer's shift + ReLU applied on the fly).  ``stride``: every stride-th pixel of every
     stride-th row (no padding); ``res_up``: the residual is the half-size map, nearest-neighbour up-sampled (FPN top-down sum).
-    No autograd: where gradients flow use PointwiseConvFn."""
+    ``second`` = (x2, w2, stride2): + conv(x2, w2) with its own stride accumulated in the same product (the projection shortcut of a
+    bottleneck's first block next to conv3; bias2 = its shift; no residual then).  No autograd: where gradients flow use PointwiseConvFn."""
     B, Cin, H, W = x.shape
     Cout = w.shape[0]
     if not pointwise_ok(x, w):
@@ -847,9 +851,21 @@ def pointwise_conv(x, w, bias=None, residual=None, bias2=None, relu=False, strid
             raise TypeError("pointwise_conv: contiguous float32 shift vectors only")
     M = B * Ho * Wo
     nbytes = 4 * (M * Cin + M * Cout * (2 if residual is not None and not res_up else 1) + Cin * Cout)
-    with _timed("pointwise_fwd", (nbytes, 2 * M * Cin * Cout)):
+    flops = 2 * M * Cin * Cout
+    seg = None
+    if second is not None:
+        x2, w2, st2 = second
+        if residual is not None or not pointwise_ok(x2, w2) or w2.shape[0] != Cout or stride != 1 or Cin % 32 or x2.shape[1] % 32:
+            raise ValueError("pointwise_conv: the second segment needs no residual, channel counts that are multiples of 32 and a stride-1 first segment")
+        B2, C2, H2, W2 = x2.shape
+        if B2 != B or (H2 - 1) // st2 + 1 != Ho or (W2 - 1) // st2 + 1 != Wo:
+            raise ValueError("pointwise_conv: the second segment's strided map %s does not match the output %s" % (tuple(x2.shape), (B, Cout, Ho, Wo)))
+        seg = (x2, w2, C2, C2, C2, st2 if st2 > 1 else 0, (H2, W2))
+        nbytes += 4 * (M * C2 + C2 * Cout)
+        flops += 2 * M * C2 * Cout
+    with _timed("pointwise_fwd", (nbytes, flops)):
         mm(x, w, out, M, Cout, Cin, Cin, Cin, Cout, bias=bias, res=residual, ldres=Cout, bias2=bias2, pbias=pbias, relu=relu, prelu=prelu,
-           a_stride=stride if stride > 1 else 0, a_hw=(H, W), res_up=res_up, res_hw=(Ho, Wo))
+           a_stride=stride if stride > 1 else 0, a_hw=(H, W), res_up=res_up, res_hw=(Ho, Wo), second=seg)
     return out
 
 
