@@ -951,6 +951,40 @@ def test_cfg3_planted_end_to_end_golden(dev, golden, name):
     LEDGER["cfg3_planted_e2e.identical_permutations_asserted"] += 1
 
 
+def test_large_graph_linear_products_on_both_engines(dev, golden):
+    """ops.LARGE_GEMM_ENGINE: the seventeen nn.Linear-shaped products of a matching step beyond 512 stacked nodes run on the streaming
+    product of csrc/pointwise.hip ("mm": 64 x 64 tiles, fixed but not ascending k order, weight gradients over 8 row slices) or on
+    gemm_f32 ("gemm": ascending k).  Same teacher-forced cfg-3 case through both: Wds, U0, loss, every node and parameter gradient
+    agree to fp32 rounding of 256- / 512- / 2048-term sums, and both meet the reference golden at the suite's tolerance."""
+    from ttdg_mgm_amd import ops
+    name = cases.PLANTED_CFG3_CASES[0][0]
+    gold = golden("mgm3_cfg3")
+    forced = torch.from_numpy(cases.columns_to_perm(gold[f"{name}_U"])).to(dev) if hasattr(cases, "columns_to_perm") else None
+    res = {}
+    keep = ops.LARGE_GEMM_ENGINE
+    for eng in ("mm", "gemm"):
+        ops.LARGE_GEMM_ENGINE = eng
+        try:
+            m, dn, loss, tr = _run_mgm3(dev, name, forced=forced)
+        finally:
+            ops.LARGE_GEMM_ENGINE = keep
+        res[eng] = (tr["Wds"].detach().clone(), tr["U0"].detach().clone(), float(loss.detach()), [x.grad.clone() for x in dn],
+                    {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+        assert abs(res[eng][2] - float(gold[f"{name}_loss"])) <= TOL
+    a, b = res["mm"], res["gemm"]
+    assert maxerr(a[0], b[0]) <= 1e-5 and maxerr(a[1], b[1]) <= 1e-5 * max(1.0, float(b[1].abs().max())) and abs(a[2] - b[2]) <= 1e-6
+    # gradients: the two engines' 1e-6 differences in P / Q pass through the Sinkhorn backward at tau = 0.05 and the relu masks of the
+    # affinity backward (measured between the engines: 2e-4 of the largest entry at 8 x 256); both meet the golden at TOL above / below
+    for x, y in zip(a[3], b[3]):
+        assert maxerr(x, y) <= 2e-3 * max(1e-30, float(y.abs().max()))
+    assert set(a[4]) == set(b[4])
+    for k in a[4]:
+        assert maxerr(a[4][k], b[4][k]) <= 2e-3 * max(1e-30, float(b[4][k].abs().max())), k
+    for eng in ("mm", "gemm"):
+        for gi, x in enumerate(res[eng][3]):
+            check_pgrad(gold, f"{name}_dnode{gi}", x, TOL)
+
+
 @pytest.mark.parametrize("name", [c[0] for c in cases.MGM_CASES])
 def test_mgm3_end_to_end_random_teacher_forced(dev, golden, name):
     """Random-weight cases: the reference's own permutations are rounding noise there (it returns different ones

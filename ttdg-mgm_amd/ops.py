@@ -132,6 +132,45 @@ def mm(A, B, out, M, N, K, lda, ldb, ldc, bias=None, res=None, ldres=0, bias2=No
     return out
 
 
+# The nn.Linear-shaped products of a matching step with more than GROUPED_GEMM_MAX_ROWS stacked nodes (cfg-3: 2048) on the streaming
+# product of csrc/pointwise.hip (64 x 64 tiles, five workgroups per CU, LDS-DMA: 8.6 - 9.2 us per 2048-row projection against 10.2 -
+# 11.6 us for gemm_f32's one workgroup per CU; weight gradients over 8 row slices 15.0 against 16.4 us) - "gemm" = the round-4 kernel
+# (ascending-k accumulation; the parity tests compare the two).
+LARGE_GEMM_ENGINE = "mm"
+
+
+def _big_linear(x, W, b=None, col_off=0, ld=None):
+    """y = x @ W[:, off:off + K]^T + b for a tall x (the large-graph path of MatchingLossFn)."""
+    if LARGE_GEMM_ENGINE != "mm":
+        return linear_raw(x, W, b, col_off, ld)
+    M, K = x.shape
+    N = W.shape[0]
+    y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    Wv = W if col_off == 0 else W[:, col_off:]
+    return mm(x, Wv, y, M, N, K, K, W.shape[1] if ld is None else ld, N, bias=b)
+
+
+def _big_dx(dy, W, K, col_off=0, out=None, accumulate=False):
+    """dx (M, K) = dy (M, N) @ W[:, off:off + K] (W row-major (N, ldw)); ``accumulate``: += into ``out``."""
+    M, N = dy.shape
+    dx = out if out is not None else torch.empty(M, K, device=dy.device, dtype=torch.float32)
+    if LARGE_GEMM_ENGINE != "mm":
+        return gemm(dy, N, 1, W, 1, W.shape[1], dx, K, 1, M, K, N, b_off=col_off, beta=1.0 if accumulate else 0.0)
+    Wv = W if col_off == 0 else W[:, col_off:]
+    return mm(dy, Wv, dx, M, K, N, N, W.shape[1], K, b_layout=1, res=dx if accumulate else None, ldres=K)
+
+
+def _big_dw(dy, x, out, col_off=0):
+    """out[:, off:off + K] (N, ldo) = dy (M, N)^T @ x (M, K): the reduction over the M stacked nodes split over 8 workgroup planes,
+    added in a fixed order."""
+    M, N = dy.shape
+    K = x.shape[1]
+    if LARGE_GEMM_ENGINE != "mm":
+        return gemm(dy, 1, N, x, 1, K, out, out.shape[1], 1, N, K, M, c_off=col_off)
+    ov = out if col_off == 0 else out[:, col_off:]
+    return mm(dy, x, ov, N, K, M, N, K, out.shape[1], a_layout=1, b_layout=1, kslices=max(0, min(8, M // 256)))
+
+
 def colsum(X):
     out = torch.empty(X.shape[1], device=X.device, dtype=torch.float32)
     call("ttdg_colsum_f32", ptr(X), X.shape[1], ptr(out), X.shape[0], X.shape[1], stream())
@@ -508,10 +547,10 @@ class MatchingLossFn(torch.autograd.Function):
             gemm_grouped([gdesc(Xs, DIM, 1, W1, HID, 1, P, HID, 1, M, HID, DIM),
                           gdesc(Xt, DIM, 1, W1, HID, 1, Q, HID, 1, M, HID, DIM, bias=b1, b_off=DIM)])
         else:
-            Xs = linear_raw(X, Psr)
-            Xt = linear_raw(X, Ptg)
-            P = linear_raw(Xs, W1, None, 0, HID)
-            Q = linear_raw(Xt, W1, b1, DIM, HID)
+            Xs = _big_linear(X, Psr)
+            Xt = _big_linear(X, Ptg)
+            P = _big_linear(Xs, W1, None, 0, HID)
+            Q = _big_linear(Xt, W1, b1, DIM, HID)
         w2f = w2.reshape(-1)
         tau, iters = opts.get("pair_tau", 0.05), opts.get("pair_iters", 20)
         fused = FUSED_PAIR_STAGE and max(sizes) <= PAIR_STAGE_MAX and not opts.get("ksplit")
@@ -525,9 +564,9 @@ class MatchingLossFn(torch.autograd.Function):
             with _timed("sinkhorn_pairs_fwd", sizes):
                 Wds, pot = sinkhorn_pairs_fwd(part, b2, gr, sizes, tau, iters)
         if not grouped:
-            q = linear_raw(X, Wq, bq)
-            k = linear_raw(X, Wk, bk)
-            U0 = linear_raw(X, U)
+            q = _big_linear(X, Wq, bq)
+            k = _big_linear(X, Wk, bk)
+            U0 = _big_linear(X, U)
         apack = mha_adjacency(q, k, gr, sizes, DIM ** -0.5, opts.get("drop_p", 0.0), opts.get("seed", 0))
         if opts.get("forced_U") is not None:      # parity tests: pseudo-labels supplied by the caller
             Ub, info, V0 = opts["forced_U"].contiguous(), None, None
@@ -572,20 +611,17 @@ class MatchingLossFn(torch.autograd.Function):
                                 second=(dXt, DIM, 1, Ptg, 1, DIM, DIM))])
             return (dX, dW1, db1, dw2.view(1, HID), db2, dPsr, dPtg, None, None, None, None, None, None, None)
         dW1 = torch.empty_like(W1)
-        gemm(dP, 1, HID, Xs, 1, DIM, dW1, HID, 1, HID, DIM, M)                    # dW1[:, :256] = dP^T Xs
-        gemm(dQ, 1, HID, Xt, 1, DIM, dW1, HID, 1, HID, DIM, M, c_off=DIM)         # dW1[:, 256:] = dQ^T Xt
+        _big_dw(dP, Xs, dW1)                                                      # dW1[:, :256] = dP^T Xs
+        _big_dw(dQ, Xt, dW1, DIM)                                                 # dW1[:, 256:] = dQ^T Xt
         db1 = colsum(dQ)
-        dXs = torch.empty_like(Xs)
-        dXt = torch.empty_like(Xt)
-        gemm(dP, HID, 1, W1, 1, HID, dXs, DIM, 1, M, DIM, HID)                    # dXs = dP W1[:, :256]
-        gemm(dQ, HID, 1, W1, 1, HID, dXt, DIM, 1, M, DIM, HID, b_off=DIM)         # dXt = dQ W1[:, 256:]
+        dXs = _big_dx(dP, W1, DIM)                                                # dXs = dP W1[:, :256]
+        dXt = _big_dx(dQ, W1, DIM, DIM)                                           # dXt = dQ W1[:, 256:]
         dPsr = torch.empty_like(Psr)
         dPtg = torch.empty_like(Ptg)
-        gemm(dXs, 1, DIM, X, 1, DIM, dPsr, DIM, 1, DIM, DIM, M)                   # dPsr = dXs^T X
-        gemm(dXt, 1, DIM, X, 1, DIM, dPtg, DIM, 1, DIM, DIM, M)
-        dX = torch.empty_like(X)
-        gemm(dXs, DIM, 1, Psr, 1, DIM, dX, DIM, 1, M, DIM, DIM)                   # dX = dXs Psr + dXt Ptg
-        gemm(dXt, DIM, 1, Ptg, 1, DIM, dX, DIM, 1, M, DIM, DIM, beta=1.0)
+        _big_dw(dXs, X, dPsr)                                                     # dPsr = dXs^T X
+        _big_dw(dXt, X, dPtg)
+        dX = _big_dx(dXs, Psr, DIM)                                               # dX = dXs Psr + dXt Ptg
+        _big_dx(dXt, Ptg, DIM, out=dX, accumulate=True)
         return (dX, dW1, db1, dw2.view(1, HID), db2, dPsr, dPtg, None, None, None, None, None, None, None)
 
 
