@@ -979,7 +979,9 @@ def test_large_graph_linear_products_on_both_engines(dev, golden):
         assert maxerr(x, y) <= 2e-3 * max(1e-30, float(y.abs().max()))
     assert set(a[4]) == set(b[4])
     for k in a[4]:
-        assert maxerr(a[4][k], b[4][k]) <= 2e-3 * max(1e-30, float(b[4][k].abs().max())), k
+        # (+ 1e-7 absolute: the gradient of the affinity's output bias is a sum that cancels to ~1e-9 - a constant shift of every
+        # block leaves the Sinkhorn output unchanged - so its two values are two roundings of zero)
+        assert maxerr(a[4][k], b[4][k]) <= 2e-3 * float(b[4][k].abs().max()) + 1e-7, k
     for eng in ("mm", "gemm"):
         for gi, x in enumerate(res[eng][3]):
             check_pgrad(gold, f"{name}_dnode{gi}", x, TOL)
