@@ -304,7 +304,7 @@ def test_trained_regime_solver_census(trained):
     # standard deviation above the arithmetic-only members' on average (its objective as much below), a small consistent offset of the
     # same sign the projection-noise members show against the float32 run in the other direction.  The gate is therefore 4.0, not 3.5
     # (the 16 batches of a continual run are positively correlated: the null variance of z is above 1); a solver that is worse on every
-    # batch reads -4.5 against four members.  The eight-member figures above stay asserted at their old width and recorded.
+    # batch reads -5.7 against four members.  The eight-member figures above stay asserted at their old width and recorded.
     z_obj_a = admission.rank_sum_z([r["objective_device"] for r in weak], [r["objective_oracle_runs"][:4] for r in weak]) if weak else 0.0
     z_loss_a = admission.rank_sum_z([r["loss_device"] for r in weak], [r["loss_oracle_runs"][:4] for r in weak]) if weak else 0.0
     z_obj_n = admission.rank_sum_z([r["objective_device"] for r in weak], [r["objective_oracle_runs"][4:] for r in weak]) if weak else 0.0
