@@ -57,6 +57,7 @@ struct mm_args {
   int64_t lda2, ldb2;
   int K2;
   int a2_map, a2_howo, a2_wo, a2_hw, a2_w, a2_s;
+  int dbg;                                   // ablation (tile field bits 8-9; WRONG RESULTS): 1 = only the first slab is loaded, 2 = no MFMA
 };
 
 __device__ __forceinline__ void mm_glds16(const float* g, float* lds_wave_base) {
@@ -118,6 +119,10 @@ struct mm_loader {
   }
 };
 
+// [r6] Measured and NOT adopted: requesting group q + 1's fragments under group q's MFMAs (two register sets, order pinned by sched_barrier,
+// exact lgkmcnt waits): 61.2 vs 59.0 us on 40000 x 512 x 128 - with the loads of every slab but the first REMOVED the product still takes
+// 54 of its 59 us (profiles/r06_pointwise_ablation.txt): five co-resident workgroups per CU already cover each other's LDS round trips, the K
+// loop runs at the rate the matrix pipe sustains at this clock.
 // the 64 (128 x 128 tile) MFMAs of one 32-deep slab: four groups of eight k; in a group the lower half wavefront owns k 8q .. 8q+3,
 // the upper half 8q+4 .. 8q+7 (one ds_read_b128 per 32 x 32 block and operand)
 template <int BM, int BN, bool AKC, bool BKC, bool PRO, bool TAIL>
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void mm_kernel(const mm_args p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wavefront's share of slab t has landed
     __syncthreads();                                     // ... everybody's has, and nobody still reads the other stage
     const int k0 = kbeg + t * MM_BK;
-    if (t + 1 < nk) {
+    if (t + 1 < nk && !(p.dbg & 1)) {
       float* nxt = smem + ((t + 1) & 1) * STAGE;
       if (!SEG2 || t + 1 < nk1) {
         la.issue(nxt, k0 + MM_BK, kend, wave);
@@ -271,7 +276,8 @@ __global__ __launch_bounds__(256, 2) void mm_kernel(const mm_args p) {
       }
     }
     // ragged end of the reduction (only the last slab can be ragged): the filler is zeroed in registers
-    if (SEG2 && t >= nk1) mm_slab<BM, BN, true, true, false, false>(As, Bs, fa, fb, sw, h, 0, MM_BK, p, pb_lds, acc);   // (no input activation on the second segment)
+    if (p.dbg & 2) {
+    } else if (SEG2 && t >= nk1) mm_slab<BM, BN, true, true, false, false>(As, Bs, fa, fb, sw, h, 0, MM_BK, p, pb_lds, acc);   // (no input activation on the second segment)
     else if (!SEG2 && kend - k0 < MM_BK) mm_slab<BM, BN, AKC, BKC, PRO, true>(As, Bs, fa, fb, sw, h, k0, kend, p, pb_lds, acc);
     else mm_slab<BM, BN, AKC, BKC, PRO, false>(As, Bs, fa, fb, sw, h, k0, kend, p, pb_lds, acc);
     if (LONGK && (t & 7) == 7) {
@@ -432,7 +438,7 @@ extern "C" int ttdg_mm_f32(const ttdg_mm_t* d, ttdg_stream_t stream) {
     TTDG_REQUIRE(d->B2 && d->a_layout == 0 && d->b_layout == 0 && d->kslices <= 1, "mm: the second segment needs k-contiguous operands and no split");
     TTDG_REQUIRE((d->K % MM_BK) == 0 && (d->K2 % MM_BK) == 0, "mm: with a second segment both reductions must be multiples of 32");
     TTDG_REQUIRE(((uintptr_t)d->A2 & 15) == 0 && ((uintptr_t)d->B2 & 15) == 0 && (d->lda2 & 3) == 0 && (d->ldb2 & 3) == 0, "mm: second-segment operand alignment");
-    TTDG_REQUIRE(d->tile == 0 || d->tile == 4, "mm: the second segment is built for 64 x 64 tiles");
+    TTDG_REQUIRE((d->tile & 255) == 0 || (d->tile & 255) == 4, "mm: the second segment is built for 64 x 64 tiles");
     if (a.a2_map) {
       TTDG_REQUIRE(d->a2_h > 0 && d->a2_w > 0, "mm: strided second-segment row map without an input size");
       const int ho = (d->a2_h - 1) / a.a2_s + 1, wo = (d->a2_w - 1) / a.a2_s + 1;
@@ -445,7 +451,8 @@ extern "C" int ttdg_mm_f32(const ttdg_mm_t* d, ttdg_stream_t stream) {
   a.kc = ks ? (((d->K + ks - 1) / ks) + MM_BK - 1) / MM_BK * MM_BK : 0;
   a.part = ks ? (float*)d->ws : nullptr;
   hipStream_t st = (hipStream_t)stream;
-  int tile = d->tile > 0 ? d->tile - 1 : mm_pick_tile(d->M, d->N, ks);
+  a.dbg = (d->tile >> 8) & 3;                                    // ablation bits (tools/ablate_pointwise.py); 0 on every product path
+  int tile = (d->tile & 255) > 0 ? (d->tile & 255) - 1 : mm_pick_tile(d->M, d->N, ks);
   TTDG_REQUIRE(tile >= 0 && tile < 4, "mm: tile code");
   dim3 gy(1, ks ? ks : 1);
   int rc;
