@@ -397,6 +397,10 @@ typedef struct {
 } ttdg_mm_t;
 size_t ttdg_mm_workspace_bytes(int M, int N, int kslices);
 int ttdg_mm_f32(const ttdg_mm_t* desc, ttdg_stream_t stream);
+/* up to 8 plain products (no input activation / second segment / row maps / forced tile) that share their operand layouts in ONE launch
+ * (+ one reduce launch for the split ones): the nn.Linear-shaped products of a matching step beyond 512 stacked nodes, 0.3 - 0.5 GFLOP each
+ * (utils/affinity.py:46-47,55, utils/attentions.py:72-74, multi_graph_matching.py:531 and their gradients).  `descs` is a HOST array. */
+int ttdg_mm_f32_grouped(const ttdg_mm_t* descs, int n, ttdg_stream_t stream);
 
 /* detectron2 ROIPooler [3P] in one launch: every ROI (image, x1, y1, x2, y2) picks its FPN level
  * clamp(floor(canonical_level + log2(sqrt(area) / canonical_size + 1e-8)), min_level, min_level + fp.n - 1) inside the

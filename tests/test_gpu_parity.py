@@ -962,7 +962,7 @@ def test_large_graph_linear_products_on_both_engines(dev, golden):
     forced = torch.from_numpy(cases.columns_to_perm(gold[f"{name}_U"])).to(dev) if hasattr(cases, "columns_to_perm") else None
     res = {}
     keep = ops.LARGE_GEMM_ENGINE
-    for eng in ("mm", "gemm"):
+    for eng in ("mm_grouped", "mm", "gemm"):
         ops.LARGE_GEMM_ENGINE = eng
         try:
             m, dn, loss, tr = _run_mgm3(dev, name, forced=forced)
@@ -971,6 +971,10 @@ def test_large_graph_linear_products_on_both_engines(dev, golden):
         res[eng] = (tr["Wds"].detach().clone(), tr["U0"].detach().clone(), float(loss.detach()), [x.grad.clone() for x in dn],
                     {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
         assert abs(res[eng][2] - float(gold[f"{name}_loss"])) <= TOL
+    # the grouped launches run the same tiles in the same order as the one-product launches: bit-identical
+    ga = res["mm_grouped"]
+    assert torch.equal(ga[0], res["mm"][0]) and torch.equal(ga[1], res["mm"][1]) and ga[2] == res["mm"][2]
+    assert all(torch.equal(x, y) for x, y in zip(ga[3], res["mm"][3])) and all(torch.equal(ga[4][k], res["mm"][4][k]) for k in ga[4])
     a, b = res["mm"], res["gemm"]
     assert maxerr(a[0], b[0]) <= 1e-5 and maxerr(a[1], b[1]) <= 1e-5 * max(1.0, float(b[1].abs().max())) and abs(a[2] - b[2]) <= 1e-6
     # gradients: the two engines' 1e-6 differences in P / Q pass through the Sinkhorn backward at tau = 0.05 and the relu masks of the
@@ -982,7 +986,7 @@ def test_large_graph_linear_products_on_both_engines(dev, golden):
         # (+ 1e-7 absolute: the gradient of the affinity's output bias is a sum that cancels to ~1e-9 - a constant shift of every
         # block leaves the Sinkhorn output unchanged - so its two values are two roundings of zero)
         assert maxerr(a[4][k], b[4][k]) <= 2e-3 * float(b[4][k].abs().max()) + 1e-7, k
-    for eng in ("mm", "gemm"):
+    for eng in ("mm_grouped", "mm", "gemm"):
         for gi, x in enumerate(res[eng][3]):
             check_pgrad(gold, f"{name}_dnode{gi}", x, TOL)
 

@@ -138,6 +138,7 @@ SIGNATURES = {
     "ttdg_relu_bwd": (C.c_int, [_P, _P, _P, C.c_size_t, _S]),
     "ttdg_mm_workspace_bytes": (C.c_size_t, [_I, _I, _I]),
     "ttdg_mm_f32": (C.c_int, [C.POINTER(Mm), _S]),
+    "ttdg_mm_f32_grouped": (C.c_int, [C.POINTER(Mm), _I, _S]),
     "ttdg_paste_masks": (C.c_int, [_P, _P, _I, _I, _I, _I, _F, _P, _S]),
     "ttdg_mask_pair_counts": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _P, _S]),
     "ttdg_mask_measures": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, C.c_double, _P, _S]),

@@ -183,8 +183,9 @@ __device__ __forceinline__ void mm_slab(const float* As, const float* Bs, const 
   }
 }
 
+// one (tile, reduction slice) of one product: `Lraw` of `T` tiles (dealt to the XCDs below), slice `zslice` of the pixel split
 template <int BM, int BN, bool AKC, bool BKC, bool PRO, bool LONGK, bool SEG2>
-__global__ __launch_bounds__(256, 2) void mm_kernel(const mm_args p) {
+__device__ __forceinline__ void mm_body(const mm_args& p, int Lraw, int T, int zslice) {
   constexpr int WM = BM / 2, WN = BN / 2, MB = WM / 32, NB = WN / 32;
   constexpr int ASZ = BM * MM_BK, BSZ = BN * MM_BK, STAGE = ASZ + BSZ;
   constexpr int CT_LD = BN + 4;
@@ -200,15 +201,15 @@ __global__ __launch_bounds__(256, 2) void mm_kernel(const mm_args p) {
 
   // tile of this workgroup: XCD x gets a contiguous run of the (m tile, n tile) list, n fastest
   const int NT = (p.N + BN - 1) / BN;
-  int L = blockIdx.x;
+  int L = Lraw;
   {
-    const int T = gridDim.x, q = T >> 3, r = T & 7, x = L & 7, i = L >> 3;
+    const int q = T >> 3, r = T & 7, x = L & 7, i = L >> 3;
     L = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
   }
   const int mt = L / NT, nt = L - mt * NT;
   const int m0 = mt * BM, n0 = nt * BN;
 
-  const int kbeg = p.part ? blockIdx.y * p.kc : 0;
+  const int kbeg = p.part ? zslice * p.kc : 0;
   const int kend = p.part ? min(p.K, kbeg + p.kc) : p.K;
   const int nk1 = (kend - kbeg + MM_BK - 1) / MM_BK;
   const int nk = nk1 + (SEG2 ? p.K2 / MM_BK : 0);          // (SEG2: K and K2 are multiples of the slab depth, no split)
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void mm_kernel(const mm_args p) {
       if (m < p.M && ncol) {
         f32x4 v = *reinterpret_cast<const f32x4*>(Ct + lr * CT_LD + cq);
         if (p.part) {
-          *reinterpret_cast<f32x4*>(p.part + ((size_t)blockIdx.y * p.M + m) * p.N + n0 + cq) = v;
+          *reinterpret_cast<f32x4*>(p.part + ((size_t)zslice * p.M + m) * p.N + n0 + cq) = v;
           continue;
         }
         v += bv;
@@ -346,6 +347,47 @@ __global__ __launch_bounds__(256, 2) void mm_kernel(const mm_args p) {
       }
     }
   }
+}
+
+template <int BM, int BN, bool AKC, bool BKC, bool PRO, bool LONGK, bool SEG2>
+__global__ __launch_bounds__(256, 2) void mm_kernel(const mm_args p) {
+  mm_body<BM, BN, AKC, BKC, PRO, LONGK, SEG2>(p, blockIdx.x, gridDim.x, blockIdx.y);
+}
+
+// Several products of one operand-layout class in ONE launch (64 x 64 tiles): the seventeen nn.Linear-shaped products of a matching
+// step beyond 512 stacked nodes are 0.3 - 0.5 GFLOP each - 8.6 - 15 us of which ~5 are launch and first-load latency.  Workgroup b
+// belongs to product d with start[d] <= b < start[d + 1]; inside a product the units are (slice, tile), tile fastest.
+#define MM_GROUP_MAX 8
+struct mm_group {
+  int n;
+  int start[MM_GROUP_MAX + 1];
+  int tiles[MM_GROUP_MAX];
+  mm_args a[MM_GROUP_MAX];
+};
+template <bool AKC, bool BKC, bool LONGK>
+__global__ __launch_bounds__(256, 2) void mm_group_kernel(const mm_group g) {
+  int d = 0;
+  while (d + 1 < g.n && (int)blockIdx.x >= g.start[d + 1]) ++d;
+  const int local = blockIdx.x - g.start[d], T = g.tiles[d];
+  const int z = local / T;
+  mm_body<64, 64, AKC, BKC, false, LONGK, false>(g.a[d], local - z * T, T, z);
+}
+
+struct mm_reduce_item { const float* part; float* C; const float* bias; int64_t ldc; int M, N, ks, start; };
+struct mm_reduce_group { int n; mm_reduce_item it[MM_GROUP_MAX]; };
+__global__ __launch_bounds__(256) void mm_group_reduce_kernel(const mm_reduce_group g) {
+  int d = 0;
+  while (d + 1 < g.n && (int)blockIdx.x >= g.it[d + 1].start) ++d;
+  const mm_reduce_item& r = g.it[d];
+  const size_t q = (size_t)(blockIdx.x - r.start) * 256 + threadIdx.x;
+  const int nq = r.N >> 2;
+  if (q >= (size_t)r.M * nq) return;
+  const int m = (int)(q / nq), n = 4 * (int)(q - (size_t)m * nq);
+  const size_t plane = (size_t)r.M * r.N, e = (size_t)m * r.N + n;
+  f32x4 v = *reinterpret_cast<const f32x4*>(r.part + e);
+  for (int z = 1; z < r.ks; ++z) v += *reinterpret_cast<const f32x4*>(r.part + z * plane + e);
+  if (r.bias) v += *reinterpret_cast<const f32x4*>(r.bias + n);
+  *reinterpret_cast<f32x4*>(r.C + (int64_t)m * r.ldc + n) = v;
 }
 
 // partial planes -> C (+ bias), fixed order: deterministic
@@ -392,10 +434,12 @@ static int mm_pick_tile(int M, int N, int kslices) { return 3; }
 
 extern "C" size_t ttdg_mm_workspace_bytes(int M, int N, int kslices) { return kslices > 1 ? (size_t)kslices * M * N * sizeof(float) : 0; }
 
-extern "C" int ttdg_mm_f32(const ttdg_mm_t* d, ttdg_stream_t stream) {
+// validation + the kernel-side argument block of one product; returns 1 for an empty product (nothing to launch)
+static int mm_prepare(const ttdg_mm_t* d, mm_args& a, int& ks_out, int& empty) {
+  empty = 0;
   TTDG_REQUIRE(d && d->A && d->B && d->C, "mm: null operand");
   TTDG_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0, "mm: negative size");
-  if (d->M == 0 || d->N == 0) return 0;
+  if (d->M == 0 || d->N == 0) { empty = 1; return 0; }
   TTDG_REQUIRE((d->N & 3) == 0 && (d->ldc & 3) == 0 && ((uintptr_t)d->C & 15) == 0, "mm: N, ldc must be multiples of 4 and C 16-byte aligned");
   TTDG_REQUIRE(((uintptr_t)d->A & 15) == 0 && ((uintptr_t)d->B & 15) == 0 && (d->lda & 3) == 0 && (d->ldb & 3) == 0, "mm: operands must be 16-byte aligned with leading dimensions that are multiples of 4");
   TTDG_REQUIRE(d->a_layout == 0 || d->a_layout == 1, "mm: a_layout");
@@ -410,7 +454,6 @@ extern "C" int ttdg_mm_f32(const ttdg_mm_t* d, ttdg_stream_t stream) {
   TTDG_REQUIRE(!d->pbias || (d->a_layout == 0 && d->b_layout == 0 && d->K <= MM_PRO_MAXK), "mm: the input shift needs k-contiguous operands and K <= 2048");
   TTDG_REQUIRE(d->kslices >= 0 && d->kslices <= 1024, "mm: kslices");
   TTDG_REQUIRE(d->kslices <= 1 || (d->ws && !d->res && !d->relu), "mm: the split form takes a workspace and no residual / ReLU");
-  mm_args a;
   a.A = d->A, a.B = d->B, a.C = d->C, a.bias = d->bias, a.res = d->res, a.bias2 = d->bias2, a.pbias = d->pbias;
   a.lda = d->lda, a.ldb = d->ldb, a.ldc = d->ldc, a.ldres = d->ldres;
   a.M = d->M, a.N = d->N, a.K = d->K;
@@ -450,8 +493,17 @@ extern "C" int ttdg_mm_f32(const ttdg_mm_t* d, ttdg_stream_t stream) {
   a.kslices = ks;
   a.kc = ks ? (((d->K + ks - 1) / ks) + MM_BK - 1) / MM_BK * MM_BK : 0;
   a.part = ks ? (float*)d->ws : nullptr;
-  hipStream_t st = (hipStream_t)stream;
   a.dbg = (d->tile >> 8) & 3;                                    // ablation bits (tools/ablate_pointwise.py); 0 on every product path
+  ks_out = ks;
+  return 0;
+}
+
+extern "C" int ttdg_mm_f32(const ttdg_mm_t* d, ttdg_stream_t stream) {
+  mm_args a;
+  int ks = 0, empty = 0;
+  if (int e = mm_prepare(d, a, ks, empty)) return e;
+  if (empty) return 0;
+  hipStream_t st = (hipStream_t)stream;
   int tile = (d->tile & 255) > 0 ? (d->tile & 255) - 1 : mm_pick_tile(d->M, d->N, ks);
   TTDG_REQUIRE(tile >= 0 && tile < 4, "mm: tile code");
   dim3 gy(1, ks ? ks : 1);
@@ -470,4 +522,52 @@ extern "C" int ttdg_mm_f32(const ttdg_mm_t* d, ttdg_stream_t stream) {
   const size_t quads = (size_t)d->M * (d->N >> 2);
   hipLaunchKernelGGL(mm_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, st, a.part, ks, d->C, d->ldc, d->bias, d->M, d->N);
   return ttdg_launch_status("mm_reduce");
+}
+
+// up to MM_GROUP_MAX products of ONE operand-layout class (and one long-reduction class) in one launch, 64 x 64 tiles; split
+// reductions are added by one grouped reduce launch.  No residual map / input activation / second segment in a group.
+extern "C" int ttdg_mm_f32_grouped(const ttdg_mm_t* descs, int n, ttdg_stream_t stream) {
+  TTDG_REQUIRE(descs && n >= 1 && n <= MM_GROUP_MAX, "mm_grouped: between 1 and 8 products");
+  mm_group g;
+  mm_reduce_group rg;
+  g.n = 0, rg.n = 0;
+  int units = 0, runits = 0, cls = -1, longk = -1;
+  for (int i = 0; i < n; ++i) {
+    const ttdg_mm_t* d = descs + i;
+    mm_args a;
+    int ks = 0, empty = 0;
+    if (int e = mm_prepare(d, a, ks, empty)) return e;
+    if (empty) continue;
+    TTDG_REQUIRE(!d->pbias && !d->A2 && !d->res_up && d->a_stride <= 1 && (d->tile & 255) == 0, "mm_grouped: plain products only (no input activation, second segment, row maps, forced tile)");
+    const int c = d->a_layout * 2 + d->b_layout, lk = (ks ? a.kc : d->K) >= 1024;
+    TTDG_REQUIRE((cls < 0 || cls == c) && (longk < 0 || longk == lk), "mm_grouped: the products of a group share their operand layouts and reduction class");
+    cls = c, longk = lk;
+    const int tiles = ((d->M + 63) / 64) * ((d->N + 63) / 64);
+    g.a[g.n] = a, g.tiles[g.n] = tiles, g.start[g.n] = units;
+    units += tiles * (ks ? ks : 1);
+    ++g.n;
+    if (ks) {
+      mm_reduce_item& r = rg.it[rg.n++];
+      r.part = a.part, r.C = d->C, r.bias = d->bias, r.ldc = d->ldc, r.M = d->M, r.N = d->N, r.ks = ks, r.start = runits;
+      runits += (int)(((size_t)d->M * (d->N >> 2) + 255) / 256);
+    }
+  }
+  if (g.n == 0) return 0;
+  g.start[g.n] = units;
+  hipStream_t st = (hipStream_t)stream;
+#define MM_GG(AKC, BKC)                                                                                        \
+  do {                                                                                                         \
+    if (longk) hipLaunchKernelGGL((mm_group_kernel<AKC, BKC, true>), dim3(units), dim3(256), 0, st, g);        \
+    else hipLaunchKernelGGL((mm_group_kernel<AKC, BKC, false>), dim3(units), dim3(256), 0, st, g);             \
+  } while (0)
+  if (cls == 0) MM_GG(true, true);
+  else if (cls == 1) MM_GG(true, false);
+  else MM_GG(false, false);
+#undef MM_GG
+  if (int e = ttdg_launch_status("mm_f32_grouped")) return e;
+  if (rg.n) {
+    hipLaunchKernelGGL(mm_group_reduce_kernel, dim3(runits), dim3(256), 0, st, rg);
+    return ttdg_launch_status("mm_grouped_reduce");
+  }
+  return 0;
 }

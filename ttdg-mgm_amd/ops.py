@@ -116,10 +116,9 @@ def linear_raw(x, W, b=None, w_col_off=0, w_ld=None, out=None):
     return y
 
 
-def mm(A, B, out, M, N, K, lda, ldb, ldc, bias=None, res=None, ldres=0, bias2=None, pbias=None, relu=False, prelu=False,
-       a_layout=0, b_layout=0, a_stride=0, a_hw=(0, 0), res_up=False, res_hw=(0, 0), kslices=0, tile=0, second=None):
-    """ttdg_mm_f32 (csrc/pointwise.hip): out[m, n] = act(sum_k A'(m, k) B(n, k) + bias[n] + (res[r(m), n] + bias2[n])).  Tensors are
-    passed as storage (pointer + leading dimensions); see include/ttdg_mgm.h for the row maps and layouts."""
+def _mm_desc(A, B, out, M, N, K, lda, ldb, ldc, bias=None, res=None, ldres=0, bias2=None, pbias=None, relu=False, prelu=False,
+             a_layout=0, b_layout=0, a_stride=0, a_hw=(0, 0), res_up=False, res_hw=(0, 0), kslices=0, tile=0, second=None):
+    """(ttdg_mm_t, workspace tensor to keep alive until the launch is enqueued)"""
     ws = torch.empty(kslices * M * N, device=out.device, dtype=torch.float32) if kslices > 1 else None
     # (positional: the field order of ttdg_mm_t; one constructor call instead of 27 attribute stores on the launch path)
     d = _lib.Mm(ptr(A), ptr(B), ptr(out), ptr(bias), ptr(res), ptr(bias2), ptr(pbias), ptr(ws), int(lda), int(ldb), int(ldc), int(ldres),
@@ -128,20 +127,55 @@ def mm(A, B, out, M, N, K, lda, ldb, ldc, bias=None, res=None, ldres=0, bias2=No
     if second is not None:          # (A2, B2, lda2, ldb2, K2, stride, (H, W)): a second reduction segment into the same accumulators
         A2, B2, lda2, ldb2, K2, st2, hw2 = second
         d.A2, d.B2, d.lda2, d.ldb2, d.K2, d.a2_stride, d.a2_h, d.a2_w = ptr(A2), ptr(B2), int(lda2), int(ldb2), int(K2), int(st2), int(hw2[0]), int(hw2[1])
+    return d, ws
+
+
+def mm(A, B, out, M, N, K, lda, ldb, ldc, **kw):
+    """ttdg_mm_f32 (csrc/pointwise.hip): out[m, n] = act(sum_k A'(m, k) B(n, k) + bias[n] + (res[r(m), n] + bias2[n])).  Tensors are
+    passed as storage (pointer + leading dimensions); see include/ttdg_mgm.h for the row maps and layouts (keywords: _mm_desc)."""
+    d, ws = _mm_desc(A, B, out, M, N, K, lda, ldb, ldc, **kw)
     call("ttdg_mm_f32", C.byref(d), stream())
     return out
+
+
+def mm_grouped(products):
+    """ttdg_mm_f32_grouped: up to 8 plain products of one operand-layout class in ONE launch.  ``products``: list of (args, kwargs) of mm()."""
+    for i in range(0, len(products), 8):
+        built = [_mm_desc(*a, **k) for a, k in products[i:i + 8]]
+        arr = (_lib.Mm * len(built))(*[d for d, _ in built])
+        call("ttdg_mm_f32_grouped", arr, len(built), stream())
 
 
 # The nn.Linear-shaped products of a matching step with more than GROUPED_GEMM_MAX_ROWS stacked nodes (cfg-3: 2048) on the streaming
 # product of csrc/pointwise.hip (64 x 64 tiles, five workgroups per CU, LDS-DMA: 8.6 - 9.2 us per 2048-row projection against 10.2 -
 # 11.6 us for gemm_f32's one workgroup per CU; weight gradients over 8 row slices 15.0 against 16.4 us) - "gemm" = the round-4 kernel
-# (ascending-k accumulation; the parity tests compare the two).
-LARGE_GEMM_ENGINE = "mm"
+# (ascending-k accumulation; the parity tests compare the two).  "mm_grouped" (default): the same products, those that do not depend on
+# each other in ONE launch per operand-layout class (ttdg_mm_f32_grouped: 21 launches per forward + backward -> 9).
+LARGE_GEMM_ENGINE = "mm_grouped"
+
+
+def _lin_spec(x, W, y, b=None, col_off=0, ld=None):
+    M, K = x.shape
+    Wv = W if col_off == 0 else W[:, col_off:]
+    return (x, Wv, y, M, W.shape[0], K, K, W.shape[1] if ld is None else ld, y.shape[1]), dict(bias=b)
+
+
+def _dx_spec(dy, W, dx, col_off=0):
+    M, N = dy.shape
+    Wv = W if col_off == 0 else W[:, col_off:]
+    return (dy, Wv, dx, M, dx.shape[1], N, N, W.shape[1], dx.shape[1]), dict(b_layout=1)
+
+
+def _dw_spec(dy, x, out, col_off=0):
+    M, N = dy.shape
+    K = x.shape[1]
+    ov = out if col_off == 0 else out[:, col_off:]
+    return (dy, x, ov, N, K, M, N, K, out.shape[1]), dict(a_layout=1, b_layout=1, kslices=max(0, min(8, M // 256)))
 
 
 def _big_linear(x, W, b=None, col_off=0, ld=None):
     """y = x @ W[:, off:off + K]^T + b for a tall x (the large-graph path of MatchingLossFn)."""
-    if LARGE_GEMM_ENGINE != "mm":
+    if LARGE_GEMM_ENGINE == "gemm":
         return linear_raw(x, W, b, col_off, ld)
     M, K = x.shape
     N = W.shape[0]
@@ -154,7 +188,7 @@ def _big_dx(dy, W, K, col_off=0, out=None, accumulate=False):
     """dx (M, K) = dy (M, N) @ W[:, off:off + K] (W row-major (N, ldw)); ``accumulate``: += into ``out``."""
     M, N = dy.shape
     dx = out if out is not None else torch.empty(M, K, device=dy.device, dtype=torch.float32)
-    if LARGE_GEMM_ENGINE != "mm":
+    if LARGE_GEMM_ENGINE == "gemm":
         return gemm(dy, N, 1, W, 1, W.shape[1], dx, K, 1, M, K, N, b_off=col_off, beta=1.0 if accumulate else 0.0)
     Wv = W if col_off == 0 else W[:, col_off:]
     return mm(dy, Wv, dx, M, K, N, N, W.shape[1], K, b_layout=1, res=dx if accumulate else None, ldres=K)
@@ -165,7 +199,7 @@ def _big_dw(dy, x, out, col_off=0):
     added in a fixed order."""
     M, N = dy.shape
     K = x.shape[1]
-    if LARGE_GEMM_ENGINE != "mm":
+    if LARGE_GEMM_ENGINE == "gemm":
         return gemm(dy, 1, N, x, 1, K, out, out.shape[1], 1, N, K, M, c_off=col_off)
     ov = out if col_off == 0 else out[:, col_off:]
     return mm(dy, x, ov, N, K, M, N, K, out.shape[1], a_layout=1, b_layout=1, kslices=max(0, min(8, M // 256)))
@@ -546,6 +580,13 @@ class MatchingLossFn(torch.autograd.Function):
                           gdesc(X, DIM, 1, U, DIM, 1, U0, U.shape[0], 1, M, U.shape[0], DIM)])
             gemm_grouped([gdesc(Xs, DIM, 1, W1, HID, 1, P, HID, 1, M, HID, DIM),
                           gdesc(Xt, DIM, 1, W1, HID, 1, Q, HID, 1, M, HID, DIM, bias=b1, b_off=DIM)])
+        elif LARGE_GEMM_ENGINE == "mm_grouped":
+            dev = X.device
+            Xs, Xt, q, k = (torch.empty(M, DIM, device=dev, dtype=torch.float32) for _ in range(4))
+            U0 = torch.empty(M, U.shape[0], device=dev, dtype=torch.float32)
+            P, Q = (torch.empty(M, HID, device=dev, dtype=torch.float32) for _ in range(2))
+            mm_grouped([_lin_spec(X, Psr, Xs), _lin_spec(X, Ptg, Xt), _lin_spec(X, Wq, q, bq), _lin_spec(X, Wk, k, bk), _lin_spec(X, U, U0)])
+            mm_grouped([_lin_spec(Xs, W1, P, None, 0, HID), _lin_spec(Xt, W1, Q, b1, DIM, HID)])
         else:
             Xs = _big_linear(X, Psr)
             Xt = _big_linear(X, Ptg)
@@ -563,7 +604,7 @@ class MatchingLossFn(torch.autograd.Function):
                 part = affinity_pairwise_fwd(P, Q, w2f, gr, ks)
             with _timed("sinkhorn_pairs_fwd", sizes):
                 Wds, pot = sinkhorn_pairs_fwd(part, b2, gr, sizes, tau, iters)
-        if not grouped:
+        if not grouped and LARGE_GEMM_ENGINE != "mm_grouped":
             q = _big_linear(X, Wq, bq)
             k = _big_linear(X, Wk, bk)
             U0 = _big_linear(X, U)
@@ -609,6 +650,16 @@ class MatchingLossFn(torch.autograd.Function):
                           gdesc(dXt, 1, DIM, X, 1, DIM, dPtg, DIM, 1, DIM, DIM, M),
                           gdesc(dXs, DIM, 1, Psr, 1, DIM, dX, DIM, 1, M, DIM, DIM,                     # dX = dXs Psr + dXt Ptg (two K segments)
                                 second=(dXt, DIM, 1, Ptg, 1, DIM, DIM))])
+            return (dX, dW1, db1, dw2.view(1, HID), db2, dPsr, dPtg, None, None, None, None, None, None, None)
+        if LARGE_GEMM_ENGINE == "mm_grouped":
+            dW1, dPsr, dPtg = torch.empty_like(W1), torch.empty_like(Psr), torch.empty_like(Ptg)
+            dXs, dXt, dX = torch.empty_like(Xs), torch.empty_like(Xt), torch.empty_like(X)
+            mm_grouped([_dw_spec(dP, Xs, dW1), _dw_spec(dQ, Xt, dW1, DIM)])           # dW1 = [dP^T Xs | dQ^T Xt]
+            db1 = colsum(dQ)
+            mm_grouped([_dx_spec(dP, W1, dXs), _dx_spec(dQ, W1, dXt, DIM)])           # dXs = dP W1[:, :256], dXt = dQ W1[:, 256:]
+            mm_grouped([_dw_spec(dXs, X, dPsr), _dw_spec(dXt, X, dPtg)])
+            _big_dx(dXs, Psr, DIM, out=dX)                                            # dX = dXs Psr + dXt Ptg (the second reads the first)
+            _big_dx(dXt, Ptg, DIM, out=dX, accumulate=True)
             return (dX, dW1, db1, dw2.view(1, HID), db2, dPsr, dPtg, None, None, None, None, None, None, None)
         dW1 = torch.empty_like(W1)
         _big_dw(dP, Xs, dW1)                                                      # dW1[:, :256] = dP^T Xs
