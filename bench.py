@@ -77,6 +77,7 @@ def parse(argv=None):
     ap.add_argument("--roi-align-mode", type=int, default=3, help="A/B: 3 = channels-last ROIPooler kernel (default), 2 = separable table kernel on NCHW, "
                                                                   "1 = direct kernel, XCD-sliced, 0 = direct, flat (round 1)")
     ap.add_argument("--roi-xcd-chunks", action="store_true", help="A/B: channels-last ROIPooler with one contiguous eighth of the ROI list per XCD instead of ROI r on workgroup r")
+    ap.add_argument("--roi-one-channel-per-lane", action="store_true", help="A/B: the round 2-5 channels-last ROIPooler (one channel per lane, dword taps) instead of four channels per lane (16-byte taps)")
     ap.add_argument("--roi-chunk", type=int, default=0, help="A/B: bins the channels-last ROIPooler stages per output flush: 49 (round 2), 25 (default) or 13")
     ap.add_argument("--graphs", action="store_true", help="A/B: hipGraph replay of the backbone's no-grad forward in the Dice pass (modeling/graphed.py; default: eager - measured equal)")
     ap.add_argument("--timer-every", type=int, default=7, help="HIP-event pairs around every N-th launch of the kernels launched dozens of times per batch "
@@ -306,7 +307,7 @@ def kernel_rooflines(run):
                         "affinity_bwd": "affinity_bwd_kernel(+finish)", "sinkhorn_pairs_fwd": "sinkhorn_pairs_fwd_kernel",
                         "sinkhorn_pairs_bwd": "sinkhorn_pairs_bwd_kernel", "pair_stage_fwd": "pair_stage_fwd_kernel",
                         "pair_stage_bwd": "pair_stage_bwd_kernel", "bias_act": BIAS_ACT_KERNEL, "relu_bwd": "relu_bwd_kernel",
-                        "roi_align_nhwc": "roi_align_nhwc_kernel", "row_scale_multi": "row_scale_multi_kernel",
+                        "roi_align_nhwc": "roi_align_nhwc4_kernel", "row_scale_multi": "row_scale_multi_kernel",
                         "pointwise_fwd": "mm_kernel (1x1 convolutions, forward + fused epilogue)", "pointwise_dx": "mm_kernel (1x1 convolutions, dX)",
                         "pointwise_dw": "mm_kernel + mm_reduce_kernel (1x1 convolutions, dW over pixel slices)"}[nm],
              "bound": "hbm" if hbm else "mfma", "achieved": ach, "peak": peak, "unit": "GB/s" if hbm else "TFLOP/s", "frac": ach / peak,
@@ -703,9 +704,10 @@ def gpu_main(args, rank, world, local):
             _ops.GAGM_VARIANT |= _lib.GAGM_256_THREADS
         _ops.ROI_ALIGN_NHWC = args.roi_align_mode == 3
         _lib.load().ttdg_debug_set_roi_align_sliced(min(args.roi_align_mode, 2))
-    if args.roi_xcd_chunks or args.roi_chunk:
+    if args.roi_xcd_chunks or args.roi_chunk or args.roi_one_channel_per_lane:
         from ttdg_mgm_amd import _lib
-        _lib.load().ttdg_debug_set_roi_align_sliced(2 | (16 if args.roi_xcd_chunks else 0) | {0: 0, 25: 0, 49: 32, 13: 64}[args.roi_chunk])
+        _lib.load().ttdg_debug_set_roi_align_sliced(2 | (16 if args.roi_xcd_chunks else 0) | {0: 0, 25: 0, 49: 32, 13: 64}[args.roi_chunk] |
+                                                    (128 if args.roi_one_channel_per_lane or args.roi_xcd_chunks or args.roi_chunk else 0))
     if args.images:
         # strong scaling: the FIXED stream is sharded; warm-up batches come from another stream so that the timed work is
         # exactly args.images images whatever the rank count

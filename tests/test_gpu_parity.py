@@ -2270,6 +2270,33 @@ def test_roi_align_multilevel_matches_per_level_pooler(dev):
                   cb.roi_align_multilevel(f5, rois, [4, 8, 16, 32], 7)) <= 1e-4
 
 
+def test_roi_align_four_channels_per_lane_is_the_one_channel_kernel(dev):
+    """[r6] roi_align_nhwc4_kernel (a lane owns four consecutive channels: one 16-byte load per tap, the ROI's (C, P, P) block leaves
+    as one contiguous run) against roi_align_nhwc_kernel (one channel per lane): same taps, same weights, same order of additions -
+    bit for bit, for P = 7 and 14, channel counts 256 / 64 / 260 (a partial last group of 256), ROIs over every border, beyond the
+    table limits and degenerate; and both against the host statement."""
+    from ttdg_mgm_amd import _lib, ops
+    cb = _cpu_backend()
+    g = synth.gen(7510)
+    rois = torch.tensor([[0, 1.0, 2.0, 30.0, 40.0], [1, 5.0, 5.0, 20.0, 12.0], [1, 0.0, 0.0, 63.0, 63.0], [0, -300.0, -200.0, 900.0, 800.0],
+                         [1, 250.0, 250.0, 700.0, 262.0], [0, 10.0, 10.0, 10.0, 10.0], [1, 3.0, 3.0, 3.5, 3.5], [0, 300.0, 40.0, 340.0, 120.0],
+                         [1, -90.0, 20.0, -30.0, 200.0]] + [[int(i % 2), float(3 * i), float(2 * i), float(3 * i + 20 + 5 * i), float(2 * i + 30 + 3 * i)] for i in range(40)])
+    for C in (256, 64, 260):
+        feats = [synth.normal(g, (2, C, 64 // s, 64 // s), 1.0) for s in (1, 2, 4, 8)]
+        fd = [f.to(dev).contiguous(memory_format=torch.channels_last) for f in feats]
+        views = ops.to_nhwc(fd)
+        for P in (7, 14):
+            out = {}
+            for wide in (True, False):
+                _lib.load().ttdg_debug_set_roi_align_sliced(2 | (0 if wide else 128))
+                try:
+                    out[wide] = ops.roi_align_multilevel(fd, rois.to(dev), [4, 8, 16, 32], P, nhwc=views)
+                finally:
+                    _lib.load().ttdg_debug_set_roi_align_sliced(2)
+            assert torch.equal(out[True], out[False]), (C, P, maxerr(out[True], out[False]))
+            assert maxerr(out[True], cb.roi_align_multilevel(feats, rois, [4, 8, 16, 32], P)) <= 1e-4, (C, P)
+
+
 # ------------------------------------------------------------------------------------------- N3: HiPPI / U_sup
 @pytest.mark.parametrize("name,sizes,seed,proj", cases.HIPPI_CASES)
 def test_hippi_golden(dev, golden, name, sizes, seed, proj):

@@ -1151,6 +1151,116 @@ __global__ __launch_bounds__(256) void roi_align_nhwc_kernel(ttdg_fpn_t fp, ttdg
   }
 }
 
+// ---- [r6] the same pooler with FOUR channels per lane ---------------------------------------------------------------------------------
+// roi_align_nhwc_kernel issues one dword per lane and tap: 256 B per wavefront instruction, 3.9 GB of tap traffic through the L1 / texture
+// addresser per box-head call (4000 ROIs x 49 bins x ~20 taps x 1 KB) - the kernel is bound by that instruction rate, not by HBM or the
+// fabric (the XCD-chunk A/B of round 3 moved it by 2 %, FETCH_SIZE 3.6 x the algorithmic bytes is L2 traffic between overlapping proposals).
+// Here a lane owns four consecutive channels (one 16-byte load per tap: 1 KB per wavefront instruction, a quarter of the instructions for
+// the same bytes), a wavefront covers 256 channels, and the four wavefronts of the workgroup split the BINS of the ROI (bin = wave + 4 i).
+// The results meet in one LDS tile [bin][256 + 1] and leave as ONE contiguous run per 49-bin chunk and channel: for P = 7 the ROI's whole
+// (C, 7, 7) block is a single 50 KB contiguous store.  Same taps, same weights, same order of the additions per output value: bit-identical
+// to roi_align_nhwc_kernel.
+#define RN4_CH 49
+__global__ __launch_bounds__(256) void roi_align_nhwc4_kernel(ttdg_fpn_t fp, ttdg_levels_t lv, const float* __restrict__ rois, int R, int P,
+                                                              float canon_size, int canon_level, int min_level, float* __restrict__ out) {
+  __shared__ RaAxis s_y, s_x;
+  __shared__ __attribute__((aligned(16))) float s_t[RN4_CH * 257];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = blockIdx.x;
+  if (r >= R) return;
+  const int C = fp.C;
+  const float* roi = rois + (size_t)r * 5;
+  const int b = (int)roi[0];
+  const float area = fmaxf((roi[3] - roi[1]) * (roi[4] - roi[2]), 0.f);
+  int l = (int)floorf((float)canon_level + log2f(sqrtf(area) / canon_size + 1e-8f));
+  l = min(max(l, min_level), min_level + fp.n - 1) - min_level;
+  const int H = fp.h[l], W = fp.w[l];
+  const float scale = 1.f / (float)lv.stride[l];
+  const float x1 = roi[1] * scale - 0.5f, y1 = roi[2] * scale - 0.5f;
+  const float rw = roi[3] * scale - 0.5f - x1, rh = roi[4] * scale - 0.5f - y1;
+  const float bw = rw / P, bh = rh / P;
+  const int gh = max(1, (int)ceilf(rh / P)), gw = max(1, (int)ceilf(rw / P));
+  const bool tables = gh <= RA_MAXW - 2 && gw <= RA_MAXW - 2;
+  if (tables) {
+    if (tid < P) ra_build_axis(s_y, tid, y1, bh, gh, H);
+    else if (tid >= 64 && tid < 64 + P) ra_build_axis(s_x, tid - 64, x1, bw, gw, W);
+  }
+  __syncthreads();
+  const float inv = 1.f / (float)(gh * gw);
+  const int PP = P * P;
+  typedef float rn4_f4 __attribute__((ext_vector_type(4)));
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int c = c0 + 4 * lane;
+    const bool cok = c < C;                                   // (C % 4 == 0: a lane's four channels are inside or outside)
+    const float* f = fp.feat[l] + (size_t)b * H * W * C + (cok ? c : 0);
+    const int nch = min(256, C - c0);
+    for (int q0 = 0; q0 < PP; q0 += RN4_CH) {
+      const int nb = min(RN4_CH, PP - q0);
+      for (int j = wave; j < nb; j += 4) {
+        const int bin = q0 + j, ph = bin / P, pw = bin - ph * P;
+        rn4_f4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (tables) {
+          const int ny = s_y.cnt[ph], nx = s_x.cnt[pw], ys = s_y.start[ph], xs = s_x.start[pw];
+          float wxr[RA_MAXW];
+#pragma unroll
+          for (int kx = 0; kx < RA_MAXW; ++kx) wxr[kx] = s_x.w[pw][kx];
+          for (int ky0 = 0; ky0 < ny; ky0 += 2) {
+            rn4_f4 v[2][RA_MAXW];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+              const float* rowp = f + ((size_t)(ys + ky0 + a) * W + xs) * C;
+#pragma unroll
+              for (int kx = 0; kx < RA_MAXW; ++kx) {
+                if (ky0 + a < ny && kx < nx) v[a][kx] = *reinterpret_cast<const rn4_f4*>(rowp + (size_t)kx * C);
+                else v[a][kx] = rn4_f4{0.f, 0.f, 0.f, 0.f};
+              }
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+              const float wyv = (ky0 + a < ny) ? s_y.w[ph][ky0 + a] : 0.f;
+#pragma unroll
+              for (int kx = 0; kx < RA_MAXW; ++kx) {
+                const float wgt = wyv * wxr[kx];
+                acc.x = fmaf(wgt, v[a][kx].x, acc.x); acc.y = fmaf(wgt, v[a][kx].y, acc.y);
+                acc.z = fmaf(wgt, v[a][kx].z, acc.z); acc.w = fmaf(wgt, v[a][kx].w, acc.w);
+              }
+            }
+          }
+        } else {      // more than 8 samples per bin and axis: the direct formula
+          for (int iy = 0; iy < gh; ++iy) {
+            float y = y1 + ph * bh + (iy + 0.5f) * bh / gh;
+            for (int ix = 0; ix < gw; ++ix) {
+              float x = x1 + pw * bw + (ix + 0.5f) * bw / gw;
+              if (y < -1.f || y > H || x < -1.f || x > W) continue;
+              float yy = fmaxf(y, 0.f), xx = fmaxf(x, 0.f);
+              int y0 = (int)yy, x0 = (int)xx, y1i, x1i;
+              if (y0 >= H - 1) { y0 = y1i = H - 1; yy = (float)y0; } else y1i = y0 + 1;
+              if (x0 >= W - 1) { x0 = x1i = W - 1; xx = (float)x0; } else x1i = x0 + 1;
+              const float ly = yy - y0, lx = xx - x0, hy = 1.f - ly, hx = 1.f - lx;
+              const rn4_f4 a00 = *reinterpret_cast<const rn4_f4*>(f + ((size_t)y0 * W + x0) * C), a01 = *reinterpret_cast<const rn4_f4*>(f + ((size_t)y0 * W + x1i) * C);
+              const rn4_f4 a10 = *reinterpret_cast<const rn4_f4*>(f + ((size_t)y1i * W + x0) * C), a11 = *reinterpret_cast<const rn4_f4*>(f + ((size_t)y1i * W + x1i) * C);
+              acc.x += hy * hx * a00.x + hy * lx * a01.x + ly * hx * a10.x + ly * lx * a11.x;
+              acc.y += hy * hx * a00.y + hy * lx * a01.y + ly * hx * a10.y + ly * lx * a11.y;
+              acc.z += hy * hx * a00.z + hy * lx * a01.z + ly * hx * a10.z + ly * lx * a11.z;
+              acc.w += hy * hx * a00.w + hy * lx * a01.w + ly * hx * a10.w + ly * lx * a11.w;
+            }
+          }
+        }
+        float* t = s_t + j * 257 + 4 * lane;
+        t[0] = acc.x * inv, t[1] = acc.y * inv, t[2] = acc.z * inv, t[3] = acc.w * inv;
+      }
+      __syncthreads();
+      // channel ch of the block owns out[ch * PP + q0 .. + nb): one contiguous run per channel; all of (C, P, P) when nb == PP
+      float* o = out + ((size_t)r * C + c0) * PP + q0;
+      for (int e = tid; e < nch * nb; e += 256) {
+        const int ch = e / nb, jj = e - ch * nb;
+        o[(size_t)ch * PP + jj] = s_t[jj * 257 + ch];
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // NCHW -> NHWC copy of one feature level: (B, C, HW) -> (B, HW, C), 32 x 32 tiles through LDS (both sides coalesced)
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW) {
   __shared__ float t[32][33];
@@ -1179,6 +1289,7 @@ extern "C" int ttdg_nchw_to_nhwc(const float* src, float* dst, int B, int C, int
 }
 
 static int g_roi_nhwc_chunk = 25;   // bins per output flush: 25 (default: 355 vs 421 us per call, profiles/r03_roi_align_ab.txt); ttdg_debug_set_roi_align_sliced(mode | 32) = 49, | 64 = 13
+static int g_roi_nhwc_wide = 1;     // [r6] 1 = four channels per lane (roi_align_nhwc4_kernel, C % 4 == 0), 0 = one channel per lane; ttdg_debug_set_roi_align_sliced(mode | 128) selects 0
 static int g_roi_nhwc_xcd = 0;      // 1 = XCD x owns a contiguous eighth of the ROI list, 0 = ROI r on workgroup r (default: measured 427 vs 437 us per call,
                                     // profiles/r03_roi_align_ab.txt - the pooler is not bound by fabric traffic); ttdg_debug_set_roi_align_sliced(mode | 16) selects 1
 extern "C" int ttdg_roi_align_multilevel_nhwc(ttdg_fpn_t fp, ttdg_levels_t lv, const float* rois, int R, int P, float canonical_size,
@@ -1186,6 +1297,13 @@ extern "C" int ttdg_roi_align_multilevel_nhwc(ttdg_fpn_t fp, ttdg_levels_t lv, c
   TTDG_REQUIRE(rois && out && R >= 0 && P > 0 && P <= RA_MAXP && fp.n >= 1 && fp.n <= TTDG_MAX_LEVELS && fp.C > 0 && lv.n == fp.n,
                "roi_align_multilevel_nhwc: bad arguments");
   if (R == 0) return 0;
+  bool aligned = (fp.C & 3) == 0;
+  for (int l = 0; l < fp.n; ++l) aligned = aligned && (((uintptr_t)fp.feat[l]) & 15) == 0;
+  if (g_roi_nhwc_wide && aligned && !g_roi_nhwc_xcd) {
+    hipLaunchKernelGGL(roi_align_nhwc4_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, fp, lv, rois, R, P, canonical_size, canonical_level,
+                       min_level, out);
+    return ttdg_launch_status("roi_align_multilevel_nhwc (4 channels per lane)");
+  }
   const int grid = g_roi_nhwc_xcd ? 8 * ((R + 7) / 8) : R;
   if (g_roi_nhwc_chunk == 13)
     hipLaunchKernelGGL((roi_align_nhwc_kernel<13>), dim3(grid), dim3(256), 0, (hipStream_t)stream, fp, lv, rois, R, P, canonical_size,
@@ -1205,6 +1323,7 @@ static int g_roi_align_mode = 2;
 // kernel gives every XCD one contiguous eighth of the ROI list instead of ROI r on workgroup r
 extern "C" int ttdg_debug_set_roi_align_sliced(int on) {
   g_roi_nhwc_xcd = (on >= 0 && (on & 16)) ? 1 : 0;
+  g_roi_nhwc_wide = (on >= 0 && (on & 128)) ? 0 : 1;
   g_roi_nhwc_chunk = (on >= 0 && (on & 64)) ? 13 : ((on >= 0 && (on & 32)) ? 49 : 25);
   if (on >= 0) on &= 7;
   g_roi_align_mode = on < 0 ? 2 : (on > 2 ? 2 : on);
