@@ -83,6 +83,7 @@ def parse(argv=None):
     ap.add_argument("--timer-every", type=int, default=7, help="HIP-event pairs around every N-th launch of the kernels launched dozens of times per batch "
                     "(ops.KERNEL_TIMER_SAMPLED; 1 = every launch, the round 1-5 protocol, which costs ~4 %% of the timed region)")
     ap.add_argument("--own-pointwise-backward", action="store_true", help="A/B: dX / dW of the 1 x 1 convolutions on the streaming product's backward layouts instead of MIOpen")
+    ap.add_argument("--cfg3-only", action="store_true", help="run only the cfg-3 operator-level block and print it (the command rocprofv3 profiles for profiles/rNN_cfg3_block_*)")
     ap.add_argument("--no-cfg3", action="store_true", help="skip the cfg-3 operator-level block and the whole-step FLOP count")
     ap.add_argument("--stamp-all", action="store_true", help="rounds 1-5 protocol: the headline pass itself stamps every hand-written kernel (no separate instrumented pass)")
     ap.add_argument("--no-kernel-timers", action="store_true", help="debug A/B: no HIP events around the hand-written kernels in the timed pass (the rooflines are then empty): what the event pairs themselves cost")
@@ -444,10 +445,26 @@ def cfg3_block(device, seeds=(0, 1, 2, 3, 4), reps=20):
                 its.append(r["avg_iterations_per_launch"])
                 solver_us.append(r["avg_launch_ms"] * 1e3)
     mean = lambda v: sum(v) / max(1, len(v))
+    # what an event pair itself reads with nothing between its two records (the marker packets' own round trip): rocprofv3's kernel
+    # durations (profiles/rNN_cfg3_rocprof_summary.txt, same block under `bench.py --cfg3-only`) are this much shorter per launch
+    br = []
+    for _ in range(50):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        b.record()
+        br.append((a, b))
+    torch.cuda.synchronize()
+    bracket = sorted(x.elapsed_time(y) * 1e3 for x, y in br)[len(br) // 2]
     return {"workload": "cfg-3: MGM3_unsup forward + backward, 8 graphs x 256 nodes, d = 256, h = 512, seeds %s, %d repetitions each (HIP events on the launch stream)" % (list(seeds), reps),
             "fwd_bwd_ms": mean(fb), "fwd_bwd_ms_per_seed": fb, "fwd_ms": mean(fw), "fwd_ms_per_seed": fw,
             "solver_us": mean(solver_us) if solver_us else None, "executed_iterations": mean(its) if its else None,
             "solver_us_per_iteration": (mean(solver_us) / mean(its)) if its and mean(its) else None,
+            "iterations_note": "executed_iterations = the stage machine's count (info[0..5]); it includes the iterations a Hungarian-stage cycle of period >= 3 lets the "
+                               "solver skip (the exact cycle shortcut jumps to the state iteration max_iter - 1 would land on), so on inputs that cycle - these seeds do - "
+                               "fewer iterations are launched than counted (rocprofv3: ~35 launched per solve)",
+            "event_bracket_us": bracket,
+            "kernels_note": "avg_us = live HIP-event bracket around the launch (includes event_bracket_us of marker round trip and the launch latency of a cold "
+                            "stream); rocprofv3 kernel durations of the same block: profiles/r06_cfg3_block_rocprof_summary.txt",
             "kernels": {k: {"avg_us": mean(v["avg_us"]), "algorithmic_work": mean(v["work"]), "frac": mean(v["frac"]), "bound": v["bound"],
                             "unit": "bytes" if v["bound"] == "hbm" else "FLOP"} for k, v in kern.items()}}
 
@@ -684,6 +701,10 @@ def gpu_main(args, rank, world, local):
         __graft_entry__.build()
     if world > 1:
         dist.barrier()
+    if args.cfg3_only:
+        if rank == 0:
+            print(json.dumps(_finite({"cfg3": cfg3_block(device)})))
+        return
     K, W, B = steps_per_rank(args, world), args.warmup, args.batch
     cfg = base_cfg(args, device)
     from ttdg_mgm_amd import ops as _ops
