@@ -281,7 +281,7 @@ def kernel_rooflines(run):
             M = sum(sizes)
             base = 2 * u * sum(n * n for n in sizes) + 4 * M * u * u + 2 * M * M * u
             e["work"] += (isk + ih) * base + isk * 5 * ksk * sum(max(n, u) ** 2 for n in sizes) + ih * sum(min(n, u) ** 2 * max(n, u) for n in sizes)
-            e["extra"].append((sizes, it[:6], it[14], it[15]))
+            e["extra"].append((sizes, it[:6], it[14], it[15], it[22] if len(it) > 22 else 0))
         elif nm in ("affinity_fwd", "affinity_bwd"):
             e["work"] += (1 if nm == "affinity_fwd" else 2) * sum(4 * H * r * c for r, c in _pairs(meta))
         elif nm in ("sinkhorn_pairs_fwd", "sinkhorn_pairs_bwd"):
@@ -326,6 +326,7 @@ def kernel_rooflines(run):
                       "avg_nodes_per_launch": sum(sum(x[0]) for x in e["extra"]) / len(e["extra"]), "graphs_per_launch": len(e["extra"][0][0]),
                       "avg_iterations_per_stage": [sum(x[1][k] for x in e["extra"]) / len(e["extra"]) for k in range(6)],
                       "hungarian_cycle_periods": [x[2] for x in e["extra"]],
+                      "avg_executed_launch_pairs": sum(x[4] for x in e["extra"]) / len(e["extra"]),      # multi-workgroup solver only (info[22]); 0: single-workgroup kernel
                       "note": "single-workgroup latency-bound solver (state LDS-resident); fp32 VALU peak == fp32 MFMA peak"})
         out.append(r)
     out.sort(key=lambda r: -r["total_ms"])
@@ -403,7 +404,7 @@ def cfg3_block(device, seeds=(0, 1, 2, 3, 4), reps=20):
     from ttdg_mgm_amd import ops, synth
     from ttdg_mgm_amd.GModule import MGM3_unsup
     sizes = (256,) * 8
-    fb, fw, its, solver_us, kern = [], [], [], [], {}
+    fb, fw, its, solver_us, pairs, kern = [], [], [], [], [], {}
     for seed in seeds:
         params, U = synth.mgm3_params(9000 + seed), synth.universe(9100 + seed)
         nodes, labels = synth.node_sets(9200 + seed, sizes, scale=0.1)
@@ -443,6 +444,7 @@ def cfg3_block(device, seeds=(0, 1, 2, 3, 4), reps=20):
             k["work"].append(r["algorithmic_work_per_launch"])
             if r["kernel"] == "gagm_kernel":
                 its.append(r["avg_iterations_per_launch"])
+                pairs.append(r.get("avg_executed_launch_pairs", 0))
                 solver_us.append(r["avg_launch_ms"] * 1e3)
     mean = lambda v: sum(v) / max(1, len(v))
     # what an event pair itself reads with nothing between its two records (the marker packets' own round trip): rocprofv3's kernel
@@ -459,9 +461,11 @@ def cfg3_block(device, seeds=(0, 1, 2, 3, 4), reps=20):
             "fwd_bwd_ms": mean(fb), "fwd_bwd_ms_per_seed": fb, "fwd_ms": mean(fw), "fwd_ms_per_seed": fw,
             "solver_us": mean(solver_us) if solver_us else None, "executed_iterations": mean(its) if its else None,
             "solver_us_per_iteration": (mean(solver_us) / mean(its)) if its and mean(its) else None,
-            "iterations_note": "executed_iterations = the stage machine's count (info[0..5]); it includes the iterations a Hungarian-stage cycle of period >= 3 lets the "
-                               "solver skip (the exact cycle shortcut jumps to the state iteration max_iter - 1 would land on), so on inputs that cycle - these seeds do - "
-                               "fewer iterations are launched than counted (rocprofv3: ~35 launched per solve)",
+            "launched_iterations": mean(pairs) if pairs else None,
+            "solver_us_per_launched_iteration": (mean(solver_us) / mean(pairs)) if pairs and mean(pairs) else None,
+            "iterations_note": "executed_iterations = the stage machine's count (info[0..5]): it includes the iterations a Hungarian-stage cycle of period >= 3 lets the "
+                               "solver skip (the exact cycle shortcut jumps to the state iteration max_iter - 1 would land on); launched_iterations = the (mul, projection) "
+                               "launch pairs that did work (info[22]) - the figure the per-iteration kernel time belongs to",
             "event_bracket_us": bracket,
             "kernels_note": "avg_us = live HIP-event bracket around the launch (includes event_bracket_us of marker round trip and the launch latency of a cold "
                             "stream); rocprofv3 kernel durations of the same block: profiles/r06_cfg3_block_rocprof_summary.txt",

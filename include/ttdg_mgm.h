@@ -170,7 +170,7 @@ int ttdg_mha_adjacency(const float* q, const float* k, int d, ttdg_graphs_t gr, 
  * info (int32[TTDG_GAGM_INFO_WORDS], device, zero-initialised by the caller): [0..5] iterations per stage, [6] total, [7] stages run,
  * [8] STATUS and nothing else (0 = ok; the cooperative multi-workgroup kernel: 1 = a grid barrier timed out, 2 = the stage
  * machine did not stop - U is then NaN); [12] Hungarian-stage LAPs solved with a uniqueness certificate, [13] LAPs that fell back to
- * the scipy-order solver (multi-workgroup solver), [21] narrow-range LAPs solved by the integer scipy-order solver; [14], [15] period and detection iteration of a Hungarian-stage cycle;
+ * the scipy-order solver (multi-workgroup solver), [21] narrow-range LAPs solved by the integer scipy-order solver; [14], [15] period and detection iteration of a Hungarian-stage cycle; [22] iterations the multi-workgroup solver executed (launch pairs that did work: [6] also counts the iterations a cycle jump skipped);
  * cfg.profile != 0: single-workgroup kernel [9..13] = cycle-counter ticks / 64 spent in B, S, V, projection, convergence;
  * multi-workgroup solver [16..20] = cycles / 1024 per phase (csrc/gagm_large.hip: gl_write_result).
  * ws: workspace of ttdg_gagm_workspace_bytes(M) bytes; its first 2*M*32 floats receive the

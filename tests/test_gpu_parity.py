@@ -1416,6 +1416,32 @@ def test_large_solver_one_cooperative_launch_equals_the_two_launch_form(dev, siz
         assert ia[8] == 0 and ib[8] == 0, (ia, ib)
         assert ia[:8] == ib[:8] and ia[12:16] == ib[12:16], (kw, ia, ib)
         assert torch.equal(Va, Vb) and torch.equal(U1a, U1b) and torch.equal(Ua, Ub_), kw
+        # [r6] info[22]: iterations EXECUTED (launch pairs that did work) - the count itself unless a Hungarian-stage cycle jump skipped the rest
+        assert ia[22] == ib[22] and 0 < ib[22] <= ib[6], (kw, ia, ib)
+        assert ib[22] == ib[6] or ib[14] >= 3, (kw, ib)
+
+
+def test_large_solver_launch_hint_does_not_touch_results(dev):
+    """[r6] The two-launch form sizes its first chunk of enqueued iterations from the iterations the PREVIOUS solve of the host thread
+    executed (csrc/gagm_large.hip: last_exec; follow-up chunks of 4, 8, 16, 32).  Whatever the hint - after a long solve, after a short
+    one, first solve of a fresh size - U, the first-iteration V and every info word are the same bits."""
+    from ttdg_mgm_amd import _lib, ops
+    probs = []
+    for sizes, seed, kw in (((256,) * 4, 640, dict()), ((130, 140), 641, dict(max_stages=1, max_iter=3)), ((200, 150, 129), 642, dict(max_iter=60)),
+                            ((256,) * 4, 640, dict(start_hungarian=True, max_stages=1, max_iter=12, no_cycle_skip=True))):
+        A, W, U0 = cases.gagm_inputs(sizes, seed)
+        probs.append((_pack(A, sizes).to(dev), W.to(dev), U0.to(dev).contiguous(), ops.graphs(sizes), list(sizes), kw))
+    ref = {}
+    for order in ((0, 1, 2, 3), (3, 2, 1, 0), (1, 1, 0, 2, 3, 0, 3, 1)):
+        for k in order:
+            ap, Wd, U0d, gr, sizes, kw = probs[k]
+            Ub, info, V0 = ops.gagm_solve(ap, Wd, U0d, gr, sizes, ops.gagm_cfg(variant=_lib.GAGM_FORCE_LARGE, **kw))
+            got = (Ub.cpu(), info.cpu().tolist(), V0.cpu().clone())
+            if k not in ref:
+                ref[k] = got
+                assert got[1][22] > 0
+            else:
+                assert torch.equal(got[0], ref[k][0]) and got[1] == ref[k][1] and torch.equal(got[2], ref[k][2]), (order, k, got[1], ref[k][1])
 
 
 def test_cfg3_scale_front_end_and_large_solver(dev):

@@ -34,13 +34,13 @@
 #define GL_HIST 256   /* states remembered per Hungarian stage (>= the reference's 200-iteration cap) */
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct GlCtl {   // control state at the START of an iteration; 16 words
+struct GlCtl {   // control state at the START of an iteration; 16 words, 16-byte aligned in the workspace (gl_carve)
   int32_t done, stage, hung, it, total;
   float tau;
   int32_t iters[6];
   int32_t jump;          // 1 + history index of the final state when the cycle shortcut fired, else 0
   int32_t cyc_p, cyc_i;  // period and detection iteration (info[14], info[15])
-  int32_t pad;
+  int32_t exec;          // iterations EXECUTED when `done` was set (= launches that did work; `total` also counts the iterations a cycle jump skipped)
 };
 
 struct GlWs {
@@ -111,11 +111,12 @@ static GlWs gl_carve(float* ws, const ttdg_graphs_t& gr) {
 // of a launch derives the same word; `store` (one workgroup per launch) persists it for the projection launch.
 __device__ __forceinline__ GlCtl gl_control(const GlWs& w, int G, const ttdg_gagm_cfg_t& cfg, int t, bool store) {
   __shared__ GlCtl s_ctl;
-  __shared__ int s_prev, s_i, s_ok;
+  __shared__ int s_prev, s_i, s_ok, s_scan;
+  __shared__ unsigned long long s_h;
   const int tid = threadIdx.x;
   if (tid == 0) {
     GlCtl c = w.ctl[t & 1];
-    s_prev = -1; s_ok = 1; s_i = 0;
+    s_prev = -1; s_ok = 1; s_i = 0; s_scan = 0;
     if (t > 0 && !c.done) {
       float s1 = 0.f, s2 = 0.f;
       for (int g = 0; g < G; ++g) { s1 += w.dn[2 * g]; s2 += w.dn[2 * g + 1]; }
@@ -129,17 +130,28 @@ __device__ __forceinline__ GlCtl gl_control(const GlWs& w, int G, const ttdg_gag
         else if (cfg.max_stages > 0 && c.stage >= cfg.max_stages) c.done = 1;
         else if (c.tau > cfg.min_tau) c.tau *= cfg.gamma;                      // :377-379
         else c.hung = 1;                                                       // :382-383
+        if (c.done) c.exec = t;
       } else if (c.hung && !cfg.no_cycle_skip && i < GL_HIST) {
         unsigned long long h = 0ull;
         for (int g = 0; g < G; ++g) h ^= w.hg[g];
         if (store) w.hhash[i] = h;
-        for (int k = i - 1; k >= 0; --k)
-          if (w.hhash[k] == h) { s_prev = k; s_i = i; break; }                  // most recent earlier state with this hash
+        s_h = h; s_i = i; s_scan = 1;
       }
     }
     s_ctl = c;
   }
   __syncthreads();
+  if (s_scan) {
+    // most recent earlier state with this hash.  [r6] every thread compares its share of the history (rounds 2-5: thread 0 walked it
+    // backwards, one dependent load per remembered state - the mul launch grew by 0.1 us per Hungarian-stage iteration, 13.8 -> 16.1 us
+    // over the 22 of a cfg-3 solve); same answer: the largest matching index
+    const int i = s_i;
+    const unsigned long long h = s_h;
+    int best = -1;
+    for (int k = tid; k < i; k += blockDim.x) if (w.hhash[k] == h) best = k;     // ascending per thread: the last hit is its largest
+    if (best >= 0) atomicMax(&s_prev, best);
+    __syncthreads();
+  }
   if (s_prev >= 0) {   // exact check of the candidate (a hash collision must not jump), all threads
     const unsigned char* ha = w.hist + (size_t)s_prev * w.M;
     const unsigned char* hb = w.hist + (size_t)s_i * w.M;
@@ -154,7 +166,7 @@ __device__ __forceinline__ GlCtl gl_control(const GlWs& w, int G, const ttdg_gag
         c.cyc_p = p; c.cyc_i = i;
         c.total += R;
         if (c.stage < 6) c.iters[c.stage] = cfg.max_iter;
-        ++c.stage; c.it = 0; c.done = 1;
+        ++c.stage; c.it = 0; c.done = 1; c.exec = t;
         s_ctl = c;
       }
     }
@@ -176,7 +188,7 @@ __global__ __launch_bounds__(256) void gagm_large_init_kernel(const float* __res
     GlCtl c;
     c.done = 0; c.stage = 0; c.hung = cfg.start_hungarian != 0; c.it = 0; c.total = 0; c.tau = cfg.tau0;
     for (int k = 0; k < 6; ++k) c.iters[k] = 0;
-    c.jump = 0; c.cyc_p = 0; c.cyc_i = 0; c.pad = 0;
+    c.jump = 0; c.cyc_p = 0; c.cyc_i = 0; c.exec = 0;
     w.ctl[0] = c;
     w.ctl[1] = c;
     for (int k = 0; k < 8; ++k) { w.lapstat[k] = 0; w.prof[k] = 0ull; w.bar[k] = 0u; }
@@ -185,8 +197,7 @@ __global__ __launch_bounds__(256) void gagm_large_init_kernel(const float* __res
 
 // [r4] every load is UNCONDITIONAL (clamped address, the zero selected after the wait): a load under a condition is waited for at
 // the join, which serialised the 32 loads of a chunk; out-of-range rows / columns read a valid neighbour and are zeroed
-__device__ __forceinline__ void gl_load_chunk(const float* __restrict__ Asrc, int lda, int nrows, const float* __restrict__ Ub,
-                                              int k0, int kend, int li, int kh, float (&ra)[16], float (&rb)[16]) {
+__device__ __forceinline__ void gl_load_chunk_a(const float* __restrict__ Asrc, int lda, int nrows, int k0, int kend, int li, int kh, float (&ra)[16]) {
   const int kl = max(kend - 1, 0), k = k0 + li, kc = min(k, kl);
   const int rmax = max(nrows - 1, 0);
 #pragma unroll
@@ -194,11 +205,19 @@ __device__ __forceinline__ void gl_load_chunk(const float* __restrict__ Asrc, in
     const int row = kh + 2 * j;
     ra[j] = Asrc[(size_t)min(row, rmax) * lda + kc];
   }
+}
+__device__ __forceinline__ void gl_load_chunk_u(const float* __restrict__ Ub, int k0, int kend, int li, int kh, float (&rb)[16]) {
+  const int kl = max(kend - 1, 0);
 #pragma unroll
   for (int s = 0; s < 16; ++s) {        // MFMA B operand: U[k][col], two k per step
     const int kk = k0 + 2 * s + kh;
     rb[s] = Ub[(size_t)min(kk, kl) * NU + li];
   }
+}
+__device__ __forceinline__ void gl_load_chunk(const float* __restrict__ Asrc, int lda, int nrows, const float* __restrict__ Ub,
+                                              int k0, int kend, int li, int kh, float (&ra)[16], float (&rb)[16]) {
+  gl_load_chunk_a(Asrc, lda, nrows, k0, kend, li, kh, ra);
+  gl_load_chunk_u(Ub, k0, kend, li, kh, rb);
 }
 // the zeros of a chunk, applied where its registers are consumed (not behind the loads: that would wait for them at once)
 __device__ __forceinline__ void gl_mask_chunk(int nrows, int k0, int kend, int li, int kh, float (&ra)[16], float (&rb)[16]) {
@@ -213,14 +232,17 @@ __device__ __forceinline__ void gl_mask_chunk(int nrows, int k0, int kend, int l
 // inside the workgroup (the two-launch kernel has one, the persistent kernel PT / 256), `tid` = thread index inside the
 // sub-group, `active` = this sub-group has an item (an idle one still meets the workgroup barriers).  smem: GL_MUL_LDS floats.
 #define GL_MUL_LDS (4 * GL_TILE * 33 + 2 * GL_TILE * 33)
+// [r6] `ctlfn()` yields the control word and may synchronise the workgroup (the two-launch kernel evaluates the stage machine there: ~4 us of
+// dependent L2 round trips on a cold cache); it is called AFTER the first chunk's 16 loads of W / A per lane are in flight - they depend on
+// the item only, not on the iteration - so the stage machine runs under their latency.  A `done` word returns (two-launch kernel only).
+template <class CtlFn>
 __device__ __forceinline__ void gl_mul_item(const float* __restrict__ Apack, const float* __restrict__ W, const ttdg_graphs_t& gr,
-                                            const GlWs& w, const GlCtl& ctl, int item_tile, int z, bool active, int tid, float* smem) {
+                                            const GlWs& w, CtlFn&& ctlfn, int item_tile, int z, bool active, int tid, float* smem) {
   float* s_a = smem;                                  // per-wavefront A tiles, then the 4 accumulator planes
   float* s_bt = smem + 4 * GL_TILE * 33;
   float* s_ut = s_bt + GL_TILE * 33;
   const int wave = tid >> 6, lane = tid & 63, M = w.M;
   const size_t MU = (size_t)M * NU;
-  const float* U = w.ring + (size_t)(ctl.total % 3) * MU;
 
   int tile = active ? item_tile : 0, g = 0;
   size_t aoff = 0;
@@ -233,20 +255,26 @@ __device__ __forceinline__ void gl_mul_item(const float* __restrict__ Apack, con
   const int o = gr.off[g], n = gr.off[g + 1] - o;
   const int row0 = o + tile * GL_TILE, nrows = active ? min(GL_TILE, o + n - row0) : 0;
   const bool wpart = z < w.ks;
-  const float* Asrc; const float* Ub;
+  const float* Asrc;
   int lda, kbeg, kend;
-  if (wpart) { Asrc = W + (size_t)row0 * M; lda = M; kbeg = z * w.Kc; kend = min(M, kbeg + w.Kc); Ub = U; }
-  else       { Asrc = Apack + aoff + (size_t)tile * GL_TILE * n; lda = n; kbeg = 0; kend = n; Ub = U + (size_t)o * NU; }
+  if (wpart) { Asrc = W + (size_t)row0 * M; lda = M; kbeg = z * w.Kc; kend = min(M, kbeg + w.Kc); }
+  else       { Asrc = Apack + aoff + (size_t)tile * GL_TILE * n; lda = n; kbeg = 0; kend = n; }
   if (!active) kend = kbeg;
+  const int li = lane & 31, kh = lane >> 5;
+  float ra[16], rb[16], cb[16];
+  int k0 = kbeg + wave * 32;
+  gl_load_chunk_a(Asrc, lda, nrows, k0, kend, li, kh, ra);
+
+  const GlCtl ctl = ctlfn();
+  if (ctl.done) return;
+  const float* U = w.ring + (size_t)(ctl.total % 3) * MU;
+  const float* Ub = wpart ? U : U + (size_t)o * NU;
+  gl_load_chunk_u(Ub, k0, kend, li, kh, rb);
 
   float* sa = s_a + wave * (GL_TILE * 33);
-  const int li = lane & 31, kh = lane >> 5;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  float ra[16], rb[16], cb[16];
-  int k0 = kbeg + wave * 32;
-  gl_load_chunk(Asrc, lda, nrows, Ub, k0, kend, li, kh, ra, rb);
   for (; k0 < kend; k0 += 128) {
     gl_mask_chunk(nrows, k0, kend, li, kh, ra, rb);
 #pragma unroll
@@ -297,9 +325,8 @@ __device__ __forceinline__ void gl_mul_item(const float* __restrict__ Apack, con
 __global__ __launch_bounds__(256) void gagm_large_mul_kernel(const float* __restrict__ Apack, const float* __restrict__ W,
                                                              ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg, GlWs w, int t) {
   __shared__ __attribute__((aligned(16))) float s_mul[GL_MUL_LDS];
-  const GlCtl ctl = gl_control(w, gr.G, cfg, t, blockIdx.x == 0 && blockIdx.y == 0);
-  if (ctl.done) return;
-  gl_mul_item(Apack, W, gr, w, ctl, blockIdx.x, blockIdx.y, true, threadIdx.x, s_mul);
+  gl_mul_item(Apack, W, gr, w, [&]() { return gl_control(w, gr.G, cfg, t, blockIdx.x == 0 && blockIdx.y == 0); }, blockIdx.x, blockIdx.y, true,
+              threadIdx.x, s_mul);
 }
 
 #define GL_PTHREADS 1024
@@ -646,16 +673,21 @@ __device__ __forceinline__ void gl_finish_projection(const ttdg_graphs_t& gr, co
 // PT threads: 512 when every graph has <= 512 nodes (2 wavefronts per SIMD: a 256-VGPR budget - with 1024 threads the
 // 128-VGPR cap made the register-resident Sinkhorn column + its 33 partial lines spill into scratch inside the sweep
 // loop), 1024 for graphs of 513..768 nodes (one column per thread).
+// [r6] `ctl_src` != nullptr (two-launch kernel): the control word is still in global memory - thread 0 requests it first, the operand loads
+// of the S and V phases (which depend on the graph only, not on the iteration) follow at once, and the word reaches `s_c` (LDS) in front of
+// the S phase's barrier: the stage machine's round trip hides under the operands'.  A `done` word returns after that barrier.
 template <int PT>
-__device__ __forceinline__ void gl_project_graph(const ttdg_graphs_t& gr, const ttdg_gagm_cfg_t& cfg, const GlWs& w, const GlCtl& s_c,
-                                                 const int g, float* gl_smem) {
+__device__ __forceinline__ void gl_project_graph(const ttdg_graphs_t& gr, const ttdg_gagm_cfg_t& cfg, const GlWs& w, GlCtl& s_c,
+                                                 const int g, float* gl_smem, const GlCtl* ctl_src = nullptr) {
   __shared__ __attribute__((aligned(16))) float s_S[NU * NU];
   __shared__ __attribute__((aligned(16))) float s_brow[(PT / 64) * 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, G = gr.G, M = w.M;
   const size_t MU = (size_t)M * NU;
-  const int total = s_c.total;
-  const bool hung = s_c.hung != 0;
-  const float tau = s_c.tau;
+  int4 early[4];                          // the 64-byte word as four 16-byte registers (a GlCtl local would live in scratch)
+  if (ctl_src && tid == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) early[k] = reinterpret_cast<const int4*>(ctl_src)[k];
+  }
   const int o = gr.off[g], n = gr.off[g + 1] - o;
   long long tph = cfg.profile ? (long long)__builtin_readcyclecounter() : 0;      // phase clock (thread 0 adds to w.prof)
 #define GL_PHASE(k)                                                                       \
@@ -666,10 +698,6 @@ __device__ __forceinline__ void gl_project_graph(const ttdg_graphs_t& gr, const 
     if ((k) == 4) atomicMax(&w.prof[7], (unsigned long long)(now - tph));                 \
     tph = now;                                                                            \
   }
-  const float* Ucur = w.ring + (size_t)(total % 3) * MU + (size_t)o * NU;
-  float* Unew = w.ring + (size_t)((total + 1) % 3) * MU + (size_t)o * NU;
-  const float* Uprev = w.ring + (size_t)((total + 2) % 3) * MU + (size_t)o * NU;
-
   const int li = lane & 31, kh = lane >> 5;
   constexpr int PW = PT / 64;
   constexpr int CHUNK = 2 * PW * 8;          // rows per pass of the V loop (256): a wavefront takes two rows at a time
@@ -716,7 +744,18 @@ __device__ __forceinline__ void gl_project_graph(const ttdg_graphs_t& gr, const 
       s_S[tid + x * PT] = (((acc[x][0] + acc[x][1]) + (acc[x][2] + acc[x][3])) + ((acc[x][4] + acc[x][5]) + (acc[x][6] + acc[x][7]))) +
                           (((acc[x][8] + acc[x][9]) + (acc[x][10] + acc[x][11])) + ((acc[x][12] + acc[x][13]) + (acc[x][14] + acc[x][15])));
   }
+  if (ctl_src && tid == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) reinterpret_cast<int4*>(&s_c)[k] = early[k];
+  }
   __syncthreads();
+  if (s_c.done) return;
+  const int total = s_c.total;
+  const bool hung = s_c.hung != 0;
+  const float tau = s_c.tau;
+  const float* Ucur = w.ring + (size_t)(total % 3) * MU + (size_t)o * NU;
+  float* Unew = w.ring + (size_t)((total + 1) % 3) * MU + (size_t)o * NU;
+  const float* Uprev = w.ring + (size_t)((total + 2) % 3) * MU + (size_t)o * NU;
   GL_PHASE(0)
   // V_g = (2q B_g S + W U) / G: B rows broadcast from LDS, S column in registers.  V_g goes to the workspace (trace /
   // next launch) AND to an LDS tile with row stride 33 that both projectors read (no global round trip in between)
@@ -855,11 +894,8 @@ __device__ __forceinline__ void gl_project_graph(const ttdg_graphs_t& gr, const 
 template <int PT>
 __global__ __launch_bounds__(PT) void gagm_large_project_kernel(ttdg_graphs_t gr, ttdg_gagm_cfg_t cfg, GlWs w, int t) {
   extern __shared__ __attribute__((aligned(16))) float gl_smem[];
-  __shared__ GlCtl s_c;
-  if (threadIdx.x == 0) s_c = w.ctl[(t + 1) & 1];
-  __syncthreads();
-  if (s_c.done) return;
-  gl_project_graph<PT>(gr, cfg, w, s_c, blockIdx.x, gl_smem);
+  __shared__ __attribute__((aligned(16))) GlCtl s_c;
+  gl_project_graph<PT>(gr, cfg, w, s_c, blockIdx.x, gl_smem, &w.ctl[(t + 1) & 1]);
 }
 
 // control word after `t` enqueued iterations -> w.res (read by the finish kernel) and, when the host gave one, its page-locked flag
@@ -871,6 +907,7 @@ __global__ __launch_bounds__(256) void gagm_large_peek_kernel(ttdg_graphs_t gr, 
     for (int k = 0; k < 16; ++k) w.res[k] = p[k];
     if (hostflag) {
       hostflag[1] = c.total;
+      hostflag[2] = c.exec;
       __hip_atomic_store(&hostflag[0], c.done ? 1 : 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
@@ -891,6 +928,7 @@ __device__ __forceinline__ void gl_write_result(const GlWs& w, const GlCtl* c, f
     for (int k = 0; k < 6; ++k) info[k] = c->iters[k];
     info[6] = c->total; info[7] = c->stage;
     info[14] = c->cyc_p; info[15] = c->cyc_i;
+    info[22] = c->exec;                                    // iterations executed (launch pairs that did work)
     info[12] = w.lapstat[0]; info[13] = w.lapstat[1];      // Hungarian stage: certified workgroup LAPs / scipy-order fallbacks
     info[21] = w.lapstat[5];                               // ... / narrow-range blocks solved by the integer scipy-order solver
     // info[8] is the STATUS word and nothing else (written by the cooperative kernel on a barrier failure, 0 otherwise - the caller
@@ -977,7 +1015,7 @@ __global__ __launch_bounds__(PT) void gagm_large_persistent_kernel(const float* 
     for (int base = blockIdx.x * NSUB; base < nitems; base += (int)nb * NSUB) {
       const int item = base + sub;
       const bool active = item < nitems;
-      gl_mul_item(Apack, W, gr, w, s_c, active ? item % w.ntiles : 0, active ? item / w.ntiles : 0, active, stid, gl_smem + sub * GL_MUL_LDS);
+      gl_mul_item(Apack, W, gr, w, [&]() -> GlCtl { return s_c; }, active ? item % w.ntiles : 0, active ? item / w.ntiles : 0, active, stid, gl_smem + sub * GL_MUL_LDS);
       __syncthreads();
     }
     arrivals += nb;
@@ -1043,15 +1081,17 @@ int ttdg_gagm_large_solve(const float* Apack, const float* W, const float* U0, t
       }
     }
   }
-  // Iterations are enqueued in chunks; a converged solve turns the rest of its chunk into no-op launches (~5 us per iteration), and
-  // every chunk ends in ONE host read of {done, total}.  [r6] The read costs what ~5 no-op iterations cost, so overshooting is the
-  // cheap side: the first chunk is sized from the previous solve of this thread (its iteration count + 2, between 8 and 40 - a steady
-  // stream of similar batches then pays one read per solve; rounds 4-5: 4-8-16-32, three reads and eight no-op iterations for a
-  // 20-iteration solve), the following ones are 16, then 32.  The flag lives in page-locked host memory the peek kernel writes
-  // directly (rounds 4-5: a 64-byte device-to-host copy into pageable memory per chunk).  The hint and the flag buffer are the
-  // library's only state besides the error string: per host thread, never read by a kernel, results do not depend on them.
+  // Iterations are enqueued in chunks; a converged solve turns the rest of its chunk into no-op launches (6 us each, 12 us per iteration:
+  // a dependent kernel's launch latency), and every chunk ends in ONE host read of {done, total, executed} (~18 us of idle device).
+  // [r6] The first chunk is sized from the previous solve of this thread: the iterations it EXECUTED, + 1 (the peek kernel evaluates the
+  // stage machine itself, so exactly `executed` launch pairs already suffice; one spare costs less than a read).  Until this round the
+  // hint was the reference's iteration COUNT + 2, which a Hungarian-stage cycle jump inflates to ~200: two of the five cfg-3 bench inputs
+  // launched 40 pairs for 28 and 35 executed (profiles/r06_cfg3_launches.txt).  A solve that needs more continues in chunks of 4, 8, 16,
+  // 32 (rounds 4-5 started every solve that way: three reads for a 20-iteration solve).  The flag lives in page-locked host memory the
+  // peek kernel writes directly.  The hint and the flag buffer are the library's only state besides the error string: per host thread,
+  // never read by a kernel, results do not depend on them.
   static thread_local int32_t* hflag = nullptr;
-  static thread_local int last_total = 0;
+  static thread_local int last_exec = 0;
   if (!hflag) {
     void* p = nullptr;
     if (hipHostMalloc(&p, 64, hipHostMallocMapped) == hipSuccess) hflag = (int32_t*)p;
@@ -1059,8 +1099,8 @@ int ttdg_gagm_large_solve(const float* Apack, const float* W, const float* U0, t
   }
   int32_t* dflag = nullptr;
   if (hflag && hipHostGetDevicePointer((void**)&dflag, hflag, 0) != hipSuccess) { (void)hipGetLastError(); dflag = nullptr; }
-  int t = 0, chunk = last_total + 2;
-  chunk = chunk < 8 ? 8 : (chunk > 40 ? 40 : chunk);
+  int t = 0, chunk = last_exec + 1;
+  chunk = chunk < 8 ? 8 : (chunk > 64 ? 64 : chunk);
   int32_t h[16];
   for (int round = 0;; ++round) {
     for (int k = 0; k < chunk; ++k, ++t) {
@@ -1075,14 +1115,15 @@ int ttdg_gagm_large_solve(const float* Apack, const float* W, const float* U0, t
       TTDG_HIP(hipStreamSynchronize(st));     // the one convergence read per chunk (the reference reads two norms per iteration)
       h[0] = __atomic_load_n(&hflag[0], __ATOMIC_ACQUIRE);
       h[4] = hflag[1];
+      h[15] = hflag[2];
       TTDG_REQUIRE(h[0] >= 0, "gagm: the convergence flag was not written");
     } else {
       TTDG_HIP(hipMemcpyAsync(h, w.res, sizeof(h), hipMemcpyDeviceToHost, st));
       TTDG_HIP(hipStreamSynchronize(st));
     }
-    if (h[0]) { last_total = h[4]; break; }
+    if (h[0]) { last_exec = h[15]; break; }
     TTDG_REQUIRE(t < cap, "gagm: the stage machine did not terminate");
-    chunk = round == 0 ? 16 : 32;
+    chunk = round >= 3 ? 32 : 4 << round;
   }
   hipLaunchKernelGGL(gagm_large_finish_kernel, dim3(cblocks), dim3(256), 0, st, w, U, info, (int)cfg.profile);
   return ttdg_launch_status("gagm_large_finish");
