@@ -82,6 +82,7 @@ def parse(argv=None):
     ap.add_argument("--graphs", action="store_true", help="A/B: hipGraph replay of the backbone's no-grad forward in the Dice pass (modeling/graphed.py; default: eager - measured equal)")
     ap.add_argument("--timer-every", type=int, default=7, help="HIP-event pairs around every N-th launch of the kernels launched dozens of times per batch "
                     "(ops.KERNEL_TIMER_SAMPLED; 1 = every launch, the round 1-5 protocol, which costs ~4 %% of the timed region)")
+    ap.add_argument("--vendor-rpn-heads", action="store_true", help="A/B: the RPN's two 1 x 1 heads as vendor convolutions behind a bias + ReLU pass (round 5) instead of one streaming product per level")
     ap.add_argument("--own-pointwise-backward", action="store_true", help="A/B: dX / dW of the 1 x 1 convolutions on the streaming product's backward layouts instead of MIOpen")
     ap.add_argument("--cfg3-only", action="store_true", help="run only the cfg-3 operator-level block and print it (the command rocprofv3 profiles for profiles/rNN_cfg3_block_*)")
     ap.add_argument("--no-cfg3", action="store_true", help="skip the cfg-3 operator-level block and the whole-step FLOP count")
@@ -720,6 +721,8 @@ def gpu_main(args, rank, world, local):
         _bb.OWN_POINTWISE = False
     if args.own_pointwise_backward:
         _ops.POINTWISE_BACKWARD = "own"
+    if args.vendor_rpn_heads:
+        _det.FUSED_RPN_HEADS = False
     _ops.KERNEL_TIMER_EVERY = max(1, args.timer_every)
     assert _det._backend is _ops, "the GPU legs must run on the HIP operators (detector._backend was re-pointed)"
     if args.gagm_threads or args.roi_align_mode != 3:

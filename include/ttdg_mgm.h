@@ -41,7 +41,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define TTDG_VERSION 110 /* 0.1.1: ttdg_gagm_solve writes TTDG_GAGM_INFO_WORDS = 24 int32 into `info` (0.1.0: 16, profile clocks at [8..11]);
+#define TTDG_VERSION 111 /* 0.1.2: ttdg_mm_t gained C2 / ldc2 / nsplit at its end (callers zero-initialise the struct and rebuild); 0.1.1: ttdg_gagm_solve writes TTDG_GAGM_INFO_WORDS = 24 int32 into `info` (0.1.0: 16, profile clocks at [8..11]);
                           * a caller built against 0.1.0 that passes a 16-word buffer must be rebuilt (INTEGRATION.md "ABI changes");
                           * new entry points ttdg_mm_f32 / ttdg_mm_workspace_bytes */
 #define TTDG_GAGM_INFO_WORDS 24 /* int32 words of the `info` buffer of ttdg_gagm_solve */
@@ -394,6 +394,11 @@ typedef struct {
   int64_t lda2, ldb2;
   int32_t K2;
   int32_t a2_stride, a2_h, a2_w;
+  /* [0.1.2] optional split output (C2 != NULL): columns [nsplit, N) are written to C2[m * ldc2 + (n - nsplit)] instead of C - two heads
+   * that read one input (the RPN's objectness and anchor-delta filters) in one pass.  nsplit, ldc2 multiples of 4; no split reduction. */
+  float* C2;
+  int64_t ldc2;
+  int32_t nsplit;
 } ttdg_mm_t;
 size_t ttdg_mm_workspace_bytes(int M, int N, int kslices);
 int ttdg_mm_f32(const ttdg_mm_t* desc, ttdg_stream_t stream);

@@ -49,7 +49,7 @@ def test_ctypes_table_matches_header():
 def test_version_and_error_string(lib):
     lib.ttdg_version.restype = ctypes.c_int
     lib.ttdg_last_error.restype = ctypes.c_char_p
-    assert lib.ttdg_version() == 110
+    assert lib.ttdg_version() == 111
     assert isinstance(lib.ttdg_last_error(), bytes)
 
 

@@ -3,6 +3,7 @@ against the CPU oracle and the committed golden vectors on the same seeded input
 
 Bars (BASELINE.json north_star / SURVEY.md §8d): <=1e-4 fp32 on Wds, V, loss and gradients; identical
 permutation matrices; bit-exact for integer/index work (sampler, LAP)."""
+import copy
 import numpy as np
 import pytest
 import torch
@@ -1942,6 +1943,62 @@ def test_channels_last_layout_is_the_same_arithmetic(dev):
         mv = res[False][2][n]                                                                   # first SGD step: -lr * (g + wd p)
         assert float((res[True][2][n] - mv).norm()) <= 2e-2 * max(1e-30, float(mv.norm())), n
     print("channels-last vs NCHW trunk: worst relative gradient difference %.2e (%s)" % worst)
+
+
+@pytest.mark.parametrize("quant", [None, 0.25])
+def test_rpn_heads_as_one_product_per_level(dev, quant):
+    """[r6] RPNHead's packed path (modeling/detector.py: FUSED_RPN_HEADS): the two 1 x 1 heads of a level as ONE streaming product with split
+    output, the 3 x 3 filter's bias + ReLU applied at the operand fetch, objectness padded 3 -> 4 anchors (pad logit -inf), deltas 12 -> 16.
+      (a) head outputs against the float64 statement conv3x3 -> +bias -> ReLU -> the two 1 x 1 filters, next to the vendor path's distance from it;
+      (b) the pad columns: logit -inf, deltas exactly 0;
+      (c) the selection (ops.rpn_select with A = 4, padded anchors, k from the three real anchors) on the packed outputs returns, bit for bit,
+          what it returns on the three real channels copied out (A = 3) - also with quantised logits (ties across the k-th rank)."""
+    from ttdg_mgm_amd import ops
+    from ttdg_mgm_amd.modeling import detector as det
+    torch.manual_seed(5)
+    rpn = det.PseudoLabRPN().to(dev).eval()
+    head = rpn.rpn_head
+    with torch.no_grad():
+        for m in (head.conv, head.objectness_logits, head.anchor_deltas):
+            m.weight.normal_(0, 0.05)
+            m.bias.normal_(0, 0.3)
+    B = 2
+    shapes = [(40, 56), (20, 28), (10, 14), (5, 7), (3, 4)]
+    feats = [torch.randn(B, 256, h, w, device=dev).contiguous(memory_format=torch.channels_last) for h, w in shapes]
+    with torch.no_grad():
+        assert det.FUSED_RPN_HEADS
+        lg_p, dl_p = head(feats)
+        det.FUSED_RPN_HEADS = False
+        try:
+            lg_v, dl_v = head(feats)
+        finally:
+            det.FUSED_RPN_HEADS = True
+    h64 = copy.deepcopy(head).double()
+    for x, lp, dp, lv, dv in zip(feats, lg_p, dl_p, lg_v, dl_v):
+        assert lp.shape[1] == 4 and dp.shape[1] == 16 and lv.shape[1] == 3 and dv.shape[1] == 12
+        assert lp.is_contiguous(memory_format=torch.channels_last) and dp.is_contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            t = torch.relu(h64.conv(x.double()))
+            l64, d64 = h64.objectness_logits(t), h64.anchor_deltas(t)
+        derived_gate("rpn heads, objectness %s" % (tuple(x.shape[-2:]),), lp[:, :3], lv, l64, quiet=True)
+        derived_gate("rpn heads, deltas %s" % (tuple(x.shape[-2:]),), dp[:, :12], dv, d64, quiet=True)
+        assert bool(torch.isneginf(lp[:, 3]).all()) and bool((dp[:, 12:] == 0).all())
+    if quant is not None:            # ties across the k-th rank: quantise the packed logits in place (pad stays -inf)
+        for lp in lg_p:
+            lp[:, :3] = (lp[:, :3] / quant).round() * quant
+    pre = 600
+    ks = [min(pre, 3 * h * w) for h, w in shapes]
+    K = sum(ks)
+    st = ops.image_sizes_tensor([(160, 224)] * B, dev)
+    a3 = rpn._anchors(shapes, dev)
+    a4 = rpn._anchors(shapes, dev, pad_to=4)
+    b4, s4 = torch.full((B, K, 4), -7.0, device=dev), torch.full((B, K), -7.0, device=dev)
+    ops.rpn_select(lg_p, dl_p, a4, ks, st, b4, s4)
+    CL = torch.channels_last
+    b3, s3 = torch.full((B, K, 4), -7.0, device=dev), torch.full((B, K), -7.0, device=dev)
+    ops.rpn_select([t[:, :3].contiguous(memory_format=CL) for t in lg_p], [t[:, :12].contiguous(memory_format=CL) for t in dl_p], a3, ks, st, b3, s3)
+    assert torch.equal(s4, s3) and torch.equal(b4, b3)
+    assert bool((s4 > float("-inf")).any())
 
 
 def test_fused_bias_epilogues_of_fpn_rpn_head_and_mask_head(dev):

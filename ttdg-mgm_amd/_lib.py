@@ -77,7 +77,8 @@ class Mm(C.Structure):
                 ("res_up", C.c_int32), ("res_h", C.c_int32), ("res_w", C.c_int32),
                 ("relu", C.c_int32), ("prelu", C.c_int32), ("kslices", C.c_int32), ("tile", C.c_int32),
                 ("A2", C.c_void_p), ("B2", C.c_void_p), ("lda2", C.c_int64), ("ldb2", C.c_int64), ("K2", C.c_int32),
-                ("a2_stride", C.c_int32), ("a2_h", C.c_int32), ("a2_w", C.c_int32)]
+                ("a2_stride", C.c_int32), ("a2_h", C.c_int32), ("a2_w", C.c_int32),
+                ("C2", C.c_void_p), ("ldc2", C.c_int64), ("nsplit", C.c_int32)]
 
 
 GEMM_GROUP_MAX = 8

@@ -58,6 +58,10 @@ struct mm_args {
   int K2;
   int a2_map, a2_howo, a2_wo, a2_hw, a2_w, a2_s;
   int dbg;                                   // ablation (tile field bits 8-9; WRONG RESULTS): 1 = only the first slab is loaded, 2 = no MFMA
+  // split output (C2 != NULL): columns [nsplit, N) go to C2[m * ldc2 + (n - nsplit)] - two heads that read one input in one pass
+  float* C2;
+  int64_t ldc2;
+  int nsplit;
 };
 
 __device__ __forceinline__ void mm_glds16(const float* g, float* lds_wave_base) {
@@ -343,7 +347,9 @@ __device__ __forceinline__ void mm_body(const mm_args& p, int Lraw, int T, int z
           v += *reinterpret_cast<const f32x4*>(p.res + rr * p.ldres + n0 + cq);
         }
         if (p.relu) v.x = fmaxf(v.x, 0.f), v.y = fmaxf(v.y, 0.f), v.z = fmaxf(v.z, 0.f), v.w = fmaxf(v.w, 0.f);
-        *reinterpret_cast<f32x4*>(p.C + (int64_t)m * p.ldc + n0 + cq) = v;
+        float* dst = p.C + (int64_t)m * p.ldc + n0 + cq;
+        if (p.C2 && n0 + cq >= p.nsplit) dst = p.C2 + (int64_t)m * p.ldc2 + (n0 + cq - p.nsplit);
+        *reinterpret_cast<f32x4*>(dst) = v;
       }
     }
   }
@@ -489,6 +495,11 @@ static int mm_prepare(const ttdg_mm_t* d, mm_args& a, int& ks_out, int& empty) {
       a.a2_wo = wo, a.a2_howo = ho * wo;
     }
   }
+  a.C2 = d->C2, a.ldc2 = d->ldc2, a.nsplit = d->C2 ? d->nsplit : 0;
+  if (d->C2) {
+    TTDG_REQUIRE(d->nsplit > 0 && d->nsplit < d->N && (d->nsplit & 3) == 0 && (d->ldc2 & 3) == 0 && ((uintptr_t)d->C2 & 15) == 0 && d->kslices <= 1,
+                 "mm: split output needs 0 < nsplit < N, multiples of 4, an aligned C2 and no split reduction");
+  }
   const int ks = d->kslices > 1 ? d->kslices : 0;
   a.kslices = ks;
   a.kc = ks ? (((d->K + ks - 1) / ks) + MM_BK - 1) / MM_BK * MM_BK : 0;
@@ -538,7 +549,7 @@ extern "C" int ttdg_mm_f32_grouped(const ttdg_mm_t* descs, int n, ttdg_stream_t 
     int ks = 0, empty = 0;
     if (int e = mm_prepare(d, a, ks, empty)) return e;
     if (empty) continue;
-    TTDG_REQUIRE(!d->pbias && !d->A2 && !d->res_up && d->a_stride <= 1 && (d->tile & 255) == 0, "mm_grouped: plain products only (no input activation, second segment, row maps, forced tile)");
+    TTDG_REQUIRE(!d->pbias && !d->A2 && !d->C2 && !d->res_up && d->a_stride <= 1 && (d->tile & 255) == 0, "mm_grouped: plain products only (no input activation, second segment, split output, row maps, forced tile)");
     const int c = d->a_layout * 2 + d->b_layout, lk = (ks ? a.kc : d->K) >= 1024;
     TTDG_REQUIRE((cls < 0 || cls == c) && (longk < 0 || longk == lk), "mm_grouped: the products of a group share their operand layouts and reduction class");
     cls = c, longk = lk;

@@ -29,6 +29,9 @@ def apply_deltas(deltas, boxes, weights):
     return torch.stack((pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph), dim=-1).reshape(deltas.shape)
 
 
+FUSED_RPN_HEADS = True      # the RPN's two 1 x 1 heads as one streaming product per level (A/B: False = two vendor convolutions behind a bias + ReLU pass)
+
+
 class RPNHead(nn.Module):
     def __init__(self, c=256, num_anchors=3):
         super().__init__()
@@ -39,10 +42,49 @@ class RPNHead(nn.Module):
             nn.init.normal_(l.weight, std=0.01)
             nn.init.constant_(l.bias, 0)
 
+    def _packed_heads(self):
+        """The two 1 x 1 head filters as ONE (A' + 4 A', C) matrix for the streaming product, A' = the anchors per location padded to a multiple
+        of four (3 -> 4): rows [objectness 0 .. A-1, pad, deltas 0 .. 4A-1, pad x 4]; a pad objectness column has weight 0 and bias -inf (never
+        selected: the selection takes k <= A H W candidates), the pad deltas are zero.  Cached until a head parameter moves."""
+        ps = (self.objectness_logits.weight, self.objectness_logits.bias, self.anchor_deltas.weight, self.anchor_deltas.bias)
+        key = tuple((p._version, p.data_ptr()) for p in ps)
+        c = self.__dict__.get("_packed")
+        if c is None or c[0] != key:
+            A, cin = ps[0].shape[0], ps[0].shape[1]
+            Ap = (A + 3) // 4 * 4
+            with torch.no_grad():
+                w = torch.zeros(Ap + 4 * Ap, cin, device=ps[0].device, dtype=torch.float32)
+                b = torch.zeros(Ap + 4 * Ap, device=ps[0].device, dtype=torch.float32)
+                w[:A], w[Ap:Ap + 4 * A] = ps[0].view(A, cin), ps[2].view(4 * A, cin)
+                b[:A], b[Ap:Ap + 4 * A] = ps[1], ps[3]
+                b[A:Ap] = float("-inf")
+            c = self.__dict__["_packed"] = (key, w, b, Ap)
+        return c[1], c[2], c[3]
+
     def forward(self, feats):
         logits, deltas = [], []
         fused = (not torch.is_grad_enabled() and feats[0].is_cuda and feats[0].dtype == torch.float32
                  and not torch.is_autocast_enabled())
+        # [r6] both 1 x 1 heads of a level in ONE streaming product (csrc/pointwise.hip, split output): the 3 x 3 filter's bias + ReLU are applied
+        # where the product fetches its operand (no epilogue pass over the 256-channel map), the map is read once instead of twice; the
+        # objectness comes out with A padded to 4 (pad logit -inf), the deltas with 4 A' = 16 channels - dense channels-last rasters for
+        # ops.rpn_select.  The two heads alone: 248 -> 106 us over the five levels; RPNHead.forward 2.22 - 2.31 -> 2.09 - 2.17 ms (profiles/r06_rpn_heads.txt).
+        packed = fused and FUSED_RPN_HEADS and getattr(ops, "pointwise_ok", None) is not None and all(ops.is_channels_last(x) for x in feats) \
+            and self.conv.weight.shape[0] % 32 == 0
+        if packed:
+            w, b, Ap = self._packed_heads()
+            cin = self.conv.weight.shape[0]
+            for x in feats:
+                t = F.conv2d(x, self.conv.weight, None, 1, 1)
+                if not ops.is_channels_last(t):
+                    t = t.contiguous(memory_format=torch.channels_last)
+                B, _, H, W = t.shape
+                lg = torch.empty(B, H, W, Ap, device=t.device, dtype=torch.float32)
+                dl = torch.empty(B, H, W, 4 * Ap, device=t.device, dtype=torch.float32)
+                ops.rpn_heads_product(t, w, b, self.conv.bias, lg, dl)
+                logits.append(lg.permute(0, 3, 1, 2))
+                deltas.append(dl.permute(0, 3, 1, 2))
+            return logits, deltas
         for x in feats:
             if fused:      # proposals carry no gradient: conv + (bias, ReLU) in one in-place epilogue
                 t = ops.bias_act_(F.conv2d(x, self.conv.weight, None, 1, 1), self.conv.bias)
@@ -69,7 +111,20 @@ class PseudoLabRPN(nn.Module):
         self._anchor_cache = {}
         self._lvl_cache = {}
 
-    def _anchors(self, shapes, device):
+    def _anchors(self, shapes, device, pad_to=None):
+        """pad_to: anchors per location padded (by repeating the last one) to this many - the packed head's layout; a pad anchor is never selected."""
+        if pad_to is not None and pad_to != len(self.ratios):
+            key = (tuple(shapes), str(device), pad_to)
+            if key not in self._anchor_cache:
+                A = len(self.ratios)
+                out = []
+                for a in self._anchors(shapes, device):
+                    a3 = a.view(-1, A, 4)
+                    out.append(torch.cat([a3, a3[:, -1:].expand(-1, pad_to - A, -1)], 1).reshape(-1, 4).contiguous())
+                if out and out[0].is_cuda:
+                    torch.cuda.current_stream(out[0].device).synchronize()
+                self._anchor_cache[key] = out
+            return self._anchor_cache[key]
         key = (tuple(shapes), str(device))
         if key not in self._anchor_cache:
             out = []
@@ -108,10 +163,11 @@ class PseudoLabRPN(nn.Module):
             logits, deltas = self.rpn_head(feats)
 
         dev = feats[0].device
-        anchors = self._anchors([f.shape[-2:] for f in feats], dev)
+        A = len(self.ratios)
+        anchors = self._anchors([f.shape[-2:] for f in feats], dev, pad_to=logits[0].shape[1])      # (the packed head pads A to 4)
         N, L = feats[0].shape[0], len(feats)
         pre, post = self.pre_nms_topk[self.training], self.post_nms_topk[self.training]
-        ks = [min(pre, lg.shape[1] * lg.shape[2] * lg.shape[3]) for lg in logits]
+        ks = [min(pre, A * lg.shape[2] * lg.shape[3]) for lg in logits]
         K = sum(ks)
         key = (tuple(ks), str(dev))
         if self._lvl_cache.get("key") != key:

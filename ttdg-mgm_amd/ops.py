@@ -117,7 +117,7 @@ def linear_raw(x, W, b=None, w_col_off=0, w_ld=None, out=None):
 
 
 def _mm_desc(A, B, out, M, N, K, lda, ldb, ldc, bias=None, res=None, ldres=0, bias2=None, pbias=None, relu=False, prelu=False,
-             a_layout=0, b_layout=0, a_stride=0, a_hw=(0, 0), res_up=False, res_hw=(0, 0), kslices=0, tile=0, second=None):
+             a_layout=0, b_layout=0, a_stride=0, a_hw=(0, 0), res_up=False, res_hw=(0, 0), kslices=0, tile=0, second=None, split=None):
     """(ttdg_mm_t, workspace tensor to keep alive until the launch is enqueued)"""
     ws = torch.empty(kslices * M * N, device=out.device, dtype=torch.float32) if kslices > 1 else None
     # (positional: the field order of ttdg_mm_t; one constructor call instead of 27 attribute stores on the launch path)
@@ -127,6 +127,8 @@ def _mm_desc(A, B, out, M, N, K, lda, ldb, ldc, bias=None, res=None, ldres=0, bi
     if second is not None:          # (A2, B2, lda2, ldb2, K2, stride, (H, W)): a second reduction segment into the same accumulators
         A2, B2, lda2, ldb2, K2, st2, hw2 = second
         d.A2, d.B2, d.lda2, d.ldb2, d.K2, d.a2_stride, d.a2_h, d.a2_w = ptr(A2), ptr(B2), int(lda2), int(ldb2), int(K2), int(st2), int(hw2[0]), int(hw2[1])
+    if split is not None:           # (out2, ldc2, nsplit): columns [nsplit, N) go to out2
+        d.C2, d.ldc2, d.nsplit = ptr(split[0]), int(split[1]), int(split[2])
     return d, ws
 
 
@@ -961,6 +963,17 @@ def _dw_slices(Cout, Cin, M):
     tiles = ((Cout + 63) // 64) * ((Cin + 63) // 64)
     ks = min(M // 256, (512 + tiles - 1) // tiles)
     return ks if ks >= 2 else 0
+
+
+def rpn_heads_product(t, w, b, pbias, logits, deltas):
+    """Both 1 x 1 heads of one RPN level in one launch: t (B, C, H, W) channels-last = the 3 x 3 filter's output WITHOUT its bias,
+    w (Ap + 4 Ap, C) / b the packed head filters (modeling/detector.py: RPNHead._packed_heads), pbias the 3 x 3 filter's bias (applied with the
+    ReLU where the product fetches its operand); logits (B, H, W, Ap) and deltas (B, H, W, 4 Ap) receive the two column groups."""
+    B, Cc, H, W = t.shape
+    M, Ap = B * H * W, logits.shape[-1]
+    N = w.shape[0]
+    with _timed("pointwise_fwd", (4 * (M * Cc + M * N + N * Cc), 2 * M * N * Cc)):
+        mm(t, w, logits, M, N, Cc, Cc, Cc, Ap, bias=b, pbias=pbias, prelu=True, split=(deltas, N - Ap, Ap))
 
 
 class StridedSliceFn(torch.autograd.Function):
