@@ -58,6 +58,8 @@ class RPNHead(nn.Module):
                 w[:A], w[Ap:Ap + 4 * A] = ps[0].view(A, cin), ps[2].view(4 * A, cin)
                 b[:A], b[Ap:Ap + 4 * A] = ps[1], ps[3]
                 b[A:Ap] = float("-inf")
+            if w.is_cuda:
+                torch.cuda.current_stream(w.device).synchronize()      # cached constants may be read from other streams
             c = self.__dict__["_packed"] = (key, w, b, Ap)
         return c[1], c[2], c[3]
 
