@@ -18,7 +18,7 @@ c = json.load(open(os.path.join(go, "trained_census.json")))
 e = json.load(open(os.path.join(go, "census_exchangeability.json")))
 rec = dict(head=head, passed=[l for l in tail if " passed" in l or " failed" in l][-1:],
            trajectory_worst_fraction_of_bound=t.get("worst_fraction_of_bound"), additive_worst_fraction=t.get("additive_worst_fraction"),
-           dice_device=t.get("dice_device"), dice_host=t.get("dice_host"),
+           dice_device=t.get("dice_device"), dice_host=t.get("dice_host"), outside_frozen_bound=t.get("outside_frozen_bound"),
            census=dict(rank_sum_z_objective=c["rank_sum_z_objective"], rank_sum_z_loss=c["rank_sum_z_loss"],
                        outside_reference_min_max=c["outside_reference_min_max"], min_max_checks=c["min_max_checks"],
                        outside_round4_bound=c["outside_round4_bound"], stage_states_defined=c["stage_states_defined_by_the_reference"],
