@@ -120,6 +120,7 @@ def run(cfg, cpu0, gpu0, batches, K, f64_steps=None, log=print):
             v = row["groups"][g]
             v["host32_minus_host64"] = max(float((th_h[n].double() - t64[n]).abs().max()) for n in ns)
             v["device_minus_host64"] = max(float((th_d[n].double() - t64[n]).abs().max()) for n in ns)
+            v["device_minus_host64_at"] = max(ns, key=lambda n: float((th_d[n].double() - t64[n]).abs().max()))      # [r6] which tensor carries the distance
         log("step %d: loss host %.6f device %.6f float64 %.6f | per group |host32-host64|, |device-host64|, |device-host32| (units of 1e-9): %s" %
             (row["step"], row["loss_host"], row["loss_device"], loss64,
              {g: tuple(round(v.get(x, float("nan")) * 1e9, 1) for x in ("host32_minus_host64", "device_minus_host64", "device_minus_host")) for g, v in row["groups"].items()}))
