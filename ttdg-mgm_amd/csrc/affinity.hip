@@ -68,11 +68,11 @@ __global__ __launch_bounds__(256) void affinity_fwd_kernel(const float* __restri
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   const int kbeg = blockIdx.z * kslice, kend = kbeg + kslice;
 
-  float acc[4][4];
+  float acc[4][4], tot[4][4];
 #pragma unroll
   for (int a = 0; a < 4; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+    for (int b = 0; b < 4; ++b) acc[a][b] = tot[a][b] = 0.f;
   float pa[2] = {0.f, 0.f}, qa[2] = {0.f, 0.f};
 
   const int lrow = tid >> 3, lk = (tid & 7) * 4;  // staging map: 8 lanes x float4 cover one 32-wide row
@@ -140,7 +140,19 @@ __global__ __launch_bounds__(256) void affinity_fwd_kernel(const float* __restri
           acc[a][b] = fma_abs(w.w, x1.y, acc[a][b]);
         }
     }
+    if (((k0 - kbeg) / BK & 3) == 3) {
+      // [r6] every 128 hidden units the running sums move to a second register set and the chains restart (as in pair_stage.hip: a 512-long fp32
+      // chain per entry lost 2 - 3 x what the fp32 reference loses)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { tot[a][b] += acc[a][b]; acc[a][b] = 0.f; }
+    }
   }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] += tot[a][b];
 #undef AFF_LOAD
   // row sums of the linear half: the 8 lanes that staged a row hold its partial dot products
 #pragma unroll

@@ -216,11 +216,11 @@ __global__ __launch_bounds__(256) void pair_stage_fwd_kernel(const float* __rest
   // 64-deep slabs, double buffered in LDS AND in registers: slab s + 1 is requested from L2 before slab s is consumed and
   // stored into the other LDS buffer after it - one barrier per slab, the memory round trip hidden behind ~900 VALU
   // instructions; the loop body is instantiated per (ta, tb): no guards inside.
-  float acc[4][4];
+  float acc[4][4], tot[4][4];
 #pragma unroll
   for (int x = 0; x < 4; ++x)
 #pragma unroll
-    for (int y = 0; y < 4; ++y) acc[x][y] = 0.f;
+    for (int y = 0; y < 4; ++y) acc[x][y] = tot[x][y] = 0.f;
   float pa[4] = {0.f, 0.f, 0.f, 0.f}, qa[4] = {0.f, 0.f, 0.f, 0.f};
   const int lrow = tid >> 4, lk = (tid & 15) * 4;         // staging map: 16 lanes x float4 cover one 64-wide row, 16 rows per pass
   float4 pv[4], qv[4], wv;
@@ -259,8 +259,20 @@ __global__ __launch_bounds__(256) void pair_stage_fwd_kernel(const float* __rest
 #undef PS_CASE
     }
     if (sl + 1 < nslab) deposit(cur ^ 1);
+    if ((sl & 1) == 1) {
+      // [r6] every 128 hidden units the running sums move to a second register set and the chains restart: a 512-long fp32 chain per entry lost
+      // ~3 x what the fp32 reference loses on the same inputs (|Wds - fp64| 1.9e-6 against 4.6e-7, dM 2e-5 against 6e-6: tools/probe_pair_stage_sizes.py)
+#pragma unroll
+      for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) { tot[x][y] += acc[x][y]; acc[x][y] = 0.f; }
+    }
     __syncthreads();
   }
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) acc[x][y] += tot[x][y];
 #pragma unroll
   for (int h = 0; h < 4; ++h) {
 #pragma unroll
