@@ -291,7 +291,7 @@ def kernel_rooflines(run):
             e["work"] += sum(4 * H * r * c for r, c in _pairs(meta))
         elif nm == "pair_stage_bwd":
             e["work"] += 2 * sum(8 * r * c for r, c in _pairs(meta))
-        elif nm in ("sgd", "bias_act", "relu_bwd", "roi_align_nhwc", "row_scale_multi"):
+        elif nm in ("sgd", "bias_act", "relu_bwd", "roi_align_nhwc", "row_scale_multi", "rpn_heads"):
             e["work"] += meta
         elif nm in ("pointwise_fwd", "pointwise_dx", "pointwise_dw"):      # meta = (algorithmic bytes, FLOPs) of the product
             e["work"] += meta[1]
@@ -302,7 +302,7 @@ def kernel_rooflines(run):
         return _o.KERNEL_TIMER_EVERY if nm in _o.KERNEL_TIMER_SAMPLED else 1
     out = []
     for nm, e in acc.items():
-        hbm = nm in ("sinkhorn_pairs_fwd", "sinkhorn_pairs_bwd", "sgd", "pair_stage_bwd", "bias_act", "relu_bwd", "roi_align_nhwc", "row_scale_multi")
+        hbm = nm in ("sinkhorn_pairs_fwd", "sinkhorn_pairs_bwd", "sgd", "pair_stage_bwd", "bias_act", "relu_bwd", "roi_align_nhwc", "row_scale_multi", "rpn_heads")
         ach = e["work"] / e["t"] / (1e9 if hbm else 1e12)
         peak = HBM_PEAK_GBS if hbm else FP32_PEAK_TFLOPS
         r = {"kernel": {"gagm": "gagm_kernel", "sgd": "sgd_multi_tensor_kernel", "affinity_fwd": "affinity_fwd_kernel",
@@ -310,6 +310,7 @@ def kernel_rooflines(run):
                         "sinkhorn_pairs_bwd": "sinkhorn_pairs_bwd_kernel", "pair_stage_fwd": "pair_stage_fwd_kernel",
                         "pair_stage_bwd": "pair_stage_bwd_kernel", "bias_act": BIAS_ACT_KERNEL, "relu_bwd": "relu_bwd_kernel",
                         "roi_align_nhwc": "roi_align_nhwc4_kernel", "row_scale_multi": "row_scale_multi_kernel",
+                        "rpn_heads": "mm_kernel (RPN objectness + anchor-delta heads, one product per level, split output)",
                         "pointwise_fwd": "mm_kernel (1x1 convolutions, forward + fused epilogue)", "pointwise_dx": "mm_kernel (1x1 convolutions, dX)",
                         "pointwise_dw": "mm_kernel + mm_reduce_kernel (1x1 convolutions, dW over pixel slices)"}[nm],
              "bound": "hbm" if hbm else "mfma", "achieved": ach, "peak": peak, "unit": "GB/s" if hbm else "TFLOP/s", "frac": ach / peak,
@@ -344,6 +345,8 @@ def pmc_traffic(stamp_name):
              "pair_stage_bwd": ("pair_stage_bwd", False), "bias_act": ("bias_act", True), "relu_bwd": ("relu_bwd", True),
              "roi_align_nhwc": ("roi_align_nhwc", True), "row_scale_multi": ("row_scale_multi", True),
              "pointwise_fwd": ("mm_kernel", True), "pointwise_dx": ("mm_kernel", True), "pointwise_dw": ("mm_kernel", True)}
+    if stamp_name not in names:          # (no separate PMC record: the RPN heads' launches are mm_kernel instantiations inside the pointwise record)
+        return None
     kernel, streaming = names[stamp_name]
     import glob
     for f in sorted((os.path.basename(x) for x in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_pmc.json"))), reverse=True):   # newest round first

@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void pair_stage_fwd_kernel(const float* __rest
     L[i] = (p < r && lane < c) ? mat[p * PS_LDM + lane] : -INFINITY;
     f[i] = 0.f;
   }
-  float g = 0.f, fd = 0.f;
+  float g = 0.f, fd = 0.f, tdn = SK_DUMMY;
   int buf = 0;
   for (int it = 0; it < iters; ++it) {
     if ((it & 1) == 0) {
@@ -324,11 +324,15 @@ __global__ __launch_bounds__(256) void pair_stage_fwd_kernel(const float* __rest
         const float td = lane < c ? -g : -INFINITY;
         const float dm = wave_max_f32_dpp(td);
         const float ds = wave_sum_f32_dpp(fast_exp2(td - dm));
-        fd = SK_DUMMY + dm + fast_log2(ds);
+        // [r6] the dummy row's normalised value -(dm + log2 ds) is kept as it is for the column sweep: rounds 3-5 formed fd = SK_DUMMY + dm + log2 ds
+        // and read it back as SK_DUMMY - fd - a round trip through |fd| ~ 144 that put ulp(144) = 1.5e-5 (relative) on the dummy mass of every
+        // column sum in every sweep (ragged pairs lost 4 x what the fp32 reference loses, equal-size pairs 2 x: tools/probe_pair_stage_sizes.py)
+        tdn = -(dm + fast_log2(ds));
+        fd = SK_DUMMY - tdn;
         if (tid == 0) plog[it * potld + r] = fd;
       }
     } else {
-      const float td0 = (mult > 0) ? SK_DUMMY - fd : -INFINITY;
+      const float td0 = (mult > 0) ? tdn : -INFINITY;
       // NR is chosen from r alone (not from this wavefront's row count): all four wavefronts take the same instantiation and
       // meet at the same barriers
       const int nrm = (r + PS_WAVES - 1) / PS_WAVES;

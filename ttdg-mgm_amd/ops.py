@@ -972,7 +972,7 @@ def rpn_heads_product(t, w, b, pbias, logits, deltas):
     B, Cc, H, W = t.shape
     M, Ap = B * H * W, logits.shape[-1]
     N = w.shape[0]
-    with _timed("pointwise_fwd", (4 * (M * Cc + M * N + N * Cc), 2 * M * N * Cc)):
+    with _timed("rpn_heads", 4 * (M * Cc + M * N + N * Cc)):          # 20 output columns: a streaming read of the map, HBM-bound (its own stamp)
         mm(t, w, logits, M, N, Cc, Cc, Cc, Ap, bias=b, pbias=pbias, prelu=True, split=(deltas, N - Ap, Ap))
 
 
