@@ -99,26 +99,29 @@ __device__ void sk_forward(const SkProb& pb, float* smem, int iters) {
       for (int p = sgi; p < nlines; p += nsg) {
         const bool dum = (p == r);
         float m = -INFINITY;
+        // [r6] the dummy row is swept WITHOUT its constant (t = -g_q; the fill cancels in L - f): f[r] holds lse_q(-g_q), the logged potential is
+        // SK_DUMMY + that.  Rounds 1-5 formed SK_DUMMY - g_q and SK_DUMMY - f[r]: two round trips through |144| per sweep pair, ulp(144) = 1.5e-5
+        // relative on the dummy mass of every column sum (profiles/r06_pair_stage_accuracy.txt).
         for (int q = sl; q < c; q += sg) {
-          const float t = (dum ? SK_DUMMY : (kLds ? mat[p * ldm + q] : sk_load(pb, p, q))) - g[q];
+          const float t = (dum ? 0.f : (kLds ? mat[p * ldm + q] : sk_load(pb, p, q))) - g[q];
           m = fmaxf(m, t);
         }
         m = sub_max(m, sg);
         float s = 0.f;
         for (int q = sl; q < c; q += sg) {
-          const float t = (dum ? SK_DUMMY : (kLds ? mat[p * ldm + q] : sk_load(pb, p, q))) - g[q];
+          const float t = (dum ? 0.f : (kLds ? mat[p * ldm + q] : sk_load(pb, p, q))) - g[q];
           s += fast_exp2(t - m);
         }
         s = sub_sum(s, sg);
         if (sl == 0) {
           const float v = m + fast_log2(s);
           f[p] = v;
-          if (pb.pot) pb.pot[it * pb.potld + p] = v;
+          if (pb.pot) pb.pot[it * pb.potld + p] = dum ? SK_DUMMY + v : v;
         }
       }
     } else {
       // cols: g_q = lse over the r real rows and `mult` copies of the dummy row
-      const float td0 = SK_DUMMY - f[r];
+      const float td0 = -f[r];                               // (f[r] is the dummy row's potential without the fill: see the row sweep)
       for (int q = sgi; q < c; q += nsg) {
         float m = (mult > 0) ? td0 : -INFINITY;
         for (int p = sl; p < r; p += sg) m = fmaxf(m, (kLds ? mat[p * ldm + q] : sk_load(pb, p, q)) - f[p]);
