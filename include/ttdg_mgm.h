@@ -120,7 +120,9 @@ int ttdg_affinity_pairwise_bwd(const float* P, const float* Q, const float* w2, 
  * dummy rows (-100), `iters` alternating row/col normalisations at temperature tau, exp; the
  * result is written to Wds[a,b] and (a != b) transposed to Wds[b,a]  (Wds is M x M, fully written).
  * pot receives the per-sweep potentials needed by the backward ((npairs, iters, cmax+1) floats,
- * cmax = max n_g); pass NULL when no backward will follow. */
+ * cmax = max n_g; log2 domain; a row sweep's entry r is the dummy row's potential WITHOUT the constant fill, i.e.
+ * lse_q(-g_q) [0.1.2: rounds 1-5 logged it with the fill, -100 log2(e) + that]; the buffer is opaque to callers: it only
+ * travels from a forward to the matching backward of the same library version); pass NULL when no backward will follow. */
 int ttdg_sinkhorn_pairs_fwd(const float* part, int ksplit, const float* b2, ttdg_graphs_t gr, float tau, int iters,
                             float* Wds, float* pot, ttdg_stream_t stream);
 /* bwd: dWds (M x M; only blocks a<b are read, as the loss only touches those,

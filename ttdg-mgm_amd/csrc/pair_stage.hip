@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void pair_stage_fwd_kernel(const float* __rest
     L[i] = (p < r && lane < c) ? mat[p * PS_LDM + lane] : -INFINITY;
     f[i] = 0.f;
   }
-  float g = 0.f, fd = 0.f, tdn = SK_DUMMY;
+  float g = 0.f, tdn = SK_DUMMY;
   int buf = 0;
   for (int it = 0; it < iters; ++it) {
     if ((it & 1) == 0) {
@@ -328,8 +328,7 @@ __global__ __launch_bounds__(256) void pair_stage_fwd_kernel(const float* __rest
         // and read it back as SK_DUMMY - fd - a round trip through |fd| ~ 144 that put ulp(144) = 1.5e-5 (relative) on the dummy mass of every
         // column sum in every sweep (ragged pairs lost 4 x what the fp32 reference loses, equal-size pairs 2 x: tools/probe_pair_stage_sizes.py)
         tdn = -(dm + fast_log2(ds));
-        fd = SK_DUMMY - tdn;
-        if (tid == 0) plog[it * potld + r] = fd;
+        if (tid == 0) plog[it * potld + r] = -tdn;       // logged without the fill: the backward forms exp2(-x - g) with no round trip either
       }
     } else {
       const float td0 = (mult > 0) ? tdn : -INFINITY;
@@ -455,7 +454,7 @@ __global__ __launch_bounds__(256) void pair_stage_bwd_kernel(const float* __rest
     const int kf = rows ? k : k - 1, kg = rows ? k - 1 : k;      // logs holding f / g as of just after sweep k
     const float gq = (kg >= 0 && lane < c) ? plog[kg * potld + lane] : 0.f;
     const float fdum = (dummy && kf >= 0) ? plog[kf * potld + r] : 0.f;
-    const float ed = (dummy && lane < c) ? fast_exp2(SK_DUMMY - fdum - gq) : 0.f;
+    const float ed = (dummy && lane < c) ? fast_exp2(-fdum - gq) : 0.f;          // (fdum: logged without the fill; kf >= 0 for every k >= 0)
     if (rows) {
       // branch-free over the rows a wavefront owns (rows beyond r carry dY = 0, L = -inf: their update is 0 * S)
       if (nrw <= 4) ps_bwd_rows<4>(L, dY, plog + kf * potld, gq, r, wave);

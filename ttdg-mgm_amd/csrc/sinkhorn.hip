@@ -376,7 +376,7 @@ __global__ __launch_bounds__(SKR_THREADS) void sinkhorn_pairs_fwd_scale_kernel(c
     for (int j = 0; j < 4; ++j) A[i][j] *= u;
   }
   const float kd = mult > 0 ? 1.f / (float)c : 0.f;                                   // the dummy row of K: uniform
-  const float fd0 = SK_DUMMY + fast_log2((float)c);
+  const float fd0 = fast_log2((float)c);             // [r6] the dummy row's potential is logged WITHOUT the constant fill (include/ttdg_mgm.h: pot)
   if (pt && iters > 0 && mult > 0 && tid == 0) pt[r] = fd0;
   if (__ballot(bad) != 0ull && lane == 0) s_bad = 1;
   float usc[SKR_RW];                     // u_p of this wavefront's rows (wavefront-uniform: SGPRs)
@@ -608,7 +608,7 @@ __device__ void sk_backward(const SkProb& pb, const float* __restrict__ pt, int 
         DY(p, q) -= fast_exp2(LV(p, q) - f[p] - g[q]) * ls[p];
       }
       if (mult > 0)
-        for (int q = tid; q < c; q += nthr) dd[q] -= fast_exp2(SK_DUMMY - f[r] - g[q]) * ls[r];
+        for (int q = tid; q < c; q += nthr) dd[q] -= fast_exp2(-f[r] - g[q]) * ls[r];
     } else {
       for (int q = sgi; q < c; q += nsg) {
         float s = 0.f;
@@ -622,7 +622,7 @@ __device__ void sk_backward(const SkProb& pb, const float* __restrict__ pt, int 
         DY(p, q) -= fast_exp2(LV(p, q) - f[p] - g[q]) * ls[q];
       }
       if (mult > 0)
-        for (int q = tid; q < c; q += nthr) dd[q] -= fast_exp2(SK_DUMMY - f[r] - g[q]) * ls[q];
+        for (int q = tid; q < c; q += nthr) dd[q] -= fast_exp2(-f[r] - g[q]) * ls[q];
     }
     __syncthreads();
   }
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(SKR_THREADS) void sinkhorn_pairs_bwd_reg_kernel(con
     if ((k & 1) == 0) { SKR_LOAD_POT(k, (k >= 1 ? k - 1 : -1)) } else { SKR_LOAD_POT(k - 1, k) }
     float de[4];   // exp(y) of the dummy row in the lane's columns
 #pragma unroll
-    for (int j = 0; j < 4; ++j) de[j] = (mult > 0 && q0 + j < c) ? fast_exp2(SK_DUMMY - fd - g[j]) : 0.f;
+    for (int j = 0; j < 4; ++j) de[j] = (mult > 0 && q0 + j < c) ? fast_exp2(-fd - g[j]) : 0.f;      // (fd: logged without the fill)
     float ls[4] = {0.f, 0.f, 0.f, 0.f};
     const bool rows = (k & 1) == 0;
     if (!rows) {

@@ -99,8 +99,7 @@ __device__ void sk_forward(const SkProb& pb, float* smem, int iters) {
       for (int p = sgi; p < nlines; p += nsg) {
         const bool dum = (p == r);
         float m = -INFINITY;
-        // [r6] the dummy row is swept WITHOUT its constant (t = -g_q; the fill cancels in L - f): f[r] holds lse_q(-g_q), the logged potential is
-        // SK_DUMMY + that.  Rounds 1-5 formed SK_DUMMY - g_q and SK_DUMMY - f[r]: two round trips through |144| per sweep pair, ulp(144) = 1.5e-5
+        // [r6] the dummy row is swept WITHOUT its constant (t = -g_q; the fill cancels in L - f): f[r] holds lse_q(-g_q), and that is what is logged.  Rounds 1-5 formed SK_DUMMY - g_q and SK_DUMMY - f[r]: two round trips through |144| per sweep pair, ulp(144) = 1.5e-5
         // relative on the dummy mass of every column sum (profiles/r06_pair_stage_accuracy.txt).
         for (int q = sl; q < c; q += sg) {
           const float t = (dum ? 0.f : (kLds ? mat[p * ldm + q] : sk_load(pb, p, q))) - g[q];
@@ -116,7 +115,7 @@ __device__ void sk_forward(const SkProb& pb, float* smem, int iters) {
         if (sl == 0) {
           const float v = m + fast_log2(s);
           f[p] = v;
-          if (pb.pot) pb.pot[it * pb.potld + p] = dum ? SK_DUMMY + v : v;
+          if (pb.pot) pb.pot[it * pb.potld + p] = v;       // (the dummy row's entry: its potential without the fill, as every backward reads it)
         }
       }
     } else {
