@@ -1890,6 +1890,23 @@ def test_channels_last_layout_is_the_same_arithmetic(dev):
         (rows * up).sum().backward()
         res[cl] = (rows.detach().clone(), [f.grad.clone() for f in fs], [f.grad.is_contiguous(memory_format=CL) for f in fs])
     assert torch.equal(res[True][0], res[False][0]) and all(torch.equal(a, c) for a, c in zip(res[True][1], res[False][1])) and all(res[True][2])
+    # [r6] no node selected in the whole batch (detections too small to contain an FPN point: a random-initialised detector produced that on one
+    # fresh box, profiles/r06_gpu_suite_box13_failed.txt): empty index tensors carry null pointers - empty rows, zero gradients, no error
+    for cl in (False, True):
+        fs = [f.clone().contiguous(memory_format=CL if cl else torch.contiguous_format).requires_grad_() for f in feats]
+        e32 = torch.empty(0, dtype=torch.int32, device=dev)
+        rows = ops.NodeGatherFn.apply(e32, e32, *fs)
+        assert rows.shape == (0, 16)
+        (rows.sum() + sum(f.sum() * 0 for f in fs)).backward()
+        assert all(f.grad is not None and not bool(f.grad.any()) for f in fs)
+    # the same for an empty ROI set / empty candidate set
+    maps0 = [synth.normal(g, (2, 32, 16 // k, 16 // k), 1.0).to(dev) for k in (1, 2)]
+    r0 = torch.empty(0, 5, device=dev)
+    assert ops.roi_align_multilevel(maps0, r0, [4, 8], 7).shape == (0, 32, 7, 7)
+    assert ops.roi_align_multilevel(maps0, r0, [4, 8], 7, nhwc=ops.to_nhwc(maps0)).shape == (0, 32, 7, 7)
+    b0, s0 = ops.box_inference(torch.empty(0, 3, device=dev), torch.empty(0, 8, device=dev), torch.empty(0, 5, device=dev),
+                               ops.image_sizes_tensor([(64, 64)], dev), 2, (10.0, 10.0, 5.0, 5.0), 0.05)
+    assert b0.shape == (0, 2, 4) and s0.shape == (0, 2)
     # pooler: channels-last maps are used as they are
     maps = [synth.normal(g, (2, 32, 16 // k, 16 // k), 1.0).to(dev) for k in (1, 2)]
     rois = torch.tensor([[0, 1.0, 2.0, 30.0, 40.0], [1, 5.0, 5.0, 20.0, 12.0], [1, 0.0, 0.0, 63.0, 63.0]], device=dev)

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void roi_align_fwd_kernel(const float* __restr
 
 extern "C" int ttdg_roi_align_fwd(const float* feat, int B, int C, int H, int W, const float* rois, int R, float scale,
                                   int P, float* out, ttdg_stream_t stream) {
-  TTDG_REQUIRE(feat && rois && out && R >= 0 && C > 0 && P > 0, "roi_align: bad arguments");
+  TTDG_REQUIRE(feat && R >= 0 && (R == 0 || (rois && out)) && C > 0 && P > 0, "roi_align: bad arguments");      // (R == 0: empty tensors carry null pointers)
   if (R == 0) return 0;
   const long total = (long)R * C * P * P;
   const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256) void box_inference_kernel(const float* __restr
 extern "C" int ttdg_box_inference(const float* logits, const float* deltas, const float* rois, const float* sizes, int N,
                                   int C, float wx, float wy, float ww, float wh, float score_thresh, float* boxes,
                                   float* scores, ttdg_stream_t stream) {
-  TTDG_REQUIRE(logits && deltas && rois && sizes && boxes && scores && N >= 0 && C >= 1, "box_inference: bad arguments");
+  TTDG_REQUIRE(N >= 0 && (N == 0 || (logits && deltas && rois && sizes && boxes && scores)) && C >= 1, "box_inference: bad arguments");
   if (N == 0) return 0;
   hipLaunchKernelGGL(box_inference_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, deltas, rois, sizes, N,
                      C, wx, wy, ww, wh, score_thresh, boxes, scores);
@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restric
 
 extern "C" int ttdg_paste_masks(const float* masks, const float* boxes, int R, int S, int H, int W, float threshold,
                                 unsigned char* out, ttdg_stream_t stream) {
-  TTDG_REQUIRE(masks && boxes && out && R >= 0 && S > 0 && H > 0 && W > 0, "paste_masks: bad arguments");
+  TTDG_REQUIRE(R >= 0 && (R == 0 || (masks && boxes && out)) && S > 0 && H > 0 && W > 0, "paste_masks: bad arguments");
   if (R == 0) return 0;
   const int bx = (H * W + 255) / 256 < 64 ? (H * W + 255) / 256 : 64;
   hipLaunchKernelGGL(paste_masks_kernel, dim3(bx, R), dim3(256), 0, (hipStream_t)stream, masks, boxes, R, S, H, W, threshold, out);
@@ -1294,7 +1294,7 @@ static int g_roi_nhwc_xcd = 0;      // 1 = XCD x owns a contiguous eighth of the
                                     // profiles/r03_roi_align_ab.txt - the pooler is not bound by fabric traffic); ttdg_debug_set_roi_align_sliced(mode | 16) selects 1
 extern "C" int ttdg_roi_align_multilevel_nhwc(ttdg_fpn_t fp, ttdg_levels_t lv, const float* rois, int R, int P, float canonical_size,
                                               int canonical_level, int min_level, float* out, ttdg_stream_t stream) {
-  TTDG_REQUIRE(rois && out && R >= 0 && P > 0 && P <= RA_MAXP && fp.n >= 1 && fp.n <= TTDG_MAX_LEVELS && fp.C > 0 && lv.n == fp.n,
+  TTDG_REQUIRE(R >= 0 && (R == 0 || (rois && out)) && P > 0 && P <= RA_MAXP && fp.n >= 1 && fp.n <= TTDG_MAX_LEVELS && fp.C > 0 && lv.n == fp.n,
                "roi_align_multilevel_nhwc: bad arguments");
   if (R == 0) return 0;
   bool aligned = (fp.C & 3) == 0;
@@ -1333,7 +1333,7 @@ extern "C" int ttdg_debug_set_roi_align_sliced(int on) {
 
 extern "C" int ttdg_roi_align_multilevel(ttdg_fpn_t fp, ttdg_levels_t lv, const float* rois, int R, int P, float canonical_size,
                                          int canonical_level, int min_level, float* out, ttdg_stream_t stream) {
-  TTDG_REQUIRE(rois && out && R >= 0 && P > 0 && fp.n >= 1 && fp.n <= TTDG_MAX_LEVELS && fp.C > 0 && lv.n == fp.n,
+  TTDG_REQUIRE(R >= 0 && (R == 0 || (rois && out)) && P > 0 && fp.n >= 1 && fp.n <= TTDG_MAX_LEVELS && fp.C > 0 && lv.n == fp.n,
                "roi_align_multilevel: bad arguments");
   if (R == 0) return 0;
   if (g_roi_align_mode == 2 && P <= RA_MAXP) {   // separable table kernel: one workgroup per (ROI, channel slice = XCD)

@@ -167,7 +167,7 @@ static int check_fpn(const ttdg_fpn_t& fp) {
 
 extern "C" int ttdg_node_gather_fwd(ttdg_fpn_t fp, const int32_t* img, const int32_t* pid, int n, float* out,
                                     ttdg_stream_t stream) {
-  TTDG_REQUIRE(img && pid && out && n >= 0, "node_gather_fwd: bad arguments");
+  TTDG_REQUIRE(n >= 0 && (n == 0 || (img && pid && out)), "node_gather_fwd: bad arguments");      // n == 0 (no node selected in the whole batch): empty tensors carry null pointers
   if (int e = check_fpn(fp)) return e;
   if (n == 0) return 0;
   hipLaunchKernelGGL((node_gather_kernel<false>), dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, fp, img, pid, n, out);
@@ -176,7 +176,7 @@ extern "C" int ttdg_node_gather_fwd(ttdg_fpn_t fp, const int32_t* img, const int
 
 extern "C" int ttdg_node_gather_bwd(ttdg_fpn_t dfp, const int32_t* img, const int32_t* pid, int n, const float* dout,
                                     ttdg_stream_t stream) {
-  TTDG_REQUIRE(img && pid && dout && n >= 0, "node_gather_bwd: bad arguments");
+  TTDG_REQUIRE(n >= 0 && (n == 0 || (img && pid && dout)), "node_gather_bwd: bad arguments");      // n == 0 (no node selected in the whole batch): empty tensors carry null pointers
   if (int e = check_fpn(dfp)) return e;
   if (n == 0) return 0;
   hipLaunchKernelGGL((node_gather_kernel<true>), dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, dfp, img, pid, n,
@@ -186,7 +186,7 @@ extern "C" int ttdg_node_gather_bwd(ttdg_fpn_t dfp, const int32_t* img, const in
 
 extern "C" int ttdg_node_gather_fwd_nhwc(ttdg_fpn_t fp, const int32_t* img, const int32_t* pid, int n, float* out,
                                          ttdg_stream_t stream) {
-  TTDG_REQUIRE(img && pid && out && n >= 0, "node_gather_fwd_nhwc: bad arguments");
+  TTDG_REQUIRE(n >= 0 && (n == 0 || (img && pid && out)), "node_gather_fwd_nhwc: bad arguments");      // n == 0 (no node selected in the whole batch): empty tensors carry null pointers
   if (int e = check_fpn(fp)) return e;
   if (n == 0) return 0;
   hipLaunchKernelGGL((node_gather_nhwc_kernel<false>), dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, fp, img, pid, n, out);
@@ -195,7 +195,7 @@ extern "C" int ttdg_node_gather_fwd_nhwc(ttdg_fpn_t fp, const int32_t* img, cons
 
 extern "C" int ttdg_node_gather_bwd_nhwc(ttdg_fpn_t dfp, const int32_t* img, const int32_t* pid, int n, const float* dout,
                                          ttdg_stream_t stream) {
-  TTDG_REQUIRE(img && pid && dout && n >= 0, "node_gather_bwd_nhwc: bad arguments");
+  TTDG_REQUIRE(n >= 0 && (n == 0 || (img && pid && dout)), "node_gather_bwd_nhwc: bad arguments");      // n == 0 (no node selected in the whole batch): empty tensors carry null pointers
   if (int e = check_fpn(dfp)) return e;
   if (n == 0) return 0;
   hipLaunchKernelGGL((node_gather_nhwc_kernel<true>), dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, dfp, img, pid, n,
